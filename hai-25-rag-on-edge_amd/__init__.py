@@ -1,0 +1,334 @@
+"""hai-25-rag-on-edge_amd -- MI355X (gfx950) backend for the distance + top-k hot path.
+
+The product is ``libvsearch_hip.so`` (HIP kernels + C ABI, sources in ``csrc/``,
+interface in ``include/vsearch.h``).  This Python layer is plumbing: a ctypes
+binding of that ABI and thin classes that mirror the reference's C++ operator
+interfaces so that tests read like the reference's own call sites:
+
+* :class:`BruteForceIndex`  <- run_benchmark's query loop (cpu/cpu_baseline.cpp:209-254)
+  and QnnRunner::executeBatchRaw (qidk_*/android/app/main/jni/QnnRunner.h:28-39)
+* :class:`IVFIndex`         <- class IVFIndex (qidk_ivf/android/app/main/jni/IVFIndex.h:14-97)
+
+There is no CPU fallback: every search call goes through the HIP library and
+raises :class:`VSearchError` if it is missing or no GPU is present.
+
+The directory name contains '-', so import it through ``__graft_entry__.load_package()``
+(or ``importlib``) under the module name ``hai_25_rag_on_edge_amd``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvsearch_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+VS_OK = 0
+METRIC_L2 = 0
+METRIC_IP = 1
+MAX_BATCH = 32
+
+
+class VSearchError(RuntimeError):
+    def __init__(self, status: int, msg: str):
+        super().__init__(f"vsearch error {status}: {msg}")
+        self.status = status
+
+
+class Timing(C.Structure):
+    """vs_timing (include/vsearch.h) == IVFIndex::SearchTiming (IVFIndex.h:31-36) + extras."""
+    _fields_ = [
+        ("centroid_search_ms", C.c_double),
+        ("gather_ms", C.c_double),
+        ("fine_search_ms", C.c_double),
+        ("total_ms", C.c_double),
+        ("h2d_ms", C.c_double),
+        ("d2h_ms", C.c_double),
+        ("tie_resolve_ms", C.c_double),
+        ("tie_queries", C.c_int64),
+    ]
+
+
+def build(verbose: bool = False, targets=("lib",)) -> str:
+    """Compile csrc/ for gfx950 with hipcc (cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC, *targets]
+    subprocess.check_call(cmd, stdout=None if verbose else subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load libvsearch_hip.so (never falls back to anything else)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VSearchError(-3, f"{LIB_PATH} not built; run __graft_entry__.build() / make -C {CSRC}")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, f32p = C.c_void_p, C.c_int, C.c_int64, C.c_void_p
+    sig = {
+        "vs_version": (C.c_char_p, []),
+        "vs_last_error": (C.c_char_p, []),
+        "vs_device_count": (i32, []),
+        "vs_fvecs_shape": (i32, [C.c_char_p, C.POINTER(i64), C.POINTER(i32)]),
+        "vs_fvecs_read": (i32, [C.c_char_p, vp, i64, C.POINTER(i64), C.POINTER(i32)]),
+        "vs_ivecs_read": (i32, [C.c_char_p, vp, i64, C.POINTER(i64), C.POINTER(i32)]),
+        "vs_fvecs_write": (i32, [C.c_char_p, vp, i64, i32]),
+        "vs_ivecs_write": (i32, [C.c_char_p, vp, i64, i32]),
+        "vs_results_write": (i32, [C.c_char_p, vp, vp, i64, i32, i32]),
+        "vs_synth_sift": (i32, [vp, i64, i64, i32, C.c_uint64]),
+        "vs_select_topk_slots": (i32, [vp, vp, i64, i32, vp, vp]),
+        "vs_bf_create": (i32, [vp, i64, i32, i32, i32, i64, C.POINTER(vp)]),
+        "vs_set_batch": (i32, [vp, i32]),
+        "vs_bf_search": (i32, [vp, vp, i64, i32, vp, vp, C.POINTER(Timing)]),
+        "vs_bf_search_dev": (i32, [vp, vp, i32, i32, vp, vp, vp, vp]),
+        "vs_bf_scores_dev": (i32, [vp, vp, i32, vp, i64, vp]),
+        "vs_ivf_load": (i32, [C.c_char_p, i32, i32, i32, C.POINTER(vp)]),
+        "vs_ivf_create": (i32, [vp, i64, i32, vp, i32, vp, vp, i32, i32, i32, C.POINTER(vp)]),
+        "vs_ivf_save": (i32, [vp, C.c_char_p]),
+        "vs_ivf_search": (i32, [vp, vp, i64, i32, i32, vp, vp, C.POINTER(i64), C.POINTER(Timing)]),
+        "vs_ivf_search_dev": (i32, [vp, vp, i32, i32, i32, vp, vp, vp]),
+        "vs_topk_merge_dev": (i32, [vp, vp, i32, i32, i32, i64, i32, vp, vp, vp, vp]),
+        "vs_prof_enable": (i32, [vp, i32]),
+        "vs_prof_read": (i32, [vp, i32, C.POINTER(C.c_double), C.POINTER(i64)]),
+        "vs_index_rows": (i64, [vp]),
+        "vs_index_dim": (i32, [vp]),
+        "vs_index_nlist": (i32, [vp]),
+        "vs_destroy": (None, [vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    L._vs_signatures = sig
+    _lib = L
+    return L
+
+
+def exported_symbols():
+    """Names declared in include/vsearch.h that this binding expects."""
+    return sorted(lib()._vs_signatures.keys())
+
+
+def _check(rc: int):
+    if rc != VS_OK:
+        raise VSearchError(rc, lib().vs_last_error().decode(errors="replace"))
+
+
+def _p(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _f32c(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def device_count() -> int:
+    return int(lib().vs_device_count())
+
+
+# ------------------------------------------------------------------ file formats
+def read_fvecs(path: str) -> np.ndarray:
+    """read_fvecs (cpu_baseline.cpp:31-58) through the C ABI."""
+    L = lib()
+    rows, dim = C.c_int64(0), C.c_int(0)
+    _check(L.vs_fvecs_shape(path.encode(), C.byref(rows), C.byref(dim)))
+    out = np.empty((rows.value, max(dim.value, 0)), dtype=np.float32)
+    if out.size:
+        _check(L.vs_fvecs_read(path.encode(), _p(out), out.size, C.byref(rows), C.byref(dim)))
+    return out
+
+
+def read_ivecs(path: str) -> np.ndarray:
+    """load_ivecs (main_ivf.cpp:35-50)."""
+    L = lib()
+    rows, dim = C.c_int64(0), C.c_int(0)
+    _check(L.vs_fvecs_shape(path.encode(), C.byref(rows), C.byref(dim)))
+    out = np.empty((rows.value, max(dim.value, 0)), dtype=np.int32)
+    if out.size:
+        _check(L.vs_ivecs_read(path.encode(), _p(out), out.size, C.byref(rows), C.byref(dim)))
+    return out
+
+
+def write_fvecs(path: str, x) -> None:
+    x = _f32c(x)
+    _check(lib().vs_fvecs_write(path.encode(), _p(x), x.shape[0], x.shape[1]))
+
+
+def write_ivecs(path: str, x) -> None:
+    x = np.ascontiguousarray(x, dtype=np.int32)
+    _check(lib().vs_ivecs_write(path.encode(), _p(x), x.shape[0], x.shape[1]))
+
+
+def write_results(path: str, ids, dists, style: int = 0) -> None:
+    """write_results (cpu_baseline.cpp:155-175) / results.txt of main_ivf.cpp:179-183 (style=1)."""
+    ids = np.ascontiguousarray(ids, dtype=np.int32)
+    dists = _f32c(dists)
+    _check(lib().vs_results_write(path.encode(), _p(ids), _p(dists), ids.shape[0], ids.shape[1], style))
+
+
+def synth_sift(rows: int, seed: int, dim: int = 128, row_begin: int = 0) -> np.ndarray:
+    """Deterministic SIFT-shaped synthetic rows; integer valued f32 in [0, 218]."""
+    out = np.empty((rows, dim), dtype=np.float32)
+    _check(lib().vs_synth_sift(_p(out), row_begin, rows, dim, seed))
+    return out
+
+
+def select_topk_slots(rows, dists, k: int):
+    """select_topk (cpu_baseline.cpp:127-153) over a row-ordered candidate list (tie resolver)."""
+    rows = np.ascontiguousarray(rows, dtype=np.int32)
+    dists = _f32c(dists)
+    oi = np.empty(k, dtype=np.int32)
+    od = np.empty(k, dtype=np.float32)
+    _check(lib().vs_select_topk_slots(_p(rows), _p(dists), rows.shape[0], k, _p(oi), _p(od)))
+    return oi, od
+
+
+# ------------------------------------------------------------------ index classes
+class _Index:
+    def __init__(self):
+        self._h = C.c_void_p(None)
+
+    def close(self):
+        if self._h:
+            lib().vs_destroy(self._h)
+            self._h = C.c_void_p(None)
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def set_batch(self, batch: int):
+        _check(lib().vs_set_batch(self._h, batch))
+
+    # QnnRunner-style getters (QnnRunner.h:37-39)
+    def getNumDocs(self) -> int:
+        return int(lib().vs_index_rows(self._h))
+
+    def getDim(self) -> int:
+        return int(lib().vs_index_dim(self._h))
+
+    def prof_enable(self, on: bool = True):
+        _check(lib().vs_prof_enable(self._h, 1 if on else 0))
+
+    def prof_read(self, which: int = 0):
+        ms, n = C.c_double(0), C.c_int64(0)
+        _check(lib().vs_prof_read(self._h, which, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+
+class BruteForceIndex(_Index):
+    """Exact L2 (or IP) search over a resident base: the GPU side of run_benchmark
+    (cpu_baseline.cpp:177-254).  ``search`` returns exactly what the reference writes
+    to results.txt: ids and squared-L2 distances, ascending, reference tie order."""
+
+    def __init__(self, base, metric: int = METRIC_L2, device: int = 0, id_offset: int = 0):
+        super().__init__()
+        base = _f32c(base)
+        if base.ndim != 2:
+            raise ValueError("base must be [N, d]")
+        self.n, self.d = base.shape
+        _check(lib().vs_bf_create(_p(base), self.n, self.d, metric, device, id_offset, C.byref(self._h)))
+
+    def search(self, queries, k: int, timing: Timing | None = None):
+        q = _f32c(queries).reshape(-1, self.d)
+        nq = q.shape[0]
+        ids = np.empty((nq, k), dtype=np.int32)
+        dists = np.empty((nq, k), dtype=np.float32)
+        tm = timing if timing is not None else Timing()
+        _check(lib().vs_bf_search(self._h, _p(q), nq, k, _p(ids), _p(dists), C.byref(tm)))
+        return ids, dists
+
+    def search_dev(self, q_ptr: int, B: int, k: int, ids_ptr: int, dists_ptr: int, flags_ptr: int, stream: int):
+        """Asynchronous device-pointer call (vs_bf_search_dev): outputs are [B, k+1]."""
+        _check(lib().vs_bf_search_dev(self._h, q_ptr, B, k, ids_ptr, dists_ptr, flags_ptr, stream))
+
+    def scores_dev(self, q_ptr: int, B: int, scores_ptr: int, ld: int, stream: int):
+        """QnnRunner::executeBatchRaw analogue: raw [B, ld] score matrix on the device."""
+        _check(lib().vs_bf_scores_dev(self._h, q_ptr, B, scores_ptr, ld, stream))
+
+
+class IVFIndex(_Index):
+    """class IVFIndex (IVFIndex.h:14-97) on the GPU, reordered (contiguous list) layout, L2."""
+
+    def __init__(self, index_dir: str | None = None, device: int = 0, rank: int = 0, world: int = 1, *,
+                 vectors_reordered=None, centroids=None, cluster_offsets=None, reorder_to_original=None):
+        super().__init__()
+        if index_dir is not None:
+            _check(lib().vs_ivf_load(index_dir.encode(), device, rank, world, C.byref(self._h)))
+        else:
+            v = _f32c(vectors_reordered)
+            c = _f32c(centroids)
+            off = np.ascontiguousarray(cluster_offsets, dtype=np.int32)
+            r2o = None if reorder_to_original is None else np.ascontiguousarray(reorder_to_original, dtype=np.int32)
+            _check(lib().vs_ivf_create(_p(v), v.shape[0], v.shape[1], _p(c), c.shape[0], _p(off),
+                                       _p(r2o) if r2o is not None else None, device, rank, world, C.byref(self._h)))
+        self.d = self.getDim()
+
+    def getNumVectors(self) -> int:
+        return self.getNumDocs()
+
+    def getNumClusters(self) -> int:
+        return int(lib().vs_index_nlist(self._h))
+
+    def save(self, index_dir: str):
+        os.makedirs(index_dir, exist_ok=True)
+        _check(lib().vs_ivf_save(self._h, index_dir.encode()))
+
+    def searchBatch(self, queries, batchSize: int, k: int, nprobe: int, timing: Timing | None = None):
+        """IVFIndex::searchBatch (IVFIndex.h:45-48): returns (allIndices, allScores, totalCandidates)."""
+        q = _f32c(queries).reshape(-1, self.d)[:batchSize]
+        nq = q.shape[0]
+        ids = np.empty((nq, k), dtype=np.int32)
+        dists = np.empty((nq, k), dtype=np.float32)
+        total = C.c_int64(0)
+        tm = timing if timing is not None else Timing()
+        _check(lib().vs_ivf_search(self._h, _p(q), nq, k, nprobe, _p(ids), _p(dists), C.byref(total), C.byref(tm)))
+        return ids, dists, int(total.value)
+
+    def search(self, query, k: int, nprobe: int):
+        """IVFIndex::search (IVFIndex.h:25-26) for one query."""
+        ids, dists, total = self.searchBatch(np.asarray(query).reshape(1, -1), 1, k, nprobe)
+        return ids[0], dists[0], total
+
+    def search_dev(self, q_ptr: int, B: int, k: int, nprobe: int, ids_ptr: int, dists_ptr: int, stream: int):
+        _check(lib().vs_ivf_search_dev(self._h, q_ptr, B, k, nprobe, ids_ptr, dists_ptr, stream))
+
+
+def topk_merge_dev(dists_ptr: int, ids_ptr: int, G: int, B: int, kin: int, kout: int, out_d_ptr: int,
+                   out_i_ptr: int, flags_ptr: int, stream: int, stride_g: int = 0):
+    """Merge G per-shard sorted lists (e.g. an RCCL all-gather receive buffer) on the device."""
+    _check(lib().vs_topk_merge_dev(dists_ptr, ids_ptr, G, B, kin, stride_g, kout, out_d_ptr, out_i_ptr,
+                                   flags_ptr, stream))
+
+
+# ------------------------------------------------------------------ IVF index building (host logic)
+def ivf_layout_from_assignment(vectors: np.ndarray, cluster_ids: np.ndarray, n_clusters: int):
+    """Reordered index layout of create_ivf_model_reordered.py:108-128: stable argsort by cluster,
+    offsets = cumsum(sizes).  Returns (vectors_reordered, cluster_offsets, reorder_to_original)."""
+    order = np.argsort(cluster_ids, kind="stable").astype(np.int32)
+    sizes = np.bincount(cluster_ids, minlength=n_clusters).astype(np.int64)
+    offsets = np.zeros(n_clusters + 1, dtype=np.int32)
+    offsets[1:] = np.cumsum(sizes)
+    return np.ascontiguousarray(vectors[order], dtype=np.float32), offsets, order
+
+
+def clamp_nlist(n_vectors: int, n_clusters: int) -> int:
+    """nlist clamp of create_ivf_model_reordered.py:92-94."""
+    if n_clusters > n_vectors // 10:
+        n_clusters = max(16, n_vectors // 100)
+    return n_clusters

@@ -1,0 +1,129 @@
+// vsearch_ivf -- drop-in for the reference's qidk_ivf CLI (main_ivf.cpp:61-293) on the MI355X backend.
+//   vsearch_ivf <index_dir> <queries.fvecs> <results_dir> <backend.so> <top_k> [nprobe=16] [groundtruth.ivecs] [batch=1]
+// Writes <results_dir>/results.txt and metrics.txt in the reference's layouts.  The <backend.so>
+// slot is accepted and ignored (the reference passes libQnnHtp.so there).
+#include <sys/stat.h>
+
+#include <algorithm>
+#include <chrono>
+#include <fstream>
+#include <iomanip>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "../../include/vsearch.hpp"
+
+int main(int argc, char* argv[]) {
+    if (argc < 6) {
+        std::cerr << "Usage: " << argv[0]
+                  << " <index_dir> <queries.fvecs> <results_dir> <backend.so> <top_k> [nprobe] [groundtruth.ivecs] [batch]"
+                  << std::endl;
+        return 1;
+    }
+    const std::string index_dir = argv[1], query_file = argv[2], results_dir = argv[3], backend_path = argv[4];
+    const int TOP_K = std::stoi(argv[5]);
+    const int NPROBE = (argc > 6) ? std::stoi(argv[6]) : 16;  // main_ivf.cpp:76
+    const std::string gt_file = (argc > 7) ? argv[7] : "";
+    const int BATCH_SIZE = (argc > 8) ? std::stoi(argv[8]) : 1;  // main_ivf.cpp:78
+    try {
+        mkdir(results_dir.c_str(), 0755);
+        const std::string results_txt = results_dir + "/results.txt", metrics_txt = results_dir + "/metrics.txt";
+        std::cout << "Loading queries..." << std::endl;
+        std::vector<float> queries;
+        int nq = 0, query_dim = 0;
+        if (!vsearch::read_fvecs(query_file, queries, nq, query_dim)) throw std::runtime_error(vs_last_error());
+        std::cout << "Loaded " << nq << " queries." << std::endl;
+        std::vector<std::vector<int>> ground_truth;
+        int gt_k = 0;
+        if (!gt_file.empty()) {
+            vsearch::load_ivecs(gt_file, ground_truth, gt_k);
+            std::cout << "Loaded " << ground_truth.size() << " ground truth entries." << std::endl;
+        }
+        std::cout << "Loading IVF index..." << std::endl;
+        vsearch::IVFIndex ivf(index_dir, backend_path);
+        if (query_dim != static_cast<int>(ivf.getDim()))
+            throw std::runtime_error("Query dim (" + std::to_string(query_dim) + ") != index dim (" +
+                                     std::to_string(ivf.getDim()) + ")");
+        ivf.setBatchSize(std::min(std::max(BATCH_SIZE, 1), 32));
+        std::ofstream results_file(results_txt);
+        if (!results_file) throw std::runtime_error("Cannot open output file: " + results_txt);
+
+        double total_centroid_ms = 0, total_gather_ms = 0, total_fine_ms = 0, total_search_ms = 0, total_recall = 0;
+        size_t total_candidates = 0;
+        std::vector<double> latencies;
+        const size_t num_queries = (size_t)nq;
+        auto total_start = std::chrono::high_resolution_clock::now();
+        for (size_t i = 0; i < num_queries; i += (size_t)BATCH_SIZE) {
+            const size_t cur = std::min((size_t)BATCH_SIZE, num_queries - i);
+            std::vector<float> batch(queries.begin() + (long)(i * query_dim), queries.begin() + (long)((i + cur) * query_dim));
+            std::vector<std::vector<int>> bi;
+            std::vector<std::vector<float>> bs;
+            vsearch::IVFIndex::SearchTiming timing;
+            auto b0 = std::chrono::high_resolution_clock::now();
+            total_candidates += ivf.searchBatch(batch, (int)cur, TOP_K, NPROBE, bi, bs, timing);
+            auto b1 = std::chrono::high_resolution_clock::now();
+            const double batch_ms = std::chrono::duration<double, std::milli>(b1 - b0).count();
+            total_centroid_ms += timing.centroid_search_ms;
+            total_gather_ms += timing.gather_ms;
+            total_fine_ms += timing.fine_search_ms;
+            total_search_ms += batch_ms;
+            for (size_t j = 0; j < cur; ++j) {
+                latencies.push_back(batch_ms);
+                if (!ground_truth.empty() && (i + j) < ground_truth.size())
+                    total_recall += vsearch::compute_recall(bi[j], ground_truth[i + j], TOP_K);
+                results_file << "Query " << (i + j) << ":";
+                for (size_t t = 0; t < bi[j].size(); ++t)
+                    results_file << " (" << bi[j][t] << ", " << std::fixed << std::setprecision(4) << bs[j][t] << ")";
+                results_file << "\n";
+            }
+        }
+        auto total_end = std::chrono::high_resolution_clock::now();
+        const std::chrono::duration<double> total_time = total_end - total_start;
+        results_file.close();
+
+        const double avg_latency = total_search_ms / num_queries;
+        const double avg_candidates = static_cast<double>(total_candidates) / num_queries;
+        const double avg_recall = ground_truth.empty() ? 0.0 : total_recall / num_queries;
+        const double throughput = num_queries / total_time.count();
+        std::sort(latencies.begin(), latencies.end());
+        const double p50 = latencies[latencies.size() / 2];
+        const double p95 = latencies[static_cast<size_t>(latencies.size() * 0.95)];
+        const double p99 = latencies[static_cast<size_t>(latencies.size() * 0.99)];
+        const double speedup_candidates = ivf.getNumVectors() / avg_candidates;
+
+        std::ofstream m(metrics_txt);
+        if (!m) throw std::runtime_error("Cannot open metrics file: " + metrics_txt);
+        m << std::fixed << std::setprecision(6);
+        m << "=== IVF Search Performance Metrics ===\n\n";
+        m << "Index Configuration:\n  Total vectors: " << ivf.getNumVectors() << "\n  Number of clusters: " << ivf.getNumClusters()
+          << "\n  Dimension: " << ivf.getDim() << "\n  nprobe: " << NPROBE << "\n  top_k: " << TOP_K
+          << "\n  batch_size: " << BATCH_SIZE << "\n\n";
+        m << "Query Statistics:\n  Number of queries: " << num_queries << "\n  Avg candidates searched: " << avg_candidates
+          << "\n  Candidate reduction: " << speedup_candidates << "x\n\n";
+        if (!ground_truth.empty()) m << "Accuracy:\n  Recall@" << TOP_K << ": " << (avg_recall * 100.0) << "%\n\n";
+        m << "Latency:\n  Avg per query (amortized): " << avg_latency << " ms\n  Avg centroid search (GPU): "
+          << (total_centroid_ms / num_queries) << " ms\n  Avg gather: " << (total_gather_ms / num_queries)
+          << " ms\n  Avg fine search (GPU): " << (total_fine_ms / num_queries) << " ms\n  Batch P50: " << p50
+          << " ms\n  Batch P95: " << p95 << " ms\n  Batch P99: " << p99 << " ms\n\n";
+        m << "Throughput:\n  Total time: " << total_time.count() << " s\n  QPS: " << throughput << "\n\n";
+        const double cf = 2.0 * ivf.getDim() * ivf.getNumClusters(), ff = 2.0 * ivf.getDim() * avg_candidates;
+        m << "Compute:\n  FLOPs per query (centroid): " << std::scientific << cf << "\n  FLOPs per query (fine): " << ff
+          << "\n  FLOPs per query (total): " << (cf + ff) << "\n  Avg GFLOPS: " << std::fixed
+          << ((cf + ff) / 1e9) / (avg_latency / 1000.0) << "\n  Total GFLOPS: " << (cf + ff) * num_queries / (total_time.count() * 1e9)
+          << "\n";
+        m.close();
+
+        std::cout << "\n=== IVF Search Complete ===" << std::endl;
+        std::cout << "Throughput: " << throughput << " QPS" << std::endl;
+        std::cout << "Avg latency: " << avg_latency << " ms" << std::endl;
+        std::cout << "Avg candidates: " << avg_candidates << " (" << speedup_candidates << "x reduction)" << std::endl;
+        if (!ground_truth.empty()) std::cout << "Recall@" << TOP_K << ": " << (avg_recall * 100.0) << "%" << std::endl;
+        std::cout << "\nResults saved to: " << results_txt << std::endl;
+        std::cout << "Metrics saved to: " << metrics_txt << std::endl;
+    } catch (const std::exception& e) {
+        std::cerr << "FATAL ERROR: " << e.what() << std::endl;  // main_ivf.cpp:287-290
+        return 1;
+    }
+    return 0;
+}

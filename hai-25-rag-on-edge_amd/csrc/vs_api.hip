@@ -1,0 +1,837 @@
+// vs_api.hip -- C ABI of libvsearch_hip.so: index objects, device memory, launch orchestration.
+//
+// One vs_index owns: the base (or cluster-reordered) vectors and their squared norms in HBM,
+// a small scratch arena (padded queries, thresholds, per-workgroup partial lists, result
+// staging) and a HIP stream.  Nothing here computes distances on the host: without a HIP device
+// every create/search call fails (VS_ERR_DEVICE).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/vsearch.h"
+#include "vs_host.h"
+#include "vs_kernels.h"
+
+using vs::set_error;
+
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess) {                                                                        \
+            set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                              \
+            return VS_ERR_DEVICE;                                                                      \
+        }                                                                                              \
+    } while (0)
+
+namespace {
+
+constexpr int kMaxEvents = 8192;
+constexpr int kKcapMax = 16;       // largest per-lane list the scan kernels are compiled for
+constexpr int kMaxNprobe = 256;
+
+struct ProfSlot {
+    std::vector<hipEvent_t> ev;  // pairs
+    int used = 0;
+};
+
+double now_ms() {
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+}  // namespace
+
+struct vs_index {
+    int kind = 0;  // 0 = brute force, 1 = IVF
+    int device = 0;
+    int dim = 0;
+    int metric = VS_METRIC_L2;
+    int64_t n_rows = 0;   // rows resident on this GPU
+    int64_t n_total = 0;  // rows of the whole (unsharded) index
+    int64_t id_offset = 0;
+    int batch = vs::kMaxBatch;
+    int num_cus = 256;
+
+    float* d_vecs = nullptr;   // [n_rows][128]
+    float* d_norm = nullptr;   // [n_rows + 16]
+
+    // IVF
+    int nlist = 0;
+    int rank = 0, world = 1;
+    float* d_centroids = nullptr;  // [nlist][128]
+    float* d_cnorm = nullptr;      // [nlist + 16]
+    int32_t* d_offsets = nullptr;  // [nlist + 1] offsets into the LOCAL d_vecs (non-owned lists are empty)
+    int32_t* d_r2o = nullptr;      // [n_rows] local position -> original id
+    std::vector<int32_t> h_offsets_global;  // as loaded (for save / stats)
+    double avg_cluster_size = 0;
+
+    // scratch
+    float* d_q = nullptr;        // staging for host queries [32][128]
+    float* d_qpad = nullptr;     // [32][128]
+    float* d_qnorm = nullptr;    // [32]
+    float* d_tau = nullptr;      // [32]
+    float* d_part_d = nullptr;   // [max_grid][32][16]
+    int32_t* d_part_i = nullptr;
+    float* d_seed_d = nullptr;   // [seed_grid][32][16]
+    int32_t* d_seed_i = nullptr;
+    float* d_out_d = nullptr;    // [32][64]
+    int32_t* d_out_i = nullptr;
+    int32_t* d_flags = nullptr;  // [32]
+    float* d_scores = nullptr;   // IVF coarse [32][nlist_pad]; tie fallback rows
+    int64_t scores_cap = 0;      // floats
+    int32_t* d_probes = nullptr; // [32][kMaxNprobe]
+    float* d_ipart_d = nullptr;  // [32][kMaxNprobe][16]
+    int32_t* d_ipart_i = nullptr;
+    unsigned long long* d_cand = nullptr;
+    int max_grid = 0, seed_grid = 0;
+    int64_t seed_rows = 0;
+
+    hipStream_t stream = nullptr;
+    bool prof = false;
+    ProfSlot prof_slot[2];
+};
+
+namespace {
+
+int set_device(const vs_index* h) {
+    HIPCHK(hipSetDevice(h->device));
+    return VS_OK;
+}
+
+template <typename T>
+int dev_alloc(T** p, size_t n) {
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(p), std::max<size_t>(n, 1) * sizeof(T)));
+    return VS_OK;
+}
+
+void free_all(vs_index* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    void* ptrs[] = {h->d_vecs, h->d_norm, h->d_centroids, h->d_cnorm, h->d_offsets, h->d_r2o, h->d_q, h->d_qpad,
+                    h->d_qnorm, h->d_tau, h->d_part_d, h->d_part_i, h->d_seed_d, h->d_seed_i, h->d_out_d, h->d_out_i,
+                    h->d_flags, h->d_scores, h->d_probes, h->d_ipart_d, h->d_ipart_i, h->d_cand};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    for (auto& ps : h->prof_slot)
+        for (auto e : ps.ev) (void)hipEventDestroy(e);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int check_device(int device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        set_error("no HIP device available (this library has no CPU fallback)");
+        return VS_ERR_DEVICE;
+    }
+    if (device < 0 || device >= n) {
+        set_error("device index out of range");
+        return VS_ERR_INVALID;
+    }
+    return VS_OK;
+}
+
+// scan geometry for n rows: persistent-style grid of at most one workgroup per CU
+void scan_geometry(int64_t rows, int num_cus, int& grid, int& tiles_per_wg) {
+    const int64_t tiles = (rows + vs::kTileRows - 1) / vs::kTileRows;
+    int64_t g = std::min<int64_t>(num_cus, (tiles + vs::kScanWaves - 1) / vs::kScanWaves);
+    g = std::max<int64_t>(g, 1);
+    tiles_per_wg = (int)((tiles + g - 1) / g);
+    grid = (int)((tiles + tiles_per_wg - 1) / tiles_per_wg);
+    grid = std::max(grid, 1);
+}
+
+int alloc_scratch(vs_index* h) {
+    int rc;
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, h->device));
+    h->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    int tp;
+    scan_geometry(std::max<int64_t>(h->n_rows, 1), h->num_cus, h->max_grid, tp);
+    h->max_grid = std::max(h->max_grid, h->num_cus);
+    // seed sample: first rows of the base; only worth a launch on large bases
+    h->seed_rows = 0;
+    if (h->kind == 0 && h->n_rows >= 262144) {
+        h->seed_rows = std::min<int64_t>(32768, (h->n_rows / 32) & ~int64_t(127));
+    }
+    h->seed_grid = 0;
+    if (h->seed_rows > 0) {
+        int stp;
+        scan_geometry(h->seed_rows, h->num_cus, h->seed_grid, stp);
+    }
+    if ((rc = dev_alloc(&h->d_q, 32 * vs::kDim))) return rc;
+    if ((rc = dev_alloc(&h->d_qpad, 32 * vs::kDim))) return rc;
+    if ((rc = dev_alloc(&h->d_qnorm, 32))) return rc;
+    if ((rc = dev_alloc(&h->d_tau, 32))) return rc;
+    const size_t part = (size_t)h->max_grid * 32 * kKcapMax;
+    if ((rc = dev_alloc(&h->d_part_d, part))) return rc;
+    if ((rc = dev_alloc(&h->d_part_i, part))) return rc;
+    const size_t spart = (size_t)std::max(h->seed_grid, 1) * 32 * kKcapMax;
+    if ((rc = dev_alloc(&h->d_seed_d, spart))) return rc;
+    if ((rc = dev_alloc(&h->d_seed_i, spart))) return rc;
+    if ((rc = dev_alloc(&h->d_out_d, 32 * 64))) return rc;
+    if ((rc = dev_alloc(&h->d_out_i, 32 * 64))) return rc;
+    if ((rc = dev_alloc(&h->d_flags, 32))) return rc;
+    if (h->kind == 1) {
+        h->scores_cap = (int64_t)32 * ((h->nlist + 15) & ~15);
+        if ((rc = dev_alloc(&h->d_scores, (size_t)h->scores_cap))) return rc;
+        if ((rc = dev_alloc(&h->d_probes, 32 * kMaxNprobe))) return rc;
+        if ((rc = dev_alloc(&h->d_ipart_d, (size_t)32 * kMaxNprobe * kKcapMax))) return rc;
+        if ((rc = dev_alloc(&h->d_ipart_i, (size_t)32 * kMaxNprobe * kKcapMax))) return rc;
+        if ((rc = dev_alloc(&h->d_cand, 1))) return rc;
+    }
+    HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    return VS_OK;
+}
+
+// upload `rows x dim` floats in chunks through the default pageable path and compute norms
+int upload_vectors(vs_index* h, const float* host, int64_t rows) {
+    int rc;
+    if ((rc = dev_alloc(&h->d_vecs, (size_t)std::max<int64_t>(rows, 1) * vs::kDim))) return rc;
+    if ((rc = dev_alloc(&h->d_norm, (size_t)rows + 16))) return rc;
+    HIPCHK(hipMemset(h->d_norm, 0, ((size_t)rows + 16) * sizeof(float)));
+    if (rows > 0) {
+        HIPCHK(hipMemcpy(h->d_vecs, host, (size_t)rows * vs::kDim * sizeof(float), hipMemcpyHostToDevice));
+        HIPCHK(vs::launch_row_sqnorm(h->d_vecs, rows, vs::kDim, h->d_norm, nullptr));
+        HIPCHK(hipDeviceSynchronize());
+    }
+    return VS_OK;
+}
+
+void prof_begin(vs_index* h, int which, hipStream_t s) {
+    if (!h->prof) return;
+    ProfSlot& ps = h->prof_slot[which];
+    if (ps.used + 2 > kMaxEvents) return;
+    while ((int)ps.ev.size() < ps.used + 2) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return;
+        ps.ev.push_back(e);
+    }
+    (void)hipEventRecord(ps.ev[ps.used], s);
+}
+void prof_end(vs_index* h, int which, hipStream_t s) {
+    if (!h->prof) return;
+    ProfSlot& ps = h->prof_slot[which];
+    if ((int)ps.ev.size() < ps.used + 2) return;
+    (void)hipEventRecord(ps.ev[ps.used + 1], s);
+    ps.used += 2;
+}
+
+int pick_kcap(int need) { return need <= 8 ? 8 : (need <= 16 ? 16 : 0); }
+
+// One batch of the brute-force pipeline on stream s: prep -> [seed scan -> seed merge] -> scan -> merge.
+int bf_batch_dev(vs_index* h, const float* q_dev, int B, int k1, float* out_d, int32_t* out_i, int32_t* flags,
+                 hipStream_t s) {
+    const int kcap = pick_kcap(k1);
+    if (!kcap) {
+        set_error("k too large for the compiled scan kernels (k <= 15)");
+        return VS_ERR_UNSUPPORTED;
+    }
+    const int nqh = B <= 16 ? 1 : 2;
+    HIPCHK(vs::launch_prep_queries(q_dev, B, h->d_qpad, h->d_qnorm, s));
+
+    vs::ScanParams p{};
+    p.base = h->d_vecs;
+    p.bnorm = h->d_norm;
+    p.q = h->d_qpad;
+    p.qnorm = h->d_qnorm;
+    p.metric = h->metric;
+    p.id_offset = (int32_t)h->id_offset;
+    p.nq_valid = B;
+
+    const bool seeded = h->seed_rows > 0 && h->seed_rows >= 4 * (int64_t)k1;
+    if (seeded) {
+        int grid, tp;
+        scan_geometry(h->seed_rows, h->num_cus, grid, tp);
+        p.tau0 = nullptr;
+        p.row_begin = 0;
+        p.row_end = h->seed_rows;
+        p.tiles_per_wg = tp;
+        p.part_d = h->d_seed_d;
+        p.part_i = h->d_seed_i;
+        HIPCHK(vs::launch_scan(p, grid, kcap, nqh, vs::kModeTopK, s));
+        vs::MergeParams m{};
+        m.part_d = h->d_seed_d;
+        m.part_i = h->d_seed_i;
+        m.G = grid;
+        m.nq_stride = 32;
+        m.kin = kcap;
+        m.nq = nqh * 16;
+        m.kout = k1;
+        m.tau_out = h->d_tau;
+        HIPCHK(vs::launch_merge(m, s));
+    }
+    int grid, tp;
+    scan_geometry(h->n_rows, h->num_cus, grid, tp);
+    p.tau0 = seeded ? h->d_tau : nullptr;
+    p.row_begin = 0;
+    p.row_end = h->n_rows;
+    p.tiles_per_wg = tp;
+    p.part_d = h->d_part_d;
+    p.part_i = h->d_part_i;
+    prof_begin(h, 0, s);
+    HIPCHK(vs::launch_scan(p, grid, kcap, nqh, vs::kModeTopK, s));
+    prof_end(h, 0, s);
+
+    vs::MergeParams m{};
+    m.part_d = h->d_part_d;
+    m.part_i = h->d_part_i;
+    m.G = grid;
+    m.nq_stride = 32;
+    m.kin = kcap;
+    m.nq = B;
+    m.kout = k1;
+    m.out_d = out_d;
+    m.out_i = out_i;
+    m.flags = flags;
+    HIPCHK(vs::launch_merge(m, s));
+    return VS_OK;
+}
+
+int scores_dev(vs_index* h, const float* vecs, const float* norms, int64_t rows, const float* q_dev, int B,
+               float* scores, int64_t ld, hipStream_t s) {
+    HIPCHK(vs::launch_prep_queries(q_dev, B, h->d_qpad, h->d_qnorm, s));
+    vs::ScanParams p{};
+    p.base = vecs;
+    p.bnorm = norms;
+    p.q = h->d_qpad;
+    p.qnorm = h->d_qnorm;
+    p.metric = h->metric;
+    p.nq_valid = B;
+    p.row_begin = 0;
+    p.row_end = rows;
+    int grid, tp;
+    scan_geometry(rows, h->num_cus, grid, tp);
+    p.tiles_per_wg = tp;
+    p.store = scores;
+    p.store_ld = ld;
+    HIPCHK(vs::launch_scan(p, grid, 8, B <= 16 ? 1 : 2, vs::kModeStore, s));
+    return VS_OK;
+}
+
+int ivf_batch_dev(vs_index* h, const float* q_dev, int B, int k, int nprobe, float* out_d, int32_t* out_i,
+                  hipStream_t s, double* t_marks /*optional host marks*/) {
+    (void)t_marks;
+    const int kcap = pick_kcap(k);
+    if (!kcap) {
+        set_error("k too large for the compiled IVF kernels (k <= 16)");
+        return VS_ERR_UNSUPPORTED;
+    }
+    const int64_t ld = (h->nlist + 15) & ~15;
+    // coarse: Q x C^T + ||c||^2 epilogue on the MFMA scan kernel (IVFIndex.cpp:654-666)
+    int rc = scores_dev(h, h->d_centroids, h->d_cnorm, h->nlist, q_dev, B, h->d_scores, ld, s);
+    if (rc) return rc;
+    // top-nprobe (IVFIndex.cpp:711), deterministic ascending (dist, id)
+    HIPCHK(vs::launch_pick_probes(h->d_scores, ld, B, h->nlist, nprobe, h->d_probes, s));
+    vs::IvfScanParams ip{};
+    ip.vecs = h->d_vecs;
+    ip.vnorm = h->d_norm;
+    ip.offsets = h->d_offsets;
+    ip.owned = nullptr;
+    ip.q = h->d_qpad;
+    ip.qnorm = h->d_qnorm;
+    ip.probes = h->d_probes;
+    ip.B = B;
+    ip.nprobe = nprobe;
+    ip.kcap = kcap;
+    ip.metric = h->metric;
+    ip.part_d = h->d_ipart_d;
+    ip.part_i = h->d_ipart_i;
+    ip.cand_count = h->d_cand;
+    prof_begin(h, 1, s);
+    HIPCHK(vs::launch_ivf_scan(ip, s));
+    prof_end(h, 1, s);
+    vs::MergeParams m{};
+    m.part_d = h->d_ipart_d;
+    m.part_i = h->d_ipart_i;
+    m.G = nprobe;
+    m.kin = kcap;
+    m.nq = B;
+    m.kout = k;
+    m.out_d = out_d;
+    m.out_i = out_i;
+    m.id_map = h->d_r2o;
+    HIPCHK(vs::launch_merge_layout(m, kcap, (int64_t)nprobe * kcap, s));
+    return VS_OK;
+}
+
+}  // namespace
+
+// =============================================================================================== C ABI
+extern "C" {
+
+const char* vs_version(void) { return "vsearch-hip 0.1 (gfx950)"; }
+
+int vs_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int64_t vs_index_rows(const vs_index* h) { return h ? h->n_total : 0; }
+int vs_index_dim(const vs_index* h) { return h ? h->dim : 0; }
+int vs_index_nlist(const vs_index* h) { return h ? h->nlist : 0; }
+void vs_destroy(vs_index* h) { free_all(h); }
+
+int vs_set_batch(vs_index* h, int batch) {
+    if (!h || batch < 1 || batch > vs::kMaxBatch) {
+        set_error("batch must be in 1..32");
+        return VS_ERR_INVALID;
+    }
+    h->batch = batch;
+    return VS_OK;
+}
+
+int vs_prof_enable(vs_index* h, int on) {
+    if (!h) return VS_ERR_INVALID;
+    h->prof = on != 0;
+    for (auto& ps : h->prof_slot) ps.used = 0;
+    return VS_OK;
+}
+
+int vs_prof_read(vs_index* h, int which, double* total_ms, int64_t* launches) {
+    if (!h || which < 0 || which > 1) return VS_ERR_INVALID;
+    int rc = set_device(h);
+    if (rc) return rc;
+    ProfSlot& ps = h->prof_slot[which];
+    double tot = 0;
+    for (int i = 0; i + 1 < ps.used; i += 2) {
+        HIPCHK(hipEventSynchronize(ps.ev[i + 1]));
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, ps.ev[i], ps.ev[i + 1]));
+        tot += ms;
+    }
+    if (total_ms) *total_ms = tot;
+    if (launches) *launches = ps.used / 2;
+    return VS_OK;
+}
+
+// ------------------------------------------------------------------------------------- brute force
+int vs_bf_create(const float* base_host, int64_t n_rows, int dim, int metric, int device, int64_t id_offset,
+                 vs_index** out) {
+    if (!out || !base_host || n_rows <= 0) {
+        set_error("vs_bf_create: bad arguments");
+        return VS_ERR_INVALID;
+    }
+    if (dim != vs::kDim) {
+        set_error("only dim == 128 is compiled in");
+        return VS_ERR_UNSUPPORTED;
+    }
+    if (metric != VS_METRIC_L2 && metric != VS_METRIC_IP) {
+        set_error("unknown metric");
+        return VS_ERR_INVALID;
+    }
+    if (n_rows + id_offset > std::numeric_limits<int32_t>::max()) {
+        set_error("ids must fit int32");
+        return VS_ERR_UNSUPPORTED;
+    }
+    int rc = check_device(device);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(device));
+    vs_index* h = new vs_index();
+    h->kind = 0;
+    h->device = device;
+    h->dim = dim;
+    h->metric = metric;
+    h->n_rows = h->n_total = n_rows;
+    h->id_offset = id_offset;
+    if ((rc = upload_vectors(h, base_host, n_rows)) || (rc = alloc_scratch(h))) {
+        free_all(h);
+        return rc;
+    }
+    *out = h;
+    return VS_OK;
+}
+
+int vs_bf_search_dev(vs_index* h, const float* queries_dev, int B, int k, int32_t* ids_dev, float* dists_dev,
+                     int32_t* flags_dev, void* stream) {
+    if (!h || h->kind != 0 || !queries_dev || !ids_dev || !dists_dev || B < 1 || B > vs::kMaxBatch || k < 1) {
+        set_error("vs_bf_search_dev: bad arguments");
+        return VS_ERR_INVALID;
+    }
+    int rc = set_device(h);
+    if (rc) return rc;
+    return bf_batch_dev(h, queries_dev, B, k + 1, dists_dev, ids_dev, flags_dev ? flags_dev : h->d_flags,
+                        static_cast<hipStream_t>(stream));
+}
+
+int vs_bf_scores_dev(vs_index* h, const float* queries_dev, int B, float* scores_dev_, int64_t ld, void* stream) {
+    if (!h || h->kind != 0 || !queries_dev || !scores_dev_ || B < 1 || B > vs::kMaxBatch || ld < h->n_rows) {
+        set_error("vs_bf_scores_dev: bad arguments");
+        return VS_ERR_INVALID;
+    }
+    int rc = set_device(h);
+    if (rc) return rc;
+    return scores_dev(h, h->d_vecs, h->d_norm, h->n_rows, queries_dev, B, scores_dev_, ld, static_cast<hipStream_t>(stream));
+}
+
+int vs_bf_search(vs_index* h, const float* queries_host, int64_t nq, int k, int32_t* ids, float* dists,
+                 vs_timing* timing) {
+    if (!h || h->kind != 0 || !queries_host || !ids || !dists || nq < 0 || k < 1) {
+        set_error("vs_bf_search: bad arguments");
+        return VS_ERR_INVALID;
+    }
+    int rc = set_device(h);
+    if (rc) return rc;
+    const double t_start = now_ms();
+    vs_timing tm{};
+    const int k1 = k + 1;
+    if (!pick_kcap(k1)) {
+        set_error("k too large for the compiled scan kernels (k <= 15)");
+        return VS_ERR_UNSUPPORTED;
+    }
+    std::vector<float> hd((size_t)32 * k1);
+    std::vector<int32_t> hi((size_t)32 * k1), hf(32);
+    std::vector<int64_t> flagged;
+    const float inf = std::numeric_limits<float>::infinity();
+    for (int64_t q0 = 0; q0 < nq; q0 += h->batch) {
+        const int B = (int)std::min<int64_t>(h->batch, nq - q0);
+        double t0 = now_ms();
+        HIPCHK(hipMemcpyAsync(h->d_q, queries_host + q0 * vs::kDim, (size_t)B * vs::kDim * sizeof(float),
+                              hipMemcpyHostToDevice, h->stream));
+        double t1 = now_ms();
+        rc = bf_batch_dev(h, h->d_q, B, k1, h->d_out_d, h->d_out_i, h->d_flags, h->stream);
+        if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(hd.data(), h->d_out_d, (size_t)B * k1 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(hi.data(), h->d_out_i, (size_t)B * k1 * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(hf.data(), h->d_flags, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        double t2 = now_ms();
+        tm.h2d_ms += t1 - t0;
+        tm.fine_search_ms += t2 - t1;
+        for (int b = 0; b < B; ++b) {
+            for (int t = 0; t < k; ++t) {
+                const int32_t id = hi[(size_t)b * k1 + t];
+                ids[(q0 + b) * k + t] = id;
+                float d = id >= 0 ? hd[(size_t)b * k1 + t] : inf;
+                if (h->metric == VS_METRIC_IP && id >= 0) d = -d;
+                dists[(q0 + b) * k + t] = d;
+            }
+            if (hf[b]) flagged.push_back(q0 + b);
+        }
+    }
+    // Ties inside the k+1 best: the reference's order is history dependent (cpu_baseline.cpp:127-153),
+    // so recompute the full distance row on the GPU and replay the slot algorithm over it.
+    if (!flagged.empty() && h->metric == VS_METRIC_L2) {
+        const double t0 = now_ms();
+        const int group = 16;
+        const int64_t ld = (h->n_rows + 15) & ~int64_t(15);
+        if (h->scores_cap < (int64_t)group * ld) {
+            if (h->d_scores) (void)hipFree(h->d_scores);
+            h->d_scores = nullptr;
+            h->scores_cap = 0;
+            if ((rc = dev_alloc(&h->d_scores, (size_t)group * ld))) return rc;
+            h->scores_cap = (int64_t)group * ld;
+        }
+        std::vector<float> qbuf((size_t)group * vs::kDim), row((size_t)ld);
+        for (size_t f0 = 0; f0 < flagged.size(); f0 += group) {
+            const int B = (int)std::min<size_t>(group, flagged.size() - f0);
+            for (int b = 0; b < B; ++b)
+                std::memcpy(&qbuf[(size_t)b * vs::kDim], queries_host + flagged[f0 + b] * vs::kDim, vs::kDim * sizeof(float));
+            HIPCHK(hipMemcpyAsync(h->d_q, qbuf.data(), (size_t)B * vs::kDim * sizeof(float), hipMemcpyHostToDevice, h->stream));
+            rc = scores_dev(h, h->d_vecs, h->d_norm, h->n_rows, h->d_q, B, h->d_scores, ld, h->stream);
+            if (rc) return rc;
+            for (int b = 0; b < B; ++b) {
+                HIPCHK(hipMemcpyAsync(row.data(), h->d_scores + (size_t)b * ld, (size_t)h->n_rows * sizeof(float),
+                                      hipMemcpyDeviceToHost, h->stream));
+                HIPCHK(hipStreamSynchronize(h->stream));
+                const int64_t qi = flagged[f0 + b];
+                vs::select_topk_slots_dense(row.data(), h->n_rows, k, (int32_t)h->id_offset, ids + qi * k, dists + qi * k);
+            }
+        }
+        tm.tie_resolve_ms = now_ms() - t0;
+        tm.tie_queries = (int64_t)flagged.size();
+    }
+    tm.total_ms = now_ms() - t_start;
+    if (timing) *timing = tm;
+    return VS_OK;
+}
+
+// --------------------------------------------------------------------------------------------- IVF
+static int ivf_create_impl(const float* vectors, int64_t n_rows, int dim, const float* centroids, int nlist,
+                           const int32_t* offsets, const int32_t* r2o, int device, int rank, int world,
+                           vs_index** out) {
+    if (!out || !vectors || !centroids || !offsets || n_rows <= 0 || nlist <= 0 || world < 1 || rank < 0 || rank >= world) {
+        set_error("vs_ivf_create: bad arguments");
+        return VS_ERR_INVALID;
+    }
+    if (dim != vs::kDim) {
+        set_error("only dim == 128 is compiled in");
+        return VS_ERR_UNSUPPORTED;
+    }
+    if (offsets[0] != 0 || offsets[nlist] != n_rows) {
+        set_error("cluster_offsets do not cover the vectors");
+        return VS_ERR_INVALID;
+    }
+    for (int c = 0; c < nlist; ++c)
+        if (offsets[c + 1] < offsets[c]) {
+            set_error("cluster_offsets not monotone");
+            return VS_ERR_INVALID;
+        }
+    int rc = check_device(device);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(device));
+    vs_index* h = new vs_index();
+    h->kind = 1;
+    h->device = device;
+    h->dim = dim;
+    h->metric = VS_METRIC_L2;
+    h->n_total = n_rows;
+    h->nlist = nlist;
+    h->rank = rank;
+    h->world = world;
+    h->h_offsets_global.assign(offsets, offsets + nlist + 1);
+    h->avg_cluster_size = (double)n_rows / nlist;
+
+    // Ownership: lists sorted by length (desc), dealt round-robin -> balanced bytes and probe hits
+    // (SURVEY.md 8e).  Only owned lists are made resident; the others become empty ranges.
+    std::vector<int> order(nlist);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+        return (offsets[a + 1] - offsets[a]) > (offsets[b + 1] - offsets[b]);
+    });
+    std::vector<uint8_t> owned(nlist, 0);
+    for (int i = 0; i < nlist; ++i) owned[order[i]] = (i % world) == rank;
+    std::vector<int32_t> loc_off(nlist + 1, 0);
+    for (int c = 0; c < nlist; ++c) loc_off[c + 1] = loc_off[c] + (owned[c] ? offsets[c + 1] - offsets[c] : 0);
+    const int64_t n_local = loc_off[nlist];
+    h->n_rows = n_local;
+    std::vector<int32_t> loc_r2o((size_t)std::max<int64_t>(n_local, 1));
+    const float* up = vectors;
+    std::vector<float> packed;
+    if (world > 1) {
+        packed.resize((size_t)std::max<int64_t>(n_local, 1) * dim);
+        for (int c = 0; c < nlist; ++c)
+            if (owned[c] && offsets[c + 1] > offsets[c])
+                std::memcpy(&packed[(size_t)loc_off[c] * dim], vectors + (size_t)offsets[c] * dim,
+                            (size_t)(offsets[c + 1] - offsets[c]) * dim * sizeof(float));
+        up = packed.data();
+    }
+    for (int c = 0; c < nlist; ++c)
+        if (owned[c])
+            for (int32_t r = offsets[c]; r < offsets[c + 1]; ++r)
+                loc_r2o[(size_t)loc_off[c] + (r - offsets[c])] = r2o ? r2o[r] : r;
+
+    auto fail = [&](int code) {
+        free_all(h);
+        return code;
+    };
+    if ((rc = upload_vectors(h, up, n_local))) return fail(rc);
+    if ((rc = dev_alloc(&h->d_centroids, (size_t)nlist * dim))) return fail(rc);
+    if ((rc = dev_alloc(&h->d_cnorm, (size_t)nlist + 16))) return fail(rc);
+    if ((rc = dev_alloc(&h->d_offsets, (size_t)nlist + 1))) return fail(rc);
+    if ((rc = dev_alloc(&h->d_r2o, (size_t)std::max<int64_t>(n_local, 1)))) return fail(rc);
+    hipError_t e;
+    if ((e = hipMemset(h->d_cnorm, 0, ((size_t)nlist + 16) * sizeof(float))) != hipSuccess ||
+        (e = hipMemcpy(h->d_centroids, centroids, (size_t)nlist * dim * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(h->d_offsets, loc_off.data(), ((size_t)nlist + 1) * sizeof(int32_t), hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(h->d_r2o, loc_r2o.data(), (size_t)std::max<int64_t>(n_local, 1) * sizeof(int32_t), hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = vs::launch_row_sqnorm(h->d_centroids, nlist, dim, h->d_cnorm, nullptr)) != hipSuccess ||
+        (e = hipDeviceSynchronize()) != hipSuccess) {
+        set_error(std::string("ivf upload: ") + hipGetErrorString(e));
+        return fail(VS_ERR_DEVICE);
+    }
+    if ((rc = alloc_scratch(h))) return fail(rc);
+    *out = h;
+    return VS_OK;
+}
+
+int vs_ivf_create(const float* vectors_reordered, int64_t n_rows, int dim, const float* centroids, int nlist,
+                  const int32_t* cluster_offsets, const int32_t* reorder_to_original, int device, int rank, int world,
+                  vs_index** out) {
+    return ivf_create_impl(vectors_reordered, n_rows, dim, centroids, nlist, cluster_offsets, reorder_to_original,
+                           device, rank, world, out);
+}
+
+int vs_ivf_load(const char* index_dir, int device, int rank, int world, vs_index** out) {
+    if (!index_dir || !out) {
+        set_error("vs_ivf_load: bad arguments");
+        return VS_ERR_INVALID;
+    }
+    const std::string dir(index_dir);
+    vs::IvfConfig cfg;
+    if (!vs::ivf_config_read(dir + "/ivf_config.json", cfg)) return VS_ERR_IO;
+    std::vector<int32_t> offsets, r2o;
+    std::vector<float> vecs, cents;
+    std::vector<int64_t> shp;
+    if (!vs::npy_read_i32(dir + "/cluster_offsets.npy", offsets, shp)) return VS_ERR_IO;  // IVFIndex.cpp:210-213
+    if (!vs::npy_read_f32(dir + "/centroids.npy", cents, shp)) return VS_ERR_IO;
+    if (shp.size() != 2 || shp[0] != cfg.n_clusters || shp[1] != cfg.dim) {
+        set_error("centroids.npy shape does not match ivf_config.json");
+        return VS_ERR_IO;
+    }
+    if ((int64_t)offsets.size() != cfg.n_clusters + 1) {
+        set_error("cluster_offsets.npy length != n_clusters + 1");
+        return VS_ERR_IO;
+    }
+    if (cfg.reordered) {
+        if (!vs::npy_read_i32(dir + "/reorder_to_original.npy", r2o, shp)) return VS_ERR_IO;  // IVFIndex.cpp:225-228
+        if (!vs::npy_read_f32(dir + "/vectors_reordered.npy", vecs, shp)) return VS_ERR_IO;   // IVFIndex.cpp:239-244
+    } else {
+        // plain mode (IVFIndex.cpp:216-222,247-252): gather into the contiguous layout at load time
+        std::vector<int32_t> cidx;
+        std::vector<float> plain;
+        if (!vs::npy_read_i32(dir + "/cluster_indices.npy", cidx, shp)) return VS_ERR_IO;
+        if (!vs::npy_read_f32(dir + "/vectors.npy", plain, shp)) return VS_ERR_IO;
+        if (shp.size() != 2 || shp[1] != cfg.dim) {
+            set_error("vectors.npy shape mismatch");
+            return VS_ERR_IO;
+        }
+        const int64_t n = (int64_t)cidx.size();
+        vecs.resize((size_t)n * cfg.dim);
+        r2o = cidx;
+        for (int64_t i = 0; i < n; ++i) {
+            if (cidx[i] < 0 || cidx[i] >= shp[0]) {
+                set_error("cluster_indices.npy out of range");
+                return VS_ERR_IO;
+            }
+            std::memcpy(&vecs[(size_t)i * cfg.dim], &plain[(size_t)cidx[i] * cfg.dim], (size_t)cfg.dim * sizeof(float));
+        }
+    }
+    const int64_t n = (int64_t)vecs.size() / std::max<int64_t>(cfg.dim, 1);
+    if (n != cfg.n_vectors || (int64_t)r2o.size() != n) {
+        set_error("vector count does not match ivf_config.json");
+        return VS_ERR_IO;
+    }
+    int rc = ivf_create_impl(vecs.data(), n, (int)cfg.dim, cents.data(), (int)cfg.n_clusters, offsets.data(), r2o.data(),
+                             device, rank, world, out);
+    if (rc == VS_OK && cfg.avg_cluster_size > 0) (*out)->avg_cluster_size = cfg.avg_cluster_size;
+    return rc;
+}
+
+int vs_ivf_save(vs_index* h, const char* index_dir) {
+    if (!h || h->kind != 1 || !index_dir) {
+        set_error("vs_ivf_save: bad arguments");
+        return VS_ERR_INVALID;
+    }
+    if (h->world != 1) {
+        set_error("vs_ivf_save needs an unsharded index");
+        return VS_ERR_UNSUPPORTED;
+    }
+    int rc = set_device(h);
+    if (rc) return rc;
+    const std::string dir(index_dir);
+    std::vector<float> vecs((size_t)h->n_rows * h->dim), cents((size_t)h->nlist * h->dim);
+    std::vector<int32_t> r2o((size_t)h->n_rows);
+    HIPCHK(hipMemcpy(vecs.data(), h->d_vecs, vecs.size() * sizeof(float), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(cents.data(), h->d_centroids, cents.size() * sizeof(float), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(r2o.data(), h->d_r2o, r2o.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    std::vector<int32_t> sizes(h->nlist);
+    int32_t mn = std::numeric_limits<int32_t>::max(), mx = 0;
+    for (int c = 0; c < h->nlist; ++c) {
+        sizes[c] = h->h_offsets_global[c + 1] - h->h_offsets_global[c];
+        mn = std::min(mn, sizes[c]);
+        mx = std::max(mx, sizes[c]);
+    }
+    vs::IvfConfig cfg;
+    cfg.n_vectors = h->n_rows;
+    cfg.n_clusters = h->nlist;
+    cfg.dim = h->dim;
+    cfg.batch_size = h->batch;
+    cfg.avg_cluster_size = (double)h->n_rows / h->nlist;
+    cfg.min_cluster_size = mn;
+    cfg.max_cluster_size = mx;
+    cfg.reordered = true;
+    if (!vs::ivf_config_write(dir + "/ivf_config.json", cfg)) return VS_ERR_IO;
+    if (!vs::npy_write(dir + "/vectors_reordered.npy", vecs.data(), "<f4", {h->n_rows, h->dim}, 4)) return VS_ERR_IO;
+    if (!vs::npy_write(dir + "/reorder_to_original.npy", r2o.data(), "<i4", {h->n_rows}, 4)) return VS_ERR_IO;
+    if (!vs::npy_write(dir + "/cluster_offsets.npy", h->h_offsets_global.data(), "<i4", {h->nlist + 1}, 4)) return VS_ERR_IO;
+    if (!vs::npy_write(dir + "/cluster_sizes.npy", sizes.data(), "<i4", {h->nlist}, 4)) return VS_ERR_IO;
+    if (!vs::npy_write(dir + "/centroids.npy", cents.data(), "<f4", {h->nlist, h->dim}, 4)) return VS_ERR_IO;
+    return VS_OK;
+}
+
+int vs_ivf_search_dev(vs_index* h, const float* queries_dev, int B, int k, int nprobe, int32_t* ids_dev,
+                      float* dists_dev, void* stream) {
+    if (!h || h->kind != 1 || !queries_dev || !ids_dev || !dists_dev || B < 1 || B > vs::kMaxBatch || k < 1 || nprobe < 1) {
+        set_error("vs_ivf_search_dev: bad arguments");
+        return VS_ERR_INVALID;
+    }
+    nprobe = std::min(nprobe, h->nlist);  // IVFIndex.cpp:647
+    if (nprobe > kMaxNprobe) {
+        set_error("nprobe > 256 not supported");
+        return VS_ERR_UNSUPPORTED;
+    }
+    int rc = set_device(h);
+    if (rc) return rc;
+    return ivf_batch_dev(h, queries_dev, B, k, nprobe, dists_dev, ids_dev, static_cast<hipStream_t>(stream), nullptr);
+}
+
+int vs_ivf_search(vs_index* h, const float* queries_host, int64_t nq, int k, int nprobe, int32_t* ids, float* dists,
+                  int64_t* total_candidates, vs_timing* timing) {
+    if (!h || h->kind != 1 || !queries_host || !ids || !dists || nq < 0 || k < 1 || nprobe < 1) {
+        set_error("vs_ivf_search: bad arguments");
+        return VS_ERR_INVALID;
+    }
+    nprobe = std::min(nprobe, h->nlist);
+    if (nprobe > kMaxNprobe) {
+        set_error("nprobe > 256 not supported");
+        return VS_ERR_UNSUPPORTED;
+    }
+    int rc = set_device(h);
+    if (rc) return rc;
+    const double t_start = now_ms();
+    vs_timing tm{};
+    HIPCHK(hipMemsetAsync(h->d_cand, 0, sizeof(unsigned long long), h->stream));
+    std::vector<float> hd((size_t)32 * k);
+    std::vector<int32_t> hi((size_t)32 * k);
+    const float inf = std::numeric_limits<float>::infinity();
+    for (int64_t q0 = 0; q0 < nq; q0 += h->batch) {
+        const int B = (int)std::min<int64_t>(h->batch, nq - q0);
+        double t0 = now_ms();
+        HIPCHK(hipMemcpyAsync(h->d_q, queries_host + q0 * vs::kDim, (size_t)B * vs::kDim * sizeof(float),
+                              hipMemcpyHostToDevice, h->stream));
+        double t1 = now_ms();
+        rc = ivf_batch_dev(h, h->d_q, B, k, nprobe, h->d_out_d, h->d_out_i, h->stream, nullptr);
+        if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(hd.data(), h->d_out_d, (size_t)B * k * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(hi.data(), h->d_out_i, (size_t)B * k * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        double t2 = now_ms();
+        tm.h2d_ms += t1 - t0;
+        tm.fine_search_ms += t2 - t1;
+        for (int b = 0; b < B; ++b)
+            for (int t = 0; t < k; ++t) {
+                const int32_t id = hi[(size_t)b * k + t];
+                ids[(q0 + b) * k + t] = id;
+                dists[(q0 + b) * k + t] = id >= 0 ? hd[(size_t)b * k + t] : inf;
+            }
+    }
+    unsigned long long cand = 0;
+    HIPCHK(hipMemcpy(&cand, h->d_cand, sizeof(cand), hipMemcpyDeviceToHost));
+    if (total_candidates) *total_candidates = (int64_t)cand;
+    tm.total_ms = now_ms() - t_start;
+    if (timing) *timing = tm;
+    return VS_OK;
+}
+
+// --------------------------------------------------------------------------------------- multi-GPU
+int vs_topk_merge_dev(const float* dists_dev, const int32_t* ids_dev, int G, int B, int kin, int64_t stride_g,
+                      int kout, float* out_dists_dev, int32_t* out_ids_dev, int32_t* flags_dev, void* stream) {
+    if (!dists_dev || !ids_dev || !out_dists_dev || !out_ids_dev || G < 1 || B < 1 || kin < 1 || kout < 1) {
+        set_error("vs_topk_merge_dev: bad arguments");
+        return VS_ERR_INVALID;
+    }
+    vs::MergeParams m{};
+    m.part_d = dists_dev;
+    m.part_i = ids_dev;
+    m.G = G;
+    m.kin = kin;
+    m.nq = B;
+    m.kout = kout;
+    m.out_d = out_dists_dev;
+    m.out_i = out_ids_dev;
+    m.flags = flags_dev;
+    HIPCHK(vs::launch_merge_layout(m, stride_g > 0 ? stride_g : (int64_t)B * kin, kin, static_cast<hipStream_t>(stream)));
+    return VS_OK;
+}
+
+}  // extern "C"

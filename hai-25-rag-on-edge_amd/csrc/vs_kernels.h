@@ -1,0 +1,85 @@
+// vs_kernels.h -- host-callable launchers of the gfx950 kernels (internal to libvsearch_hip.so).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vs {
+
+constexpr int kDim = 128;          // SIFT descriptor length; the scan kernels are specialised for it
+constexpr int kTileRows = 16;      // base rows per MFMA tile (v_mfma_f32_16x16x4_f32, base = A operand)
+constexpr int kScanThreads = 512;  // 8 waves: 2 per SIMD
+constexpr int kScanWaves = 8;
+constexpr int kMaxBatch = 32;      // queries per scan pass (two 16-query MFMA column blocks)
+
+enum ScanMode { kModeTopK = 0, kModeStore = 1 };
+
+struct ScanParams {
+    const float* base;       // [n_rows][128] row-major (the flat fvecs payload, cpu_baseline.cpp:48-49)
+    const float* bnorm;      // [n_rows (+16 pad)] squared norms (cpu_baseline.cpp:116-125)
+    const float* q;          // [32][128] zero-padded queries
+    const float* qnorm;      // [32]
+    const float* tau0;       // [32] initial thresholds or nullptr (= +inf)
+    int64_t row_begin;       // multiple of 16
+    int64_t row_end;         // exclusive
+    int tiles_per_wg;
+    int metric;              // 0 = L2, 1 = IP (scores negated so that smallest wins)
+    int32_t id_offset;       // added to the row number
+    int nq_valid;            // queries beyond this are padding
+    // kModeTopK outputs: per-workgroup sorted partial lists
+    float* part_d;           // [grid][32][KCAP]
+    int32_t* part_i;
+    // kModeStore output
+    float* store;            // [nq_valid][store_ld], column = row - row_begin
+    int64_t store_ld;
+};
+
+// Brute-force / coarse scan.  kcap in {8, 16}; nqh = 1 (<=16 queries) or 2.
+hipError_t launch_scan(const ScanParams& p, int grid, int kcap, int nqh, int mode, hipStream_t s);
+
+// Cross-workgroup merge of sorted partial lists -> [nq][kout] + tie flags (+ seed thresholds).
+struct MergeParams {
+    const float* part_d;     // [G][nq_stride][kin]
+    const int32_t* part_i;
+    int G;
+    int nq_stride;           // queries per partial block (32 for scan partials)
+    int kin;
+    int nq;                  // queries to produce
+    int kout;                // entries to write per query (<= kin)
+    float* out_d;            // [nq][kout] or nullptr
+    int32_t* out_i;
+    int32_t* flags;          // [nq] or nullptr: adjacent equal distances among the first kout
+    float* tau_out;          // [32] or nullptr: nextafter(kout-th best) used as scan seed
+    const int32_t* id_map;   // optional: out id = id_map[id] (IVF reorder_to_original)
+};
+hipError_t launch_merge(const MergeParams& p, hipStream_t s);  // scan-partial layout [G][nq_stride][kin]
+// general layout: entry (g, q, j) at g*stride_g + q*stride_q + j
+hipError_t launch_merge_layout(const MergeParams& p, int64_t stride_g, int64_t stride_q, hipStream_t s);
+
+// ||v||^2 per row in the reference's AVX2 summation order (cpu_baseline.cpp:95-114).
+hipError_t launch_row_sqnorm(const float* v, int64_t rows, int dim, float* out, hipStream_t s);
+
+// Pad B queries to 32 x 128 (zeros, main.cpp:206-211) and compute their norms.
+hipError_t launch_prep_queries(const float* q, int B, float* qpad, float* qnorm, hipStream_t s);
+
+// ---- IVF ----
+// Per query: the nprobe nearest centroids (ascending (dist, id)) out of a [B][ld] score matrix.
+hipError_t launch_pick_probes(const float* scores, int64_t ld, int B, int nlist, int nprobe,
+                              int32_t* probes /*[B][nprobe]*/, hipStream_t s);
+
+struct IvfScanParams {
+    const float* vecs;        // [n_rows][128] cluster-reordered (vectors_reordered.npy)
+    const float* vnorm;       // [n_rows]
+    const int32_t* offsets;   // [nlist+1] (cluster_offsets.npy)
+    const uint8_t* owned;     // [nlist] 1 = this shard scans the list, or nullptr = all
+    const float* q;           // [32][128]
+    const float* qnorm;       // [32]
+    const int32_t* probes;    // [B][nprobe]
+    int B, nprobe, kcap;
+    int metric;
+    float* part_d;            // [B][nprobe][kcap]
+    int32_t* part_i;          // reordered row positions
+    unsigned long long* cand_count;  // total rows scanned (IVFIndex::searchBatch return value)
+};
+hipError_t launch_ivf_scan(const IvfScanParams& p, hipStream_t s);
+
+}  // namespace vs

@@ -1,0 +1,184 @@
+/*
+ * vsearch.h -- C ABI of libvsearch_hip.so, the MI355X (gfx950) vector-search backend.
+ *
+ * This is the drop-in boundary for the distance + top-k hot path of
+ * zyx7k/HAI-25-RAG-on-Edge.  The reference has no FFI; its device seam is the
+ * C++ class pair QnnRunner ("queries[B x d] in -> scores[B x N] out") and
+ * IVFIndex ("queries in -> (ids, scores) out").  Every entry point below cites
+ * the reference interface it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *   - plain C, no exceptions: every call returns VS_OK (0) or a negative
+ *     vs_status; vs_last_error() gives the message for the calling thread.
+ *     (Reference: bool + std::cerr in cpu/cpu_baseline.cpp:194-207; throw
+ *     std::runtime_error caught in main in main_ivf.cpp:287-290.)
+ *   - "host" pointers are ordinary memory owned by the caller; "_dev" entry
+ *     points take device (HBM) pointers and a hipStream_t passed as void*.
+ *   - one vs_index = one GPU = one caller thread at a time (QnnRunner is not
+ *     re-entrant either: shared I/O buffers, QnnRunner.cpp:322-323).
+ *   - ids are 0-based row numbers of the base file (cpu_baseline.cpp:130,142),
+ *     or reorder_to_original[] values for IVF (IVFIndex.cpp:774-779).
+ *   - the product path never falls back to a CPU implementation: without a
+ *     usable HIP device every create/search call fails with VS_ERR_DEVICE.
+ */
+#ifndef VSEARCH_H
+#define VSEARCH_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VS_API __attribute__((visibility("default")))
+
+typedef enum vs_status {
+    VS_OK = 0,
+    VS_ERR_INVALID = -1,     /* bad argument / shape mismatch (main.cpp:121-126, main_ivf.cpp:106-109) */
+    VS_ERR_IO = -2,          /* cannot open / truncated / inconsistent file (cpu_baseline.cpp:33-56)     */
+    VS_ERR_DEVICE = -3,      /* HIP error or no gfx950 device                                              */
+    VS_ERR_NOMEM = -4,
+    VS_ERR_UNSUPPORTED = -5  /* e.g. dim != 128, k too large for the compiled kernels                      */
+} vs_status;
+
+typedef enum vs_metric {
+    VS_METRIC_L2 = 0,        /* squared L2, smallest wins (cpu_baseline.cpp:239-242) -- every graded config */
+    VS_METRIC_IP = 1         /* raw inner product, largest wins (qidk main.cpp:30-57, IVFIndex.cpp:449-496) */
+} vs_metric;
+
+typedef struct vs_index vs_index; /* opaque: owns device memory, scratch, streams */
+
+/* Mirrors IVFIndex::SearchTiming (IVFIndex.h:31-36) plus the distance / top-k
+ * split cpu_baseline prints (cpu_baseline.cpp:281-299).  All in milliseconds,
+ * accumulated over the call. */
+typedef struct vs_timing {
+    double centroid_search_ms; /* IVF coarse stage (IVFIndex.cpp:654-666)                  */
+    double gather_ms;          /* probe selection (IVFIndex.cpp:694-726)                   */
+    double fine_search_ms;     /* scan + top-k; for brute force: the whole device pipeline */
+    double total_ms;           /* wall time of the call                                    */
+    double h2d_ms;             /* query upload                                             */
+    double d2h_ms;             /* result download                                          */
+    double tie_resolve_ms;     /* exact select_topk slot emulation for flagged queries     */
+    int64_t tie_queries;       /* how many queries needed it                               */
+} vs_timing;
+
+/* ------------------------------------------------------------------ library */
+VS_API const char* vs_version(void);
+VS_API const char* vs_last_error(void);           /* thread-local, never NULL */
+VS_API int vs_device_count(void);                 /* 0 when no HIP device is visible */
+
+/* -------------------------------------------------------------- file formats */
+/* .fvecs / .ivecs: repeated [int32 d][d x 4 bytes], little endian
+ * (cpu_baseline.cpp:31-58 read_fvecs; main_ivf.cpp:18-50 load_fvecs/load_ivecs).
+ * *_shape fills rows/dim only; *_read needs cap_elems >= rows*dim. */
+VS_API int vs_fvecs_shape(const char* path, int64_t* rows, int* dim);
+VS_API int vs_fvecs_read(const char* path, float* dst, int64_t cap_elems, int64_t* rows, int* dim);
+VS_API int vs_ivecs_read(const char* path, int32_t* dst, int64_t cap_elems, int64_t* rows, int* dim);
+VS_API int vs_fvecs_write(const char* path, const float* src, int64_t rows, int dim);
+VS_API int vs_ivecs_write(const char* path, const int32_t* src, int64_t rows, int dim);
+
+/* results.txt: "Query <i>: (<id>, <dist>) ...\n".
+ * style 0 = cpu_baseline.cpp:155-175 (default ostream float formatting),
+ * style 1 = main_ivf.cpp:179-183 (std::fixed, 4 decimals).  ids < 0 are skipped. */
+VS_API int vs_results_write(const char* path, const int32_t* ids, const float* dists,
+                            int64_t nq, int k, int style);
+
+/* Deterministic SIFT-shaped synthetic data: integer-valued
+ * f32 in [0, 218], clustered.  Row i depends only on (seed, i), so any slice
+ * can be generated independently.  row_begin lets ranks generate shards. */
+VS_API int vs_synth_sift(float* dst, int64_t row_begin, int64_t rows, int dim, uint64_t seed);
+
+/* The reference's select_topk (cpu_baseline.cpp:127-153) applied to a sparse,
+ * row-ordered candidate list; exposed so the tie resolver can be unit-tested. */
+VS_API int vs_select_topk_slots(const int32_t* rows, const float* dists, int64_t m, int k,
+                                int32_t* out_ids, float* out_dists);
+
+/* -------------------------------------------------------- exact brute force */
+/* Replaces the body of run_benchmark's query loop (cpu_baseline.cpp:209-254):
+ * norms + cblas_sgemm(1 x N x d) + L2 epilogue + select_topk, and the QNN
+ * "database baked into the model" runner (QnnRunner ctor, QnnRunner.h:20).
+ * The base is copied to HBM once; id_offset is added to every returned id
+ * (row-sharded multi-GPU: each rank passes its shard and its first row). */
+VS_API int vs_bf_create(const float* base_host, int64_t n_rows, int dim, int metric,
+                        int device, int64_t id_offset, vs_index** out);
+
+/* Fixed model batch, like QnnRunner::getBatchSize (QnnRunner.h:37); 1..32, default 32.
+ * Larger query sets are processed in batches of this size, the last one
+ * zero-padded (main.cpp:206-211). */
+VS_API int vs_set_batch(vs_index* h, int batch);
+
+/* Host-buffer search with the reference's exact semantics: ids/dists are
+ * [nq x k], ascending distance, ties ordered exactly as select_topk leaves
+ * them (flagged queries are re-resolved, see DESIGN.md "Ties").  k clamps to
+ * n_rows; unused slots are id -1 / dist +inf. */
+VS_API int vs_bf_search(vs_index* h, const float* queries_host, int64_t nq, int k,
+                        int32_t* ids, float* dists, vs_timing* timing);
+
+/* Device-level, asynchronous on `stream`: one batch (B <= batch) of queries
+ * already in HBM -> the k+1 best (dist, id) per query by (dist, id) ascending,
+ * [B x (k+1)], plus flags[B] != 0 where two of those distances are equal (the
+ * caller must then use vs_bf_search for reference tie order).  This is the
+ * analogue of QnnRunner::executeBatchRaw + getRawOutputBuffer (QnnRunner.h:28-30)
+ * with the top-k fused in, so the B x N score matrix never exists. */
+VS_API int vs_bf_search_dev(vs_index* h, const float* queries_dev, int B, int k,
+                            int32_t* ids_dev, float* dists_dev, int32_t* flags_dev, void* stream);
+
+/* QnnRunner::executeBatchRaw proper (QnnRunner.cpp:683-724): the raw
+ * [B x ld] score matrix, scores_dev[b*ld + j] = dist(query b, row j), ld >= n_rows. */
+VS_API int vs_bf_scores_dev(vs_index* h, const float* queries_dev, int B,
+                            float* scores_dev, int64_t ld, void* stream);
+
+/* ---------------------------------------------------------------------- IVF */
+/* IVFIndex ctor (IVFIndex.cpp:154-177): reads ivf_config.json, cluster_offsets.npy,
+ * vectors_reordered.npy, reorder_to_original.npy (reordered mode) and
+ * centroids.npy (the reference bakes centroids into centroids.bin for the NPU,
+ * IVFIndex.cpp:167-169).  rank/world select the lists this GPU owns
+ * (cluster-sharded search); 0/1 = everything. */
+VS_API int vs_ivf_load(const char* index_dir, int device, int rank, int world, vs_index** out);
+
+/* Same, from arrays in host memory (layout of create_ivf_model_reordered.py:141-169). */
+VS_API int vs_ivf_create(const float* vectors_reordered, int64_t n_rows, int dim,
+                         const float* centroids, int nlist, const int32_t* cluster_offsets,
+                         const int32_t* reorder_to_original, int device, int rank, int world,
+                         vs_index** out);
+
+/* Writes the index held by h in the reference's directory format. */
+VS_API int vs_ivf_save(vs_index* h, const char* index_dir);
+
+/* IVFIndex::searchBatch (IVFIndex.h:45-48, IVFIndex.cpp:640-859): ids/dists
+ * [nq x k] (L2: ascending distance; ids are original row numbers), returns the
+ * total number of candidates scanned through *total_candidates (the
+ * function's return value in the reference) and the SearchTiming fields. */
+VS_API int vs_ivf_search(vs_index* h, const float* queries_host, int64_t nq, int k, int nprobe,
+                         int32_t* ids, float* dists, int64_t* total_candidates, vs_timing* timing);
+
+/* Device-level, asynchronous: one batch, outputs [B x k] on the device.
+ * For a sharded index the outputs are this shard's local top-k (global ids). */
+VS_API int vs_ivf_search_dev(vs_index* h, const float* queries_dev, int B, int k, int nprobe,
+                             int32_t* ids_dev, float* dists_dev, void* stream);
+
+/* ---------------------------------------------------------------- multi-GPU */
+/* Merge G per-shard sorted lists (e.g. the receive buffer of an RCCL
+ * all-gather) into [B x kout] by (dist, id) ascending; flags as above when
+ * flags_dev != NULL.  Entry (g, b, j) lives at g*stride_g + b*kin + j in both
+ * arrays; stride_g = 0 means the dense layout B*kin.  Runs on the current
+ * device, asynchronously on `stream`. */
+VS_API int vs_topk_merge_dev(const float* dists_dev, const int32_t* ids_dev, int G, int B, int kin,
+                             int64_t stride_g, int kout, float* out_dists_dev, int32_t* out_ids_dev,
+                             int32_t* flags_dev, void* stream);
+
+/* ------------------------------------------------------------------ profiling */
+/* HIP-event timing of the dominant scan kernel on the stream it is launched on
+ * (bench.py's roofline leg).  which: 0 = brute-force scan, 1 = IVF list scan. */
+VS_API int vs_prof_enable(vs_index* h, int on);
+VS_API int vs_prof_read(vs_index* h, int which, double* total_ms, int64_t* launches);
+
+VS_API int64_t vs_index_rows(const vs_index* h);
+VS_API int vs_index_dim(const vs_index* h);
+VS_API int vs_index_nlist(const vs_index* h);     /* 0 for brute force */
+VS_API void vs_destroy(vs_index* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VSEARCH_H */

@@ -1,0 +1,205 @@
+"""Parity of the HIP path with the CPU oracle, through the C ABI (libvsearch_hip.so).
+Integer-valued data: bit-exact ids AND distances, including the reference's tie order.
+Non-integer data: ids equal wherever the oracle's own distance gap exceeds fp32 re-association
+error, distances within rtol 2e-6 * max(||q||^2 + ||b||^2) (the tolerance is in the test)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _int_data(rng, n, nq, hi=219):
+    return (rng.integers(0, hi, size=(n, 128)).astype(np.float32),
+            rng.integers(0, hi, size=(nq, 128)).astype(np.float32))
+
+
+def _check_exact(pkg, base, q, k, batch=None):
+    with pkg.BruteForceIndex(base) as idx:
+        if batch:
+            idx.set_batch(batch)
+        ids, d = idx.search(q, k)
+    oi, od = oracle.search_bf(base, q, k)
+    assert np.array_equal(ids, oi), f"ids differ (N={len(base)}, nq={len(q)}, k={k}, batch={batch})"
+    assert np.array_equal(d, od)
+
+
+@pytest.mark.parametrize("tag", ["fwd", "rev"])
+def test_reference_tie_probes(gpu_pkg, golden_dir, tag):
+    b = gpu_pkg.read_fvecs(os.path.join(golden_dir, f"ref_ties_{tag}_base.fvecs"))
+    q = gpu_pkg.read_fvecs(os.path.join(golden_dir, f"ref_ties_{tag}_query.fvecs"))
+    rid, rd = oracle.parse_results_txt(os.path.join(golden_dir, f"ref_ties_{tag}_results.txt"))
+    with gpu_pkg.BruteForceIndex(b) as idx:
+        tm = gpu_pkg.Timing()
+        ids, d = idx.search(q, 5, tm)
+    assert np.array_equal(ids, np.array(rid)) and np.array_equal(d, np.array(rd, dtype=np.float32))
+    assert tm.tie_queries == len(q)  # every query of this fixture has ties inside the top-(k+1)
+
+
+def test_reference_synth10k(gpu_pkg, golden_dir, tmp_path):
+    z = np.load(os.path.join(golden_dir, "ref_synth10k_inputs.npz"))
+    base, query = z["base"].astype(np.float32), z["query"].astype(np.float32)
+    with gpu_pkg.BruteForceIndex(base) as idx:
+        ids, d = idx.search(query, 5)
+    out = str(tmp_path / "siftsmall_results.txt")
+    gpu_pkg.write_results(out, ids, d)
+    # byte-identical to what the reference binary wrote
+    assert open(out).read() == open(os.path.join(golden_dir, "ref_synth10k_results.txt")).read()
+
+
+@pytest.mark.parametrize("n", [1, 4, 5, 6, 15, 16, 17, 127, 1000, 4099])
+def test_small_and_ragged_bases(gpu_pkg, n):
+    rng = np.random.default_rng(n)
+    base, q = _int_data(rng, n, 7)
+    for k in (1, 5):
+        _check_exact(gpu_pkg, base, q, k)
+
+
+@pytest.mark.parametrize("nq,batch", [(1, 32), (2, 32), (16, 32), (17, 32), (31, 32), (32, 32), (33, 32), (100, 32),
+                                      (5, 1), (40, 8), (40, 16), (35, 17)])
+def test_batch_padding_paths(gpu_pkg, nq, batch):
+    rng = np.random.default_rng(100 + nq + batch)
+    base, q = _int_data(rng, 10000, nq)
+    _check_exact(gpu_pkg, base, q, 5, batch)
+
+
+@pytest.mark.parametrize("k", [1, 2, 5, 7, 8, 10, 15])
+def test_k_values(gpu_pkg, k):
+    rng = np.random.default_rng(200 + k)
+    base, q = _int_data(rng, 6000, 33)
+    _check_exact(gpu_pkg, base, q, k)
+
+
+def test_k_too_large_is_refused_not_faked(gpu_pkg):
+    rng = np.random.default_rng(1)
+    base, q = _int_data(rng, 500, 2)
+    with gpu_pkg.BruteForceIndex(base) as idx:
+        with pytest.raises(gpu_pkg.VSearchError) as e:
+            idx.search(q, 16)
+    assert e.value.status == -5
+
+
+def test_heavy_ties_and_duplicates(gpu_pkg):
+    # tiny alphabet -> many equal distances; duplicated rows like SIFT-1M has
+    rng = np.random.default_rng(7)
+    base = rng.integers(0, 3, size=(5000, 128)).astype(np.float32)
+    base[1000:1200] = base[0:200]
+    base[3000:3050] = base[0]
+    q = np.concatenate([base[[0, 5, 1000, 3001]], rng.integers(0, 3, size=(20, 128)).astype(np.float32)])
+    for k in (1, 5, 10):
+        _check_exact(gpu_pkg, base, q, k)
+    # all rows identical: every distance ties
+    same = np.tile(base[:1], (300, 1))
+    _check_exact(gpu_pkg, same, q[:3], 5)
+    # descending distances: worst case for any running-threshold scheme
+    ramp = np.zeros((4000, 128), dtype=np.float32)
+    ramp[:, 0] = np.arange(4000, 0, -1) % 251
+    _check_exact(gpu_pkg, ramp, np.zeros((3, 128), dtype=np.float32), 5)
+
+
+def test_seeded_large_base_exact(gpu_pkg):
+    # >= 262144 rows turns on the seed-threshold pass; check against the oracle bit for bit
+    base = gpu_pkg.synth_sift(300000, seed=11)
+    q = gpu_pkg.synth_sift(48, seed=12)
+    q[3] = base[123456]            # exact hit
+    base[250000] = base[17]        # duplicate far apart
+    q[4] = base[17]
+    _check_exact(gpu_pkg, base, q, 5)
+    _check_exact(gpu_pkg, base, q[:5], 10)
+
+
+def test_non_integer_data_within_tolerance(gpu_pkg):
+    rng = np.random.default_rng(5)
+    base = rng.normal(0, 1, size=(20000, 128)).astype(np.float32)
+    q = rng.normal(0, 1, size=(37, 128)).astype(np.float32)
+    with gpu_pkg.BruteForceIndex(base) as idx:
+        ids, d = idx.search(q, 5)
+    oi, od = oracle.search_bf(base, q, 5)
+    scale = float((q ** 2).sum(1).max() + (base ** 2).sum(1).max())
+    tol = 2e-6 * scale
+    assert np.allclose(d, od, rtol=0, atol=tol)
+    gaps_ok = np.ones_like(oi, dtype=bool)
+    od6 = np.sort(np.stack([oracle.l2_row(q[i], base) for i in range(len(q))]), axis=1)[:, :7]
+    for i in range(len(q)):
+        for t in range(5):
+            lo = od6[i, t] - od6[i, t - 1] if t > 0 else np.inf
+            hi = od6[i, t + 1] - od6[i, t]
+            gaps_ok[i, t] = min(lo, hi) > 4 * tol
+    assert gaps_ok.mean() > 0.9
+    assert np.array_equal(ids[gaps_ok], oi[gaps_ok])
+
+
+def test_inner_product_metric(gpu_pkg):
+    rng = np.random.default_rng(6)
+    base, q = _int_data(rng, 3000, 10, hi=100)
+    base[:, 0] += np.arange(3000) % 7  # break ties
+    with gpu_pkg.BruteForceIndex(base, metric=gpu_pkg.METRIC_IP) as idx:
+        ids, s = idx.search(q, 5)
+    ip = q.astype(np.int64) @ base.astype(np.int64).T
+    order = np.argsort(-ip, axis=1, kind="stable")[:, :5]
+    assert np.array_equal(np.take_along_axis(ip, ids.astype(np.int64), 1), np.take_along_axis(ip, order, 1))
+    assert np.array_equal(s, np.take_along_axis(ip, order, 1).astype(np.float32))
+
+
+def test_device_level_api_and_score_matrix(gpu_pkg):
+    import torch
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(8)
+    base, q = _int_data(rng, 12345, 32)
+    s = torch.cuda.current_stream().cuda_stream
+    with gpu_pkg.BruteForceIndex(base) as idx:
+        for B in (1, 16, 17, 32):
+            qd = torch.from_numpy(q[:B]).to(dev)
+            ids = torch.full((B, 6), -7, dtype=torch.int32, device=dev)
+            d = torch.zeros((B, 6), dtype=torch.float32, device=dev)
+            fl = torch.zeros((B,), dtype=torch.int32, device=dev)
+            idx.search_dev(qd.data_ptr(), B, 5, ids.data_ptr(), d.data_ptr(), fl.data_ptr(), s)
+            torch.cuda.synchronize()
+            ex = oracle.exact_int_dists(q[:B], base)
+            want = np.sort(ex, axis=1)[:, :6].astype(np.float32)
+            assert np.array_equal(d.cpu().numpy(), want)
+            got_ids = ids.cpu().numpy().astype(np.int64)
+            assert np.array_equal(np.take_along_axis(ex, got_ids, 1).astype(np.float32), want)
+            flags = fl.cpu().numpy()
+            assert np.array_equal(flags != 0, (want[:, 1:] == want[:, :-1]).any(1))
+        # QnnRunner::executeBatchRaw analogue: the raw [B, ld] matrix
+        ld = 12352
+        sc = torch.full((32, ld), -1.0, dtype=torch.float32, device=dev)
+        qd = torch.from_numpy(q).to(dev)
+        idx.scores_dev(qd.data_ptr(), 32, sc.data_ptr(), ld, s)
+        torch.cuda.synchronize()
+        got = sc.cpu().numpy()
+        assert np.array_equal(got[:, :12345], oracle.exact_int_dists(q, base).astype(np.float32))
+        assert np.all(got[:, 12345:] == -1.0)  # padding columns untouched
+
+
+def test_topk_merge_equals_unsharded(gpu_pkg):
+    import torch
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(9)
+    base, q = _int_data(rng, 9000, 32, hi=40)
+    s = torch.cuda.current_stream().cuda_stream
+    qd = torch.from_numpy(q).to(dev)
+    K1 = 6
+    def run(b, off):
+        with gpu_pkg.BruteForceIndex(b, id_offset=off) as idx:
+            ids = torch.zeros((32, K1), dtype=torch.int32, device=dev)
+            d = torch.zeros((32, K1), dtype=torch.float32, device=dev)
+            idx.search_dev(qd.data_ptr(), 32, 5, ids.data_ptr(), d.data_ptr(), 0, s)
+            torch.cuda.synchronize()
+            return d, ids
+    d_all, i_all = run(base, 0)
+    for G in (2, 3, 8):
+        bounds = np.linspace(0, len(base), G + 1).astype(int)
+        parts = [run(base[bounds[g]:bounds[g + 1]], int(bounds[g])) for g in range(G)]
+        gd = torch.stack([p[0] for p in parts]).contiguous()   # [G, B, K1] = all-gather receive layout
+        gi = torch.stack([p[1] for p in parts]).contiguous()
+        od = torch.zeros((32, K1), dtype=torch.float32, device=dev)
+        oi = torch.zeros((32, K1), dtype=torch.int32, device=dev)
+        fl = torch.zeros((32,), dtype=torch.int32, device=dev)
+        gpu_pkg.topk_merge_dev(gd.data_ptr(), gi.data_ptr(), G, 32, K1, K1, od.data_ptr(), oi.data_ptr(), fl.data_ptr(), s)
+        torch.cuda.synchronize()
+        assert torch.equal(od, d_all) and torch.equal(oi, i_all)

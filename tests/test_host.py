@@ -1,0 +1,170 @@
+"""CPU-side checks of the product library: it loads, exports the whole C ABI, its host logic
+(file formats, result grammar, synthetic data, slot emulation) matches the oracle, and every
+compute entry point fails loudly when there is no GPU (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    hdr = open(os.path.join(ROOT, "include", "vsearch.h")).read()
+    declared = set(re.findall(r"VS_API\s+[\w\s\*]+?\b(vs_\w+)\s*\(", hdr))
+    assert len(declared) >= 25
+    L = pkg.lib()
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in include/vsearch.h but not exported"
+    assert declared == set(pkg.exported_symbols())
+    out = subprocess.check_output(["nm", "-D", "--defined-only", pkg.LIB_PATH]).decode()
+    exported = {l.split()[-1] for l in out.splitlines() if " T " in l}
+    assert declared <= exported
+    assert b"gfx950" in pkg.lib().vs_version()
+
+
+def test_no_cpu_fallback_without_gpu(pkg):
+    if pkg.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    base = np.zeros((64, 128), dtype=np.float32)
+    with pytest.raises(pkg.VSearchError) as e:
+        pkg.BruteForceIndex(base)
+    assert e.value.status == -3  # VS_ERR_DEVICE
+    with pytest.raises(pkg.VSearchError) as e:
+        pkg.IVFIndex(vectors_reordered=base, centroids=base[:4], cluster_offsets=[0, 16, 32, 48, 64])
+    assert e.value.status == -3
+
+
+def test_fvecs_ivecs_roundtrip_and_errors(pkg, tmp_path):
+    x = np.arange(5 * 128, dtype=np.float32).reshape(5, 128)
+    p = str(tmp_path / "a.fvecs")
+    pkg.write_fvecs(p, x)
+    assert os.path.getsize(p) == 5 * 516  # 4 + 4*128 per record
+    assert np.array_equal(pkg.read_fvecs(p), x)
+    assert np.array_equal(oracle.read_fvecs(p), x)
+    g = np.arange(300, dtype=np.int32).reshape(3, 100)
+    pi = str(tmp_path / "g.ivecs")
+    pkg.write_ivecs(pi, g)
+    assert np.array_equal(pkg.read_ivecs(pi), g)
+    with open(p, "ab") as f:
+        f.write(b"\x80\x00\x00\x00\x00")  # truncated record (cpu_baseline.cpp:53-56)
+    with pytest.raises(pkg.VSearchError) as e:
+        pkg.read_fvecs(p)
+    assert e.value.status == -2 and "truncated" in str(e.value)
+    with pytest.raises(pkg.VSearchError) as e:
+        pkg.read_fvecs(str(tmp_path / "missing.fvecs"))
+    assert e.value.status == -2 and "Cannot open" in str(e.value)
+    # inconsistent dimension (cpu_baseline.cpp:43-46)
+    bad = np.concatenate([np.array([2], np.int32).view(np.float32), np.zeros(2, np.float32),
+                          np.array([3], np.int32).view(np.float32), np.zeros(2, np.float32)])
+    pb = str(tmp_path / "bad.fvecs")
+    bad.tofile(pb)
+    with pytest.raises(pkg.VSearchError):
+        pkg.read_fvecs(pb)
+    # empty file: zero rows, like the reference's while-loop never running
+    pe = str(tmp_path / "empty.fvecs")
+    open(pe, "wb").close()
+    assert pkg.read_fvecs(pe).shape[0] == 0
+
+
+def test_results_grammar_matches_reference_writer(pkg, tmp_path, golden_dir):
+    ids, d = oracle.parse_results_txt(os.path.join(golden_dir, "ref_synth10k_results.txt"))
+    ids = np.array(ids, dtype=np.int32)
+    d = np.array(d, dtype=np.float32)
+    p = str(tmp_path / "r.txt")
+    pkg.write_results(p, ids, d)
+    assert open(p).read() == open(os.path.join(golden_dir, "ref_synth10k_results.txt")).read()
+    # default ostream formatting switches to exponent above 6 digits, like "%g"
+    big = np.array([[1234567.0, 0.5, 100000.0]], dtype=np.float32)
+    pkg.write_results(p, np.array([[1, 2, -1]], dtype=np.int32), big)
+    assert open(p).read() == "Query 0: (1, 1.23457e+06) (2, 0.5)\n"
+    po = str(tmp_path / "o.txt")
+    oracle.write_results(po, np.array([[1, 2, -1]], dtype=np.int32), big)
+    assert open(po).read() == open(p).read()
+    pkg.write_results(p, np.array([[7]], dtype=np.int32), np.array([[2.5]], dtype=np.float32), style=1)
+    assert open(p).read() == "Query 0: (7, 2.5000)\n"  # main_ivf.cpp:181
+
+
+def test_synth_sift_is_deterministic_and_sift_shaped(pkg):
+    a = pkg.synth_sift(3000, seed=20251205)
+    b = pkg.synth_sift(3000, seed=20251205)
+    assert np.array_equal(a, b)
+    assert np.array_equal(a[1000:1100], pkg.synth_sift(100, seed=20251205, row_begin=1000))  # shardable
+    assert not np.array_equal(a[:100], pkg.synth_sift(100, seed=20251206))
+    assert a.dtype == np.float32 and a.min() >= 0 and a.max() <= 218 and np.all(a == np.rint(a))
+    assert 10 < a.mean() < 60
+    # clustered: nearest neighbour much closer than a random pair
+    ex = oracle.exact_int_dists(a[:50], a[50:])
+    assert np.median(ex.min(1)) < 0.6 * np.median(ex)
+
+
+def test_slot_emulation_equals_oracle(pkg):
+    rng = np.random.default_rng(3)
+    for trial in range(40):
+        n = int(rng.integers(1, 300))
+        k = int(rng.integers(1, 8))
+        d = rng.integers(0, 10, size=n).astype(np.float32)
+        rows = np.arange(n, dtype=np.int32) * 3 + 1  # arbitrary increasing row numbers
+        pi, pd = pkg.select_topk_slots(rows, d, k)
+        oi, od = oracle.select_topk_sparse(rows, d, k)
+        assert np.array_equal(pi, oi) and np.array_equal(pd, od)
+
+
+def _write_index(tmp_path, n=200, nlist=4, reordered=True):
+    rng = np.random.default_rng(4)
+    v = rng.integers(0, 200, size=(n, 128)).astype(np.float32)
+    off = np.linspace(0, n, nlist + 1).astype(np.int32)
+    d = tmp_path / "idx"
+    d.mkdir(exist_ok=True)
+    np.save(d / "vectors_reordered.npy", v)
+    np.save(d / "reorder_to_original.npy", rng.permutation(n).astype(np.int32))
+    np.save(d / "cluster_offsets.npy", off)
+    np.save(d / "centroids.npy", rng.random((nlist, 128)).astype(np.float32))
+    import json
+    json.dump({"n_vectors": n, "n_clusters": nlist, "dim": 128, "batch_size": 32,
+               "avg_cluster_size": n / nlist, "reordered": reordered}, open(d / "ivf_config.json", "w"), indent=2)
+    return d
+
+
+def test_ivf_load_parses_reference_directory_format(pkg, tmp_path):
+    d = _write_index(tmp_path)
+    h = C.c_void_p(None)
+    rc = pkg.lib().vs_ivf_load(str(d).encode(), 0, 0, 1, C.byref(h))
+    if pkg.device_count() == 0:
+        # parsing succeeded (numpy-written v1 .npy + json), then the device step failed loudly
+        assert rc == -3, pkg.lib().vs_last_error()
+    else:
+        assert rc == 0
+        pkg.lib().vs_destroy(h)
+    # missing key -> the reference's "Missing n_clusters in config" (IVFIndex.cpp:193-195)
+    cfg = (d / "ivf_config.json").read_text().replace("n_clusters", "n_klusters")
+    (d / "ivf_config.json").write_text(cfg)
+    rc = pkg.lib().vs_ivf_load(str(d).encode(), 0, 0, 1, C.byref(h))
+    assert rc == -2 and b"Missing n_clusters" in pkg.lib().vs_last_error()
+    # wrong dtype is rejected instead of being reinterpreted (the reference ignores descr)
+    d2 = _write_index(tmp_path)
+    np.save(d2 / "cluster_offsets.npy", np.array([0, 50, 100, 150, 200], dtype=np.int64))
+    rc = pkg.lib().vs_ivf_load(str(d2).encode(), 0, 0, 1, C.byref(h))
+    assert rc == -2 and b"dtype" in pkg.lib().vs_last_error()
+    rc = pkg.lib().vs_ivf_load(str(tmp_path / "nope").encode(), 0, 0, 1, C.byref(h))
+    assert rc == -2 and b"Cannot open config file" in pkg.lib().vs_last_error()
+
+
+def test_argument_validation(pkg):
+    L = pkg.lib()
+    h = C.c_void_p(None)
+    base = np.zeros((8, 64), dtype=np.float32)
+    assert L.vs_bf_create(base.ctypes.data_as(C.c_void_p), 8, 64, 0, 0, 0, C.byref(h)) == -5  # dim != 128
+    assert L.vs_bf_create(None, 8, 128, 0, 0, 0, C.byref(h)) == -1
+    assert L.vs_set_batch(None, 4) == -1
+    assert pkg.clamp_nlist(10000, 1024) == 100  # create_ivf_model_reordered.py:92-94
+    assert pkg.clamp_nlist(1000000, 1024) == 1024
+    v = np.arange(12, dtype=np.float32).reshape(6, 2)
+    vr, off, r2o = pkg.ivf_layout_from_assignment(v, np.array([2, 0, 1, 0, 2, 2]), 3)
+    assert off.tolist() == [0, 2, 3, 6] and r2o.tolist() == [1, 3, 2, 0, 4, 5]
+    assert np.array_equal(vr, v[r2o])
