@@ -63,6 +63,28 @@ def build(verbose: bool = False, targets=("lib",)) -> str:
 _lib = None
 
 
+def _preload_torch_hip_runtime():
+    """PyTorch wheels bundle their own libamdhip64/libhsa-runtime64.  Two HIP runtimes in one
+    process cannot both own the GPU (the second one reports "No HIP GPUs"), so when torch is
+    installed its runtime is loaded first and libvsearch_hip.so binds to it through the shared
+    SONAME (libamdhip64.so.7).  Stand-alone users (the C++ CLIs) use /opt/rocm's runtime.
+    Set VSEARCH_SYSTEM_HIP=1 to skip this."""
+    if os.environ.get("VSEARCH_SYSTEM_HIP") == "1":
+        return None
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return None
+    p = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(p):
+        C.CDLL(p, mode=C.RTLD_GLOBAL)
+        return p
+    return None
+
+
 def lib():
     """Load libvsearch_hip.so (never falls back to anything else)."""
     global _lib
@@ -70,6 +92,7 @@ def lib():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise VSearchError(-3, f"{LIB_PATH} not built; run __graft_entry__.build() / make -C {CSRC}")
+    _preload_torch_hip_runtime()
     L = C.CDLL(LIB_PATH)
     vp, i32, i64, f32p = C.c_void_p, C.c_int, C.c_int64, C.c_void_p
     sig = {

@@ -33,6 +33,13 @@ def build(force: bool = False) -> str:
 def lib():
     global _lib
     if _lib is None:
+        # a GPU box may expose far more cores than its CPU share: do not oversubscribe OpenMP
+        if "OMP_NUM_THREADS" not in os.environ:
+            try:
+                n = len(os.sched_getaffinity(0))
+            except AttributeError:
+                n = os.cpu_count() or 1
+            os.environ["OMP_NUM_THREADS"] = str(max(1, min(n, 16)))
         build()
         L = C.CDLL(_LIB_PATH)
         L.vo_read_fvecs.restype = C.c_int

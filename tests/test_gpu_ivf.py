@@ -12,11 +12,21 @@ import oracle
 pytestmark = pytest.mark.gpu
 
 
+_INDEX_CACHE = {}
+
+
 def _make_index(pkg, n=20000, nlist=64, seed=3, jitter=0.0):
+    key = (n, nlist, seed, jitter)
+    if key not in _INDEX_CACHE:
+        _INDEX_CACHE[key] = _build_index(pkg, n, nlist, seed, jitter)
+    return _INDEX_CACHE[key]
+
+
+def _build_index(pkg, n, nlist, seed, jitter):
     base = pkg.synth_sift(n, seed=seed)
     rng = np.random.default_rng(seed)
     cents = base[rng.choice(n, nlist, replace=False)].copy()
-    for _ in range(4):  # a few Lloyd steps on the host (index building is not the path under test)
+    for _ in range(2):  # a few Lloyd steps on the host (index building is not the path under test)
         d = (base ** 2).sum(1)[:, None] - 2 * base @ cents.T + (cents ** 2).sum(1)[None]
         a = d.argmin(1)
         for c in range(nlist):
@@ -41,8 +51,9 @@ def test_full_probe_equals_exact(gpu_pkg):
     assert np.array_equal(d, od) and np.array_equal(d2, od)
     ex = oracle.exact_int_dists(q, base)
     assert np.array_equal(np.take_along_axis(ex, ids.astype(np.int64), 1).astype(np.float32), od)
-    # where the oracle has no distance ties the ids are identical too
-    notie = (od[:, 1:] != od[:, :-1]).all(1)
+    # where the oracle has no distance ties (inside the top-k or at its boundary) the ids are identical too
+    top6 = np.sort(ex, axis=1)[:, :6]
+    notie = (top6[:, 1:] != top6[:, :-1]).all(1)
     assert notie.mean() > 0.9 and np.array_equal(ids[notie], oi[notie])
 
 
