@@ -111,6 +111,7 @@ def lib():
         "vs_set_batch": (i32, [vp, i32]),
         "vs_bf_search": (i32, [vp, vp, i64, i32, vp, vp, C.POINTER(Timing)]),
         "vs_bf_search_dev": (i32, [vp, vp, i32, i32, vp, vp, vp, vp]),
+        "vs_bf_search_dev_multi": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp]),
         "vs_bf_scores_dev": (i32, [vp, vp, i32, vp, i64, vp]),
         "vs_ivf_load": (i32, [C.c_char_p, i32, i32, i32, C.POINTER(vp)]),
         "vs_ivf_create": (i32, [vp, i64, i32, vp, i32, vp, vp, i32, i32, i32, C.POINTER(vp)]),
@@ -279,6 +280,11 @@ class BruteForceIndex(_Index):
     def search_dev(self, q_ptr: int, B: int, k: int, ids_ptr: int, dists_ptr: int, flags_ptr: int, stream: int):
         """Asynchronous device-pointer call (vs_bf_search_dev): outputs are [B, k+1]."""
         _check(lib().vs_bf_search_dev(self._h, q_ptr, B, k, ids_ptr, dists_ptr, flags_ptr, stream))
+
+    def search_dev_multi(self, q_ptr: int, n_batches: int, B: int, k: int, ids_ptr: int, dists_ptr: int,
+                         flags_ptr: int, stream: int):
+        """n_batches consecutive batches of B queries, pipelined over internal streams (vs_bf_search_dev_multi)."""
+        _check(lib().vs_bf_search_dev_multi(self._h, q_ptr, n_batches, B, k, ids_ptr, dists_ptr, flags_ptr, stream))
 
     def scores_dev(self, q_ptr: int, B: int, scores_ptr: int, ld: int, stream: int):
         """QnnRunner::executeBatchRaw analogue: raw [B, ld] score matrix on the device."""

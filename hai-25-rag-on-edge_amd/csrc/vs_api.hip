@@ -35,6 +35,7 @@ namespace {
 constexpr int kMaxEvents = 8192;
 constexpr int kKcapMax = 16;       // largest per-lane list the scan kernels are compiled for
 constexpr int kMaxNprobe = 256;
+constexpr int kMaxLanes = 4;
 
 struct ProfSlot {
     std::vector<hipEvent_t> ev;  // pairs
@@ -74,13 +75,20 @@ struct vs_index {
 
     // scratch
     float* d_q = nullptr;        // staging for host queries [32][128]
-    float* d_qpad = nullptr;     // [32][128]
-    float* d_qnorm = nullptr;    // [32]
-    float* d_tau = nullptr;      // [32]
-    float* d_part_d = nullptr;   // [max_grid][32][16]
-    int32_t* d_part_i = nullptr;
-    float* d_seed_d = nullptr;   // [seed_grid][32][16]
-    int32_t* d_seed_i = nullptr;
+    // Pipeline lanes: consecutive batches of a multi-batch call run on different internal streams
+    // so that the start-up / tail of one scan overlaps the streaming phase of its neighbours
+    // (inside one launch all workgroups go through those phases in lock-step and HBM idles).
+    struct Lane {
+        hipStream_t s = nullptr;
+        hipEvent_t done = nullptr;
+        float* slots = nullptr;     // [2][32][kSlotStride] threshold-exchange slots (two parities), +inf when idle
+        int parity = 0;
+        float* part_d = nullptr;    // [max_grid][32][16]
+        int32_t* part_i = nullptr;
+    };
+    Lane lane[kMaxLanes];
+    int n_lanes = 1;
+    hipEvent_t fork = nullptr;
     float* d_out_d = nullptr;    // [32][64]
     int32_t* d_out_i = nullptr;
     int32_t* d_flags = nullptr;  // [32]
@@ -90,8 +98,7 @@ struct vs_index {
     float* d_ipart_d = nullptr;  // [32][kMaxNprobe][16]
     int32_t* d_ipart_i = nullptr;
     unsigned long long* d_cand = nullptr;
-    int max_grid = 0, seed_grid = 0;
-    int64_t seed_rows = 0;
+    int max_grid = 0;
 
     hipStream_t stream = nullptr;
     bool prof = false;
@@ -114,8 +121,16 @@ int dev_alloc(T** p, size_t n) {
 void free_all(vs_index* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    void* ptrs[] = {h->d_vecs, h->d_norm, h->d_centroids, h->d_cnorm, h->d_offsets, h->d_r2o, h->d_q, h->d_qpad,
-                    h->d_qnorm, h->d_tau, h->d_part_d, h->d_part_i, h->d_seed_d, h->d_seed_i, h->d_out_d, h->d_out_i,
+    for (auto& L : h->lane) {
+        if (L.slots) (void)hipFree(L.slots);
+        if (L.part_d) (void)hipFree(L.part_d);
+        if (L.part_i) (void)hipFree(L.part_i);
+        if (L.done) (void)hipEventDestroy(L.done);
+        if (L.s) (void)hipStreamDestroy(L.s);
+    }
+    if (h->fork) (void)hipEventDestroy(h->fork);
+    void* ptrs[] = {h->d_vecs, h->d_norm, h->d_centroids, h->d_cnorm, h->d_offsets, h->d_r2o, h->d_q,
+                    h->d_out_d, h->d_out_i,
                     h->d_flags, h->d_scores, h->d_probes, h->d_ipart_d, h->d_ipart_i, h->d_cand};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -143,7 +158,7 @@ int check_device(int device) {
 void scan_geometry(int64_t rows, int num_cus, int& grid, int& tiles_per_wg) {
     const int64_t tiles = (rows + vs::kTileRows - 1) / vs::kTileRows;
     int64_t g = std::min<int64_t>(num_cus, (tiles + vs::kScanWaves - 1) / vs::kScanWaves);
-    g = std::max<int64_t>(g, 1);
+    g = std::max<int64_t>(std::min<int64_t>(g, vs::kSlotStride), 1);
     tiles_per_wg = (int)((tiles + g - 1) / g);
     grid = (int)((tiles + tiles_per_wg - 1) / tiles_per_wg);
     grid = std::max(grid, 1);
@@ -157,26 +172,24 @@ int alloc_scratch(vs_index* h) {
     int tp;
     scan_geometry(std::max<int64_t>(h->n_rows, 1), h->num_cus, h->max_grid, tp);
     h->max_grid = std::max(h->max_grid, h->num_cus);
-    // seed sample: first rows of the base; only worth a launch on large bases
-    h->seed_rows = 0;
-    if (h->kind == 0 && h->n_rows >= 262144) {
-        h->seed_rows = std::min<int64_t>(32768, (h->n_rows / 32) & ~int64_t(127));
-    }
-    h->seed_grid = 0;
-    if (h->seed_rows > 0) {
-        int stp;
-        scan_geometry(h->seed_rows, h->num_cus, h->seed_grid, stp);
-    }
     if ((rc = dev_alloc(&h->d_q, 32 * vs::kDim))) return rc;
-    if ((rc = dev_alloc(&h->d_qpad, 32 * vs::kDim))) return rc;
-    if ((rc = dev_alloc(&h->d_qnorm, 32))) return rc;
-    if ((rc = dev_alloc(&h->d_tau, 32))) return rc;
-    const size_t part = (size_t)h->max_grid * 32 * kKcapMax;
-    if ((rc = dev_alloc(&h->d_part_d, part))) return rc;
-    if ((rc = dev_alloc(&h->d_part_i, part))) return rc;
-    const size_t spart = (size_t)std::max(h->seed_grid, 1) * 32 * kKcapMax;
-    if ((rc = dev_alloc(&h->d_seed_d, spart))) return rc;
-    if ((rc = dev_alloc(&h->d_seed_i, spart))) return rc;
+    {
+        const char* e = getenv("VSEARCH_LANES");
+        h->n_lanes = e ? std::max(1, std::min(kMaxLanes, atoi(e))) : 3;
+        const size_t nslot = (size_t)2 * 32 * vs::kSlotStride;
+        std::vector<float> inf(nslot, std::numeric_limits<float>::infinity());
+        const size_t part = (size_t)h->max_grid * 32 * kKcapMax;
+        for (int i = 0; i < h->n_lanes; ++i) {
+            vs_index::Lane& L = h->lane[i];
+            if ((rc = dev_alloc(&L.slots, nslot))) return rc;
+            HIPCHK(hipMemcpy(L.slots, inf.data(), nslot * sizeof(float), hipMemcpyHostToDevice));
+            if ((rc = dev_alloc(&L.part_d, part))) return rc;
+            if ((rc = dev_alloc(&L.part_i, part))) return rc;
+            HIPCHK(hipStreamCreateWithFlags(&L.s, hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&L.done, hipEventDisableTiming));
+        }
+        HIPCHK(hipEventCreateWithFlags(&h->fork, hipEventDisableTiming));
+    }
     if ((rc = dev_alloc(&h->d_out_d, 32 * 64))) return rc;
     if ((rc = dev_alloc(&h->d_out_i, 32 * 64))) return rc;
     if ((rc = dev_alloc(&h->d_flags, 32))) return rc;
@@ -196,8 +209,8 @@ int alloc_scratch(vs_index* h) {
 int upload_vectors(vs_index* h, const float* host, int64_t rows) {
     int rc;
     if ((rc = dev_alloc(&h->d_vecs, (size_t)std::max<int64_t>(rows, 1) * vs::kDim))) return rc;
-    if ((rc = dev_alloc(&h->d_norm, (size_t)rows + 16))) return rc;
-    HIPCHK(hipMemset(h->d_norm, 0, ((size_t)rows + 16) * sizeof(float)));
+    if ((rc = dev_alloc(&h->d_norm, (size_t)rows + 64))) return rc;
+    HIPCHK(hipMemset(h->d_norm, 0, ((size_t)rows + 64) * sizeof(float)));
     if (rows > 0) {
         HIPCHK(hipMemcpy(h->d_vecs, host, (size_t)rows * vs::kDim * sizeof(float), hipMemcpyHostToDevice));
         HIPCHK(vs::launch_row_sqnorm(h->d_vecs, rows, vs::kDim, h->d_norm, nullptr));
@@ -225,65 +238,58 @@ void prof_end(vs_index* h, int which, hipStream_t s) {
     ps.used += 2;
 }
 
+// tuning knob (VSEARCH_XCHG_IT): loop iteration of the first threshold-exchange attempt
+int g_xchg_first_it = [] {
+    const char* e = getenv("VSEARCH_XCHG_IT");
+    return e ? atoi(e) : 1;
+}();
+
+int* g_dbg = nullptr;
+
+
 int pick_kcap(int need) { return need <= 8 ? 8 : (need <= 16 ? 16 : 0); }
 
-// One batch of the brute-force pipeline on stream s: prep -> [seed scan -> seed merge] -> scan -> merge.
-int bf_batch_dev(vs_index* h, const float* q_dev, int B, int k1, float* out_d, int32_t* out_i, int32_t* flags,
-                 hipStream_t s) {
+// One batch of the brute-force pipeline on stream s: scan (prep + threshold exchange + top-k fused) -> merge.
+// Consecutive calls on one index must be stream-ordered: they alternate between the two slot parities.
+int bf_batch_dev(vs_index* h, vs_index::Lane& L, const float* q_dev, int B, int k1, float* out_d, int32_t* out_i,
+                 int32_t* flags, hipStream_t s) {
     const int kcap = pick_kcap(k1);
     if (!kcap) {
         set_error("k too large for the compiled scan kernels (k <= 15)");
         return VS_ERR_UNSUPPORTED;
     }
     const int nqh = B <= 16 ? 1 : 2;
-    HIPCHK(vs::launch_prep_queries(q_dev, B, h->d_qpad, h->d_qnorm, s));
-
     vs::ScanParams p{};
     p.base = h->d_vecs;
     p.bnorm = h->d_norm;
-    p.q = h->d_qpad;
-    p.qnorm = h->d_qnorm;
+    p.q = q_dev;
     p.metric = h->metric;
     p.id_offset = (int32_t)h->id_offset;
     p.nq_valid = B;
-
-    const bool seeded = h->seed_rows > 0 && h->seed_rows >= 4 * (int64_t)k1;
-    if (seeded) {
-        int grid, tp;
-        scan_geometry(h->seed_rows, h->num_cus, grid, tp);
-        p.tau0 = nullptr;
-        p.row_begin = 0;
-        p.row_end = h->seed_rows;
-        p.tiles_per_wg = tp;
-        p.part_d = h->d_seed_d;
-        p.part_i = h->d_seed_i;
-        HIPCHK(vs::launch_scan(p, grid, kcap, nqh, vs::kModeTopK, s));
-        vs::MergeParams m{};
-        m.part_d = h->d_seed_d;
-        m.part_i = h->d_seed_i;
-        m.G = grid;
-        m.nq_stride = 32;
-        m.kin = kcap;
-        m.nq = nqh * 16;
-        m.kout = k1;
-        m.tau_out = h->d_tau;
-        HIPCHK(vs::launch_merge(m, s));
-    }
+    p.k1 = k1;
+    p.xchg_first_it = g_xchg_first_it;
+    p.dbg = g_dbg;
     int grid, tp;
     scan_geometry(h->n_rows, h->num_cus, grid, tp);
-    p.tau0 = seeded ? h->d_tau : nullptr;
+    // the exchange pays once every wave has a few tiles left after its first two
+    const bool exchange = grid >= 16 && grid <= vs::kSlotStride && tp >= 6 * vs::kScanWaves;
+    if (exchange) {
+        p.slots_cur = L.slots + (size_t)L.parity * 32 * vs::kSlotStride;
+        p.slots_next = L.slots + (size_t)(1 - L.parity) * 32 * vs::kSlotStride;
+        L.parity ^= 1;
+    }
     p.row_begin = 0;
     p.row_end = h->n_rows;
     p.tiles_per_wg = tp;
-    p.part_d = h->d_part_d;
-    p.part_i = h->d_part_i;
+    p.part_d = L.part_d;
+    p.part_i = L.part_i;
     prof_begin(h, 0, s);
     HIPCHK(vs::launch_scan(p, grid, kcap, nqh, vs::kModeTopK, s));
     prof_end(h, 0, s);
 
     vs::MergeParams m{};
-    m.part_d = h->d_part_d;
-    m.part_i = h->d_part_i;
+    m.part_d = L.part_d;
+    m.part_i = L.part_i;
     m.G = grid;
     m.nq_stride = 32;
     m.kin = kcap;
@@ -296,14 +302,31 @@ int bf_batch_dev(vs_index* h, const float* q_dev, int B, int k1, float* out_d, i
     return VS_OK;
 }
 
+// nb batches of B queries: batch i runs on lane i % n_lanes; fork from / join into the caller's stream.
+int bf_multi_dev(vs_index* h, const float* q_dev, int nb, int B, int k1, float* out_d, int32_t* out_i, int32_t* flags,
+                 hipStream_t user) {
+    const int nl = std::min(h->n_lanes, nb);
+    HIPCHK(hipEventRecord(h->fork, user));
+    for (int l = 0; l < nl; ++l) HIPCHK(hipStreamWaitEvent(h->lane[l].s, h->fork, 0));
+    for (int i = 0; i < nb; ++i) {
+        vs_index::Lane& L = h->lane[i % nl];
+        int rc = bf_batch_dev(h, L, q_dev + (size_t)i * B * vs::kDim, B, k1, out_d + (size_t)i * B * k1,
+                              out_i + (size_t)i * B * k1, flags ? flags + (size_t)i * B : h->d_flags, L.s);
+        if (rc) return rc;
+    }
+    for (int l = 0; l < nl; ++l) {
+        HIPCHK(hipEventRecord(h->lane[l].done, h->lane[l].s));
+        HIPCHK(hipStreamWaitEvent(user, h->lane[l].done, 0));
+    }
+    return VS_OK;
+}
+
 int scores_dev(vs_index* h, const float* vecs, const float* norms, int64_t rows, const float* q_dev, int B,
                float* scores, int64_t ld, hipStream_t s) {
-    HIPCHK(vs::launch_prep_queries(q_dev, B, h->d_qpad, h->d_qnorm, s));
     vs::ScanParams p{};
     p.base = vecs;
     p.bnorm = norms;
-    p.q = h->d_qpad;
-    p.qnorm = h->d_qnorm;
+    p.q = q_dev;
     p.metric = h->metric;
     p.nq_valid = B;
     p.row_begin = 0;
@@ -336,8 +359,7 @@ int ivf_batch_dev(vs_index* h, const float* q_dev, int B, int k, int nprobe, flo
     ip.vnorm = h->d_norm;
     ip.offsets = h->d_offsets;
     ip.owned = nullptr;
-    ip.q = h->d_qpad;
-    ip.qnorm = h->d_qnorm;
+    ip.q = q_dev;
     ip.probes = h->d_probes;
     ip.B = B;
     ip.nprobe = nprobe;
@@ -459,8 +481,23 @@ int vs_bf_search_dev(vs_index* h, const float* queries_dev, int B, int k, int32_
     }
     int rc = set_device(h);
     if (rc) return rc;
-    return bf_batch_dev(h, queries_dev, B, k + 1, dists_dev, ids_dev, flags_dev ? flags_dev : h->d_flags,
+    return bf_batch_dev(h, h->lane[0], queries_dev, B, k + 1, dists_dev, ids_dev, flags_dev ? flags_dev : h->d_flags,
                         static_cast<hipStream_t>(stream));
+}
+
+int vs_bf_search_dev_multi(vs_index* h, const float* queries_dev, int n_batches, int B, int k, int32_t* ids_dev,
+                           float* dists_dev, int32_t* flags_dev, void* stream) {
+    if (!h || h->kind != 0 || !queries_dev || !ids_dev || !dists_dev || n_batches < 1 || B < 1 || B > vs::kMaxBatch || k < 1) {
+        set_error("vs_bf_search_dev_multi: bad arguments");
+        return VS_ERR_INVALID;
+    }
+    int rc = set_device(h);
+    if (rc) return rc;
+    if (!pick_kcap(k + 1)) {
+        set_error("k too large for the compiled scan kernels (k <= 15)");
+        return VS_ERR_UNSUPPORTED;
+    }
+    return bf_multi_dev(h, queries_dev, n_batches, B, k + 1, dists_dev, ids_dev, flags_dev, static_cast<hipStream_t>(stream));
 }
 
 int vs_bf_scores_dev(vs_index* h, const float* queries_dev, int B, float* scores_dev_, int64_t ld, void* stream) {
@@ -498,7 +535,7 @@ int vs_bf_search(vs_index* h, const float* queries_host, int64_t nq, int k, int3
         HIPCHK(hipMemcpyAsync(h->d_q, queries_host + q0 * vs::kDim, (size_t)B * vs::kDim * sizeof(float),
                               hipMemcpyHostToDevice, h->stream));
         double t1 = now_ms();
-        rc = bf_batch_dev(h, h->d_q, B, k1, h->d_out_d, h->d_out_i, h->d_flags, h->stream);
+        rc = bf_batch_dev(h, h->lane[0], h->d_q, B, k1, h->d_out_d, h->d_out_i, h->d_flags, h->stream);
         if (rc) return rc;
         HIPCHK(hipMemcpyAsync(hd.data(), h->d_out_d, (size_t)B * k1 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipMemcpyAsync(hi.data(), h->d_out_i, (size_t)B * k1 * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
@@ -626,11 +663,11 @@ static int ivf_create_impl(const float* vectors, int64_t n_rows, int dim, const 
     };
     if ((rc = upload_vectors(h, up, n_local))) return fail(rc);
     if ((rc = dev_alloc(&h->d_centroids, (size_t)nlist * dim))) return fail(rc);
-    if ((rc = dev_alloc(&h->d_cnorm, (size_t)nlist + 16))) return fail(rc);
+    if ((rc = dev_alloc(&h->d_cnorm, (size_t)nlist + 64))) return fail(rc);
     if ((rc = dev_alloc(&h->d_offsets, (size_t)nlist + 1))) return fail(rc);
     if ((rc = dev_alloc(&h->d_r2o, (size_t)std::max<int64_t>(n_local, 1)))) return fail(rc);
     hipError_t e;
-    if ((e = hipMemset(h->d_cnorm, 0, ((size_t)nlist + 16) * sizeof(float))) != hipSuccess ||
+    if ((e = hipMemset(h->d_cnorm, 0, ((size_t)nlist + 64) * sizeof(float))) != hipSuccess ||
         (e = hipMemcpy(h->d_centroids, centroids, (size_t)nlist * dim * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess ||
         (e = hipMemcpy(h->d_offsets, loc_off.data(), ((size_t)nlist + 1) * sizeof(int32_t), hipMemcpyHostToDevice)) != hipSuccess ||
         (e = hipMemcpy(h->d_r2o, loc_r2o.data(), (size_t)std::max<int64_t>(n_local, 1) * sizeof(int32_t), hipMemcpyHostToDevice)) != hipSuccess ||
@@ -810,6 +847,11 @@ int vs_ivf_search(vs_index* h, const float* queries_host, int64_t nq, int k, int
     if (total_candidates) *total_candidates = (int64_t)cand;
     tm.total_ms = now_ms() - t_start;
     if (timing) *timing = tm;
+    return VS_OK;
+}
+
+__attribute__((visibility("default"))) int vs_debug_buffer(int* dev_ptr) {
+    g_dbg = dev_ptr;
     return VS_OK;
 }
 

@@ -10,15 +10,19 @@ constexpr int kTileRows = 16;      // base rows per MFMA tile (v_mfma_f32_16x16x
 constexpr int kScanThreads = 512;  // 8 waves: 2 per SIMD
 constexpr int kScanWaves = 8;
 constexpr int kMaxBatch = 32;      // queries per scan pass (two 16-query MFMA column blocks)
+constexpr int kSlotStride = 256;   // threshold-exchange slots: [32 queries][256 workgroups]
 
 enum ScanMode { kModeTopK = 0, kModeStore = 1 };
 
 struct ScanParams {
     const float* base;       // [n_rows][128] row-major (the flat fvecs payload, cpu_baseline.cpp:48-49)
     const float* bnorm;      // [n_rows (+16 pad)] squared norms (cpu_baseline.cpp:116-125)
-    const float* q;          // [32][128] zero-padded queries
-    const float* qnorm;      // [32]
-    const float* tau0;       // [32] initial thresholds or nullptr (= +inf)
+    const float* q;          // [nq_valid][128] raw queries; rows up to 32 are zero-padded in-kernel (main.cpp:206-211)
+    float* slots_cur;        // [32][kSlotStride] per-workgroup minima of this launch (pre-set to +inf) or nullptr = no exchange
+    float* slots_next;       // [32][kSlotStride] reset to +inf for the next launch, or nullptr
+    int k1;                  // the exchange bounds the k1-th best distance
+    int* dbg;                // optional debug counters [grid][16]
+    int xchg_first_it;       // first loop iteration (2 tiles per wave each) at which the exchange is attempted
     int64_t row_begin;       // multiple of 16
     int64_t row_end;         // exclusive
     int tiles_per_wg;
@@ -58,9 +62,6 @@ hipError_t launch_merge_layout(const MergeParams& p, int64_t stride_g, int64_t s
 // ||v||^2 per row in the reference's AVX2 summation order (cpu_baseline.cpp:95-114).
 hipError_t launch_row_sqnorm(const float* v, int64_t rows, int dim, float* out, hipStream_t s);
 
-// Pad B queries to 32 x 128 (zeros, main.cpp:206-211) and compute their norms.
-hipError_t launch_prep_queries(const float* q, int B, float* qpad, float* qnorm, hipStream_t s);
-
 // ---- IVF ----
 // Per query: the nprobe nearest centroids (ascending (dist, id)) out of a [B][ld] score matrix.
 hipError_t launch_pick_probes(const float* scores, int64_t ld, int B, int nlist, int nprobe,
@@ -71,8 +72,7 @@ struct IvfScanParams {
     const float* vnorm;       // [n_rows]
     const int32_t* offsets;   // [nlist+1] (cluster_offsets.npy)
     const uint8_t* owned;     // [nlist] 1 = this shard scans the list, or nullptr = all
-    const float* q;           // [32][128]
-    const float* qnorm;       // [32]
+    const float* q;           // [B][128] raw queries (norms are computed in-kernel)
     const int32_t* probes;    // [B][nprobe]
     int B, nprobe, kcap;
     int metric;

@@ -48,45 +48,221 @@ __device__ __forceinline__ void list_insert(float (&ld)[KCAP], int (&li)[KCAP], 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Brute-force scan, register-direct variant.
-//
-// Workgroup = 8 waves (2 per SIMD).  Each wave owns whole 16-row base tiles: lane (r = l & 15,
-// g = l >> 4) loads base[row0 + r][16 t + 4 g .. +3] for t = 0..7 straight into VGPRs (eight
-// global_load_dwordx4, 64 contiguous bytes per row per instruction) and feeds element i of chunk t
-// to MFMA step (t, i) as the A operand; the query fragments use the same k permutation as the B
-// operand, so D[row][query] accumulates the full 128-long dot product.  In the 16x16 result a lane
-// holds one query column (l & 15) and four base rows (4 g + reg): the top-k state of a query is
-// therefore lane-private and needs no cross-lane traffic until the workgroup is done.
-//
-// Two tiles are kept in flight per wave (one being multiplied, one landing), i.e. 8 waves x 8 KB
-// per CU, which is what it takes to cover HBM latency at ~10 B/clk/CU.
+// DPP helpers: wave-wide reductions without LDS round trips (ds_bpermute chains cost ~10x more
+// latency than these when a single wave runs them back to back).
 // ------------------------------------------------------------------------------------------------
-template <int NQH>
-struct TileRegs {
-    f32x4 a[8];
-    f32x4 bn;
-};
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov_f(float x) {
+    const int xi = __builtin_bit_cast(int, x);
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(xi, xi, CTRL, 0xF, 0xF, false));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_mov_i(int x) {
+    return __builtin_amdgcn_update_dpp(x, x, CTRL, 0xF, 0xF, false);
+}
+__device__ __forceinline__ float rdlane_f(float x, int l) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l));
+}
+// min over the 64 lanes, result uniform
+__device__ __forceinline__ float wave_min_f32(float x) {
+    x = fminf(x, dpp_mov_f<0xB1>(x));   // quad_perm [1,0,3,2]
+    x = fminf(x, dpp_mov_f<0x4E>(x));   // quad_perm [2,3,0,1]
+    x = fminf(x, dpp_mov_f<0x141>(x));  // row_half_mirror
+    x = fminf(x, dpp_mov_f<0x140>(x));  // row_mirror
+    return fminf(fminf(rdlane_f(x, 0), rdlane_f(x, 16)), fminf(rdlane_f(x, 32), rdlane_f(x, 48)));
+}
+__device__ __forceinline__ int wave_min_i32(int x) {
+    x = min(x, dpp_mov_i<0xB1>(x));
+    x = min(x, dpp_mov_i<0x4E>(x));
+    x = min(x, dpp_mov_i<0x141>(x));
+    x = min(x, dpp_mov_i<0x140>(x));
+    return min(min(__builtin_amdgcn_readlane(x, 0), __builtin_amdgcn_readlane(x, 16)),
+               min(__builtin_amdgcn_readlane(x, 32), __builtin_amdgcn_readlane(x, 48)));
+}
+// lexicographic (dist, id) argmin over the wave; ids are unique or negative
+__device__ __forceinline__ void wave_lexmin(float d, int id, float& bd, int& bi) {
+    bd = wave_min_f32(d);
+    bi = wave_min_i32(d == bd ? id : 0x7fffffff);
+}
+
+// k-th smallest (1-based) of the 256 values held 4 per lane across the wave; +inf if fewer are finite
+__device__ __forceinline__ float wave_kth_smallest(float a0, float a1, float a2, float a3, int k, int lane) {
+    float res = VS_INF;
+    for (int round = 0; round < k; ++round) {
+        const float m = fminf(fminf(a0, a1), fminf(a2, a3));
+        const float wm = wave_min_f32(m);
+        res = wm;
+        if (!(wm < VS_INF)) break;
+        const unsigned long long mask = __ballot(m == wm);
+        if (lane == __builtin_ctzll(mask)) {  // drop exactly one instance
+            if (a0 == wm) a0 = VS_INF;
+            else if (a1 == wm) a1 = VS_INF;
+            else if (a2 == wm) a2 = VS_INF;
+            else a3 = VS_INF;
+        }
+    }
+    return res;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Brute-force scan: Q[<=32 x 128] x base^T on v_mfma_f32_16x16x4_f32, L2 epilogue and top-k fused.
+//
+// Workgroup = 8 waves (2 per SIMD).  A wave owns whole 16-row base tiles.  In the MFMA the base
+// tile is the A operand (lane (r = l & 15, g = l >> 4) supplies base[row0 + r][16 t + 4 g + i] to
+// step (t, i)) and the queries are the B operand with the same k permutation, so in the 16x16
+// result a lane holds ONE query column (l & 15) and four base rows (4 g + reg): the top-k state of
+// a query is lane-private and needs no cross-lane traffic until the workgroup is done.
+//
+// Data path.  Every wave owns a private ring of DEPTH tile slots in LDS and fills them with
+// LDS-DMA (global_load_lds_dwordx4: one wave-instruction moves two whole 512-byte rows, fully
+// coalesced, no VGPR destination).  The only VMEM operations in the loop are those DMA pieces and
+// they are counted by hand (s_waitcnt vmcnt(9*(DEPTH-1))): nothing drains the queue, and no
+// barrier is needed because a wave reads only what it loaded itself.  LDS image of a slot:
+// 16 rows x 512 B with 16-byte chunk c of row r stored at chunk c ^ r (XOR applied to the DMA
+// *source* address, the LDS side stays lane-linear), which makes the ds_read_b128 of the A
+// fragments bank-conflict free; followed by the tile's squared norms.
+//
+// Everything a batch needs is inside this one launch:
+//   * query zero-padding (main.cpp:206-211) and squared norms in the reference's summation order
+//     (cpu_baseline.cpp:95-114, :211) -- queries are staged once through LDS;
+//   * the threshold exchange: after its first tile round every workgroup publishes, per query,
+//     the smallest distance it has seen (write-through stores into slots[query][workgroup]); soon
+//     after it reads the published minima (one coalesced 1 KB row per query) and takes the k1-th
+//     smallest as an upper bound tau0 of the final k1-th best distance: k1 distinct rows are known
+//     to be at least that close.  From then on a distance is looked at only if it is below
+//     min(tau0, own lane's KCAP-th best), so the insertion path goes cold.  Nothing waits for
+//     anybody: an unpublished slot reads +inf and merely loosens the bound, so the result never
+//     depends on timing, placement or residency;
+//   * the workgroup merge: surviving candidates (d < tau0) are compacted into LDS and ranked with
+//     DPP reductions; the per-workgroup sorted lists go to the cross-workgroup merge kernel.
+// ------------------------------------------------------------------------------------------------
+constexpr int kSlotBytes = kTileRows * kDim * 4 + 256;  // 16 rows + 64 norms
+constexpr int kDepth = 2;
+constexpr int kRingBytes = kScanWaves * kDepth * kSlotBytes;  // 135168
+constexpr int kQStageBytes = 32 * kDim * 4;                  // 16384
+constexpr int kScratchBytes = 2048;
+constexpr int kScanLds = kRingBytes + kQStageBytes + kScratchBytes;  // 153600 <= 160 KiB
+
+#ifdef VS_STAMPS
+#define VS_STAMP(i)                                                                                    \
+    do {                                                                                               \
+        if (p.dbg && threadIdx.x == 0)                                                                 \
+            p.dbg[blockIdx.x * 16 + (i)] = (int)(__builtin_amdgcn_s_memrealtime() & 0x7fffffff);       \
+    } while (0)
+#else
+#define VS_STAMP(i)
+#endif
 
 template <int NQH, int KCAP, int MODE>
 __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* q_s = reinterpret_cast<float*>(smem + kRingBytes);           // [32][128], chunk-swizzled
+    float* lds_qn = reinterpret_cast<float*>(smem + kRingBytes + kQStageBytes);  // [32]
+    float* lds_tau = lds_qn + 32;                                       // [32]
+    float* lds_wmin = lds_tau + 32;                                     // [8][32]
+    int* lds_flag = reinterpret_cast<int*>(lds_wmin + kScanWaves * 32); // [1]
+    int* lds_cnt = lds_flag + 4;                                        // [32]
+    int* lds_ticket = lds_cnt + 32;                                     // [1]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably wave-uniform
     const int r = lane & 15;
     const int g = lane >> 4;
+    VS_STAMP(0);
 
-    // query fragments (B operand): qf[h][t][i] = Q[16 h + r][16 t + 4 g + i]
+    const int64_t n_rows = p.row_end - p.row_begin;
+    const int tiles_total = (int)((n_rows + kTileRows - 1) / kTileRows);
+    const int tile0 = blockIdx.x * p.tiles_per_wg;
+    const int tile1 = min(tile0 + p.tiles_per_wg, tiles_total);
+    const int64_t last_row = p.row_end - 1;
+    const int tlast = max(tile1 - 1, 0);
+
+    char* ring = smem + wave * (kDepth * kSlotBytes);
+    // DMA source mapping: piece j (0..7) writes LDS chunks [64 j, 64 j + 64) of the slot; lane l
+    // lands at row 2 j + (l >> 5), stored chunk (l & 31)  <-  source chunk (l & 31) ^ row
+    const int dma_rhalf = lane >> 5;
+    const int dma_c = lane & 31;
+    auto issue_tile = [&](int tile, int slot) {
+        const int64_t row0 = p.row_begin + (int64_t)tile * kTileRows;
+        char* dst = ring + slot * kSlotBytes;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int row_in = 2 * j + dma_rhalf;
+            const int64_t row = min(row0 + row_in, last_row);  // tail rows re-read the last row, masked below
+            const float* src = p.base + row * kDim + 4 * (dma_c ^ row_in);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, 0, 0);
+        }
+        // norms of rows row0 .. row0+63 (the first 16 are this tile's); bnorm is padded by 64
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.bnorm + row0 + lane),
+                                         (__attribute__((address_space(3))) void*)(dst + kTileRows * kDim * 4), 4, 0, 0);
+    };
+
+    // Tiles of the workgroup's chunk are handed out through an LDS ticket counter, so a wave that
+    // is served late by HBM simply takes fewer tiles: the eight private streams stay balanced.
+    // Tickets 0..15 are pre-assigned (wave, wave + 8); the counter starts at 16.
+    //
+    // DMA queue bookkeeping (vmcnt counts LDS-DMA, loads and stores together, in issue order):
+    // "s_waitcnt vmcnt(N)" is placed where exactly N younger operations follow the data needed.
+    auto lds_barrier = [&]() {  // workgroup barrier that leaves the DMA queue alone
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    // queries -> LDS by DMA as well (2 pieces per wave): chunk c of row q lands at chunk c ^ (q & 15);
+    // rows >= nq_valid read row 0 and are zeroed when used (main.cpp:206-211 zero padding)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int j = 2 * wave + u;
+        const int row = 2 * j + (lane >> 5);
+        const int c4 = lane & 31;
+        const float* src = p.q + (row < p.nq_valid ? row : 0) * kDim + 4 * (c4 ^ (row & 15));
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(q_s) + j * 1024),
+                                         16, 0, 0);
+    }
+    int t_a = tile0 + wave, t_b = tile0 + wave + kScanWaves;
+    issue_tile(min(t_a, tlast), 0);
+    issue_tile(min(t_b, tlast), 1);
+    if (threadIdx.x == 0) lds_ticket[0] = 2 * kScanWaves;
+    if (threadIdx.x < 32) lds_cnt[threadIdx.x] = 0;
+    if (MODE == kModeTopK && p.slots_next && threadIdx.x >= 64 && threadIdx.x < 96)  // wave 1: keeps wave 0's queue short
+        p.slots_next[(threadIdx.x - 64) * kSlotStride + blockIdx.x] = VS_INF;  // reset the other parity for the next launch
+    asm volatile("s_waitcnt vmcnt(18)" ::: "memory");  // the two query pieces have landed (2 tiles + maybe a store follow)
+    lds_barrier();
+    // squared norms in the reference's AVX2 order (8 FMA lanes, then r0+...+r7): threads 0..255
+    if (threadIdx.x < 256) {
+        const int row = threadIdx.x >> 3, j = threadIdx.x & 7;
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            float x = q_s[row * kDim + 4 * ((2 * i + (j >> 2)) ^ (row & 15)) + (j & 3)];
+            x = row < p.nq_valid ? x : 0.f;
+            acc = fmaf(x, x, acc);
+        }
+        const int b8 = lane & ~7;
+        float sum = __shfl(acc, b8);
+#pragma unroll
+        for (int u = 1; u < 8; ++u) sum = sum + __shfl(acc, b8 + u);
+        if (j == 0) lds_qn[row] = sum;
+    }
+    // query fragments (B operand): qf[h][c][i] = Q[16 h + r][16 c + 4 g + i]
     f32x4 qf[NQH][8];
-    float qn[NQH];
-    float tau[NQH];
+#pragma unroll
+    for (int h = 0; h < NQH; ++h)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(q_s + (h * 16 + r) * kDim + 4 * ((4 * c + g) ^ r));
+            qf[h][c] = (h * 16 + r) < p.nq_valid ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    lds_barrier();
+    float qn[NQH], tau[NQH], tq[NQH];
 #pragma unroll
     for (int h = 0; h < NQH; ++h) {
-        const float* qrow = p.q + (h * 16 + r) * kDim + 4 * g;
-#pragma unroll
-        for (int t = 0; t < 8; ++t) qf[h][t] = *reinterpret_cast<const f32x4*>(qrow + 16 * t);
-        qn[h] = p.qnorm[h * 16 + r];
-        tau[h] = p.tau0 ? p.tau0[h * 16 + r] : VS_INF;
+        qn[h] = lds_qn[h * 16 + r];
+        tau[h] = VS_INF;
+        tq[h] = VS_INF;
     }
+    VS_STAMP(1);
 
     float ld[NQH][KCAP];
     int li[NQH][KCAP];
@@ -98,22 +274,14 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams 
             li[h][j] = -1;
         }
 
-    const int64_t n_rows = p.row_end - p.row_begin;
-    const int tiles_total = (int)((n_rows + kTileRows - 1) / kTileRows);
-    const int tile0 = blockIdx.x * p.tiles_per_wg;
-    const int tile1 = min(tile0 + p.tiles_per_wg, tiles_total);
-    const int64_t last_row = p.row_end - 1;
-
-    auto load_tile = [&](int t, TileRegs<NQH>& T) {
-        const int64_t row0 = p.row_begin + (int64_t)t * kTileRows;
-        const int64_t row = min(row0 + r, last_row);  // tail rows re-read the last row, masked below
-        const float* src = p.base + row * kDim + 4 * g;
+    // distances of one tile: d[h][j] for query column 16 h + r, base rows 4 g + j
+    auto tile_distances = [&](int tt, int slot, float (&d)[NQH][4]) {
+        const char* src = ring + slot * kSlotBytes;
+        f32x4 a[8];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) T.a[c] = *reinterpret_cast<const f32x4*>(src + 16 * c);
-        T.bn = *reinterpret_cast<const f32x4*>(p.bnorm + row0 + 4 * g);  // bnorm is padded by 16
-    };
-
-    auto compute_tile = [&](int t, const TileRegs<NQH>& T) {
+        for (int c = 0; c < 8; ++c)
+            a[c] = *reinterpret_cast<const f32x4*>(src + r * 512 + (((4 * c + g) ^ r) << 4));
+        const f32x4 bn = *reinterpret_cast<const f32x4*>(src + kTileRows * kDim * 4 + 16 * g);
         f32x4 acc[NQH];
 #pragma unroll
         for (int h = 0; h < NQH; ++h) acc[h] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -123,26 +291,29 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams 
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int h = 0; h < NQH; ++h)
-                    acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(T.a[c][i], qf[h][c][i], acc[h], 0, 0, 0);
-
-        const int64_t rbase = p.row_begin + (int64_t)t * kTileRows + 4 * g;  // this lane's first row
+                    acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][i], qf[h][c][i], acc[h], 0, 0, 0);
+        const int64_t rbase = p.row_begin + (int64_t)tt * kTileRows + 4 * g;  // this lane's first row
 #pragma unroll
-        for (int h = 0; h < NQH; ++h) {
-            float d[4];
+        for (int h = 0; h < NQH; ++h)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 // cpu_baseline.cpp:241  dist = qn + bn - 2*dot  (gcc contracts to fnmadd(2, dot, qn+bn))
-                const float l2 = fmaf(-2.0f, acc[h][j], qn[h] + T.bn[j]);
+                const float l2 = fmaf(-2.0f, acc[h][j], qn[h] + bn[j]);
                 const float v = p.metric ? -acc[h][j] : l2;
-                d[j] = (rbase + j <= last_row) ? v : VS_INF;
+                d[h][j] = (rbase + j <= last_row) ? v : VS_INF;
             }
+    };
+    auto consume = [&](int tt, const float (&d)[NQH][4]) {
+        const int64_t rbase = p.row_begin + (int64_t)tt * kTileRows + 4 * g;
+#pragma unroll
+        for (int h = 0; h < NQH; ++h) {
             if (MODE == kModeTopK) {
-                const float dmin = fminf(fminf(d[0], d[1]), fminf(d[2], d[3]));
+                const float dmin = fminf(fminf(d[h][0], d[h][1]), fminf(d[h][2], d[h][3]));
                 if (dmin < tau[h]) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        if (d[j] < tau[h]) {
-                            list_insert<KCAP>(ld[h], li[h], d[j], (int)(rbase + j) + p.id_offset);
+                        if (d[h][j] < tau[h]) {
+                            list_insert<KCAP>(ld[h], li[h], d[h][j], (int)(rbase + j) + p.id_offset);
                             tau[h] = fminf(tau[h], ld[h][KCAP - 1]);
                         }
                 }
@@ -152,90 +323,203 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams 
                     float* dst = p.store + (int64_t)qidx * p.store_ld + (rbase - p.row_begin);
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        if (rbase + j <= last_row) dst[j] = d[j];
+                        if (rbase + j <= last_row) dst[j] = d[h][j];
                 }
             }
         }
     };
+    auto next_ticket = [&]() -> int {
+        int tk = 0;
+        if (lane == 0) tk = atomicAdd(&lds_ticket[0], 1);
+        return tile0 + __builtin_amdgcn_readfirstlane(tk);
+    };
 
-    // Two register tile buffers, statically named (runtime-indexed vector arrays would spill).
-    // Loads are issued unconditionally (the tile index is clamped, so a wave's last one or two
-    // prefetches re-read a valid tile and are discarded): with a load under a branch hipcc can no
-    // longer count the queue and falls back to s_waitcnt vmcnt(0), which serialises load and MFMA.
-    TileRegs<NQH> TA, TB;
-    const int tlast = max(tile1 - 1, 0);
-    int t = tile0 + wave;
-    load_tile(min(t, tlast), TA);
-    for (; t < tile1; t += 2 * kScanWaves) {
-        load_tile(min(t + kScanWaves, tlast), TB);
-        compute_tile(t, TA);
-        load_tile(min(t + 2 * kScanWaves, tlast), TA);
-        if (t + kScanWaves < tile1) compute_tile(t + kScanWaves, TB);
+    const bool exchange = MODE == kModeTopK && p.slots_cur != nullptr;
+    int t_cur = t_a, t_nxt = t_b, slot = 0;
+    if (exchange) {
+        // ---- warm-up: three tiles per wave whose distances are only kept (no top-k work yet) ----
+        float w0[NQH][4], w1[NQH][4], w2[NQH][4];
+        auto kill = [&](bool dead, float (&w)[NQH][4]) {
+            if (dead) {
+#pragma unroll
+                for (int h = 0; h < NQH; ++h)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) w[h][j] = VS_INF;
+            }
+        };
+        asm volatile("s_waitcnt vmcnt(9)" ::: "memory");  // A landed (B follows)
+        tile_distances(min(t_a, tlast), 0, w0);
+        kill(t_a >= tile1, w0);
+        const int t_c = next_ticket();
+        issue_tile(min(t_c, tlast), 0);  // queue: B C
+        // publish this workgroup's per-query minimum (distinct workgroups hold distinct rows)
+#pragma unroll
+        for (int h = 0; h < NQH; ++h) {
+            float m = fminf(fminf(w0[h][0], w0[h][1]), fminf(w0[h][2], w0[h][3]));
+            m = fminf(m, __shfl_xor(m, 16));
+            m = fminf(m, __shfl_xor(m, 32));
+            if (g == 0) lds_wmin[wave * 32 + h * 16 + r] = m;
+        }
+        lds_barrier();
+        if (threadIdx.x >= 64 && threadIdx.x < 64 + NQH * 16) {  // wave 1 publishes (one extra op in its queue)
+            const int qx = threadIdx.x - 64;
+            float m = lds_wmin[qx];
+#pragma unroll
+            for (int w = 1; w < kScanWaves; ++w) m = fminf(m, lds_wmin[w * 32 + qx]);
+            __hip_atomic_store(p.slots_cur + qx * kSlotStride + blockIdx.x, m, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
+        VS_STAMP(2);
+        asm volatile("s_waitcnt vmcnt(9)" ::: "memory");  // B landed (C, and on wave 1 the store, follow)
+        tile_distances(min(t_b, tlast), 1, w1);
+        kill(t_b >= tile1, w1);
+        // DPP row `g` of wave w will reduce query 4w+g: its 16 lanes read that query's 1 KB row of
+        // minima (write-through-coherent sc1 loads, 64 contiguous bytes per lane = workgroups
+        // 16 l .. 16 l + 15).  Issued now, consumed after the next tile.
+        f32x4 v0, v1, v2, v3;
+        {
+            const float* s0 = p.slots_cur + (4 * wave + g) * kSlotStride + 16 * r;
+            asm volatile(
+                "global_load_dwordx4 %0, %4, off sc1\n\t"
+                "global_load_dwordx4 %1, %4, off offset:16 sc1\n\t"
+                "global_load_dwordx4 %2, %4, off offset:32 sc1\n\t"
+                "global_load_dwordx4 %3, %4, off offset:48 sc1"
+                : "=v"(v0), "=v"(v1), "=v"(v2), "=v"(v3)
+                : "v"(s0)
+                : "memory");
+        }
+        const int t_d = next_ticket();
+        issue_tile(min(t_d, tlast), 1);  // queue: C loads(4) D
+        asm volatile("s_waitcnt vmcnt(13)" ::: "memory");  // C landed
+        tile_distances(min(t_c, tlast), 0, w2);
+        kill(t_c >= tile1, w2);
+        const int t_e = next_ticket();
+        issue_tile(min(t_e, tlast), 0);  // queue: loads(4) D E
+        asm volatile("s_waitcnt vmcnt(18)" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3)::"memory");  // the minima are here
+        {
+            // Each lane folds its 16 workgroups into one minimum; the k1-th smallest of the row's
+            // 16 lane minima is still backed by k1 distinct rows (one per lane group), and with
+            // groups this large it is within a few per cent of the k1-th smallest of all 256.
+            float m = fminf(fminf(fminf(v0[0], v0[1]), fminf(v0[2], v0[3])), fminf(fminf(v1[0], v1[1]), fminf(v1[2], v1[3])));
+            m = fminf(m, fminf(fminf(fminf(v2[0], v2[1]), fminf(v2[2], v2[3])), fminf(fminf(v3[0], v3[1]), fminf(v3[2], v3[3]))));
+            float kth = VS_INF;
+            for (int round = 0; round < p.k1; ++round) {
+                float x = m;
+                x = fminf(x, dpp_mov_f<0xB1>(x));
+                x = fminf(x, dpp_mov_f<0x4E>(x));
+                x = fminf(x, dpp_mov_f<0x141>(x));
+                x = fminf(x, dpp_mov_f<0x140>(x));  // row minimum in every lane of the row
+                kth = x;
+                const unsigned rowmask = (unsigned)((__ballot(m == x) >> (16 * g)) & 0xFFFFull);
+                if (rowmask != 0u && r == __builtin_ctz(rowmask)) m = VS_INF;  // drop exactly one instance
+            }
+            if (r == 0) lds_tau[4 * wave + g] = kth < VS_INF ? next_up(kth) : VS_INF;
+        }
+        lds_barrier();
+#pragma unroll
+        for (int h = 0; h < NQH; ++h) {
+            tq[h] = lds_tau[h * 16 + r];
+            tau[h] = tq[h];
+        }
+        VS_STAMP(3);
+        // replay the kept tiles against the bound (almost nothing passes)
+        consume(min(t_a, tlast), w0);
+        consume(min(t_b, tlast), w1);
+        consume(min(t_c, tlast), w2);
+        t_cur = t_d;
+        t_nxt = t_e;
+        slot = 1;
     }
-
+    // ---- steady state: t_cur sits in `slot` (landed or landing), t_nxt in the other slot ----
+    while (t_cur < tile1) {
+        asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        float d[NQH][4];
+        tile_distances(t_cur, slot, d);
+        consume(t_cur, d);
+        t_cur = t_nxt;
+        t_nxt = next_ticket();
+        issue_tile(min(t_nxt, tlast), slot);
+        slot ^= 1;
+    }
+    VS_STAMP(5);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // retire the discarded tail prefetches: LDS is reused below
     if (MODE != kModeTopK) return;
+    __syncthreads();
+    VS_STAMP(4);
 
-    // ---- workgroup merge: 32 lane lists per query (8 waves x 4 lane groups) -> one sorted list ----
-    // LDS image: [query][list s = wave*4+g][KCAP] for dist and id.
-    float* sd = reinterpret_cast<float*>(smem);
-    int* si = reinterpret_cast<int*>(smem + (size_t)NQH * 16 * 32 * KCAP * sizeof(float));
+    // ---- workgroup merge: compact the entries that can still matter (d < tau0), rank them ----
+    constexpr int NQ = NQH * 16;
+    constexpr int CAP = 32 * KCAP;  // 32 lane lists per query: cannot overflow
+    float* cand_d = reinterpret_cast<float*>(smem);
+    int* cand_i = reinterpret_cast<int*>(smem + (size_t)NQ * CAP * sizeof(float));
 #pragma unroll
     for (int h = 0; h < NQH; ++h) {
-        const int base_off = ((h * 16 + r) * 32 + (wave * 4 + g)) * KCAP;
+        const int qidx = h * 16 + r;
 #pragma unroll
-        for (int j = 0; j < KCAP; ++j) {
-            sd[base_off + j] = ld[h][j];
-            si[base_off + j] = li[h][j];
-        }
+        for (int j = 0; j < KCAP; ++j)
+            if (li[h][j] >= 0 && ld[h][j] < tq[h]) {
+                const int pos = atomicAdd(&lds_cnt[qidx], 1);
+                cand_d[qidx * CAP + pos] = ld[h][j];
+                cand_i[qidx * CAP + pos] = li[h][j];
+            }
     }
     __syncthreads();
-
-    // each half-wave merges one query: lane s of the half walks list s
-    const int half = lane >> 5;
-    const int s = lane & 31;
-    constexpr int NQ = NQH * 16;
-    for (int qq = wave * 2 + half; qq < NQ; qq += 2 * kScanWaves) {
-        const int lo = (qq * 32 + s) * KCAP;
-        int ptr = 0;
-        float hd = sd[lo];
-        int hi = si[lo];
+    constexpr int EPL = CAP / 64;
+    for (int qq = wave; qq < NQ; qq += kScanWaves) {
+        const int M = lds_cnt[qq];
+        float cd[EPL];
+        int ci[EPL];
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const int idx = e * 64 + lane;
+            cd[e] = idx < M ? cand_d[qq * CAP + idx] : VS_INF;
+            ci[e] = idx < M ? cand_i[qq * CAP + idx] : 0x7fffffff;
+        }
         float* od = p.part_d + ((int64_t)blockIdx.x * kMaxBatch + qq) * KCAP;
         int32_t* oi = p.part_i + ((int64_t)blockIdx.x * kMaxBatch + qq) * KCAP;
-        for (int round = 0; round < KCAP; ++round) {
-            float bd = hd;
-            int bi = hi;
+        const int rounds = min(min(p.k1, KCAP), M);
+        for (int round = 0; round < rounds; ++round) {
+            float md = cd[0];
+            int mi = ci[0];
 #pragma unroll
-            for (int m = 1; m < 32; m <<= 1) {
-                const float od2 = __shfl_xor(bd, m);
-                const int oi2 = __shfl_xor(bi, m);
-                if (lex_lt(od2, oi2, bd, bi)) {
-                    bd = od2;
-                    bi = oi2;
+            for (int e = 1; e < EPL; ++e)
+                if (lex_lt(cd[e], ci[e], md, mi)) {
+                    md = cd[e];
+                    mi = ci[e];
                 }
-            }
-            if (s == 0) {
+            float bd;
+            int bi;
+            wave_lexmin(md, mi, bd, bi);
+            if (lane == 0) {
                 od[round] = bd;
                 oi[round] = bi;
             }
-            if (bi >= 0 && hi == bi && hd == bd) {  // the owner of the winner advances
-                ++ptr;
-                hd = ptr < KCAP ? sd[lo + ptr] : VS_INF;
-                hi = ptr < KCAP ? si[lo + ptr] : -1;
-            }
+#pragma unroll
+            for (int e = 0; e < EPL; ++e)
+                if (ci[e] == bi && cd[e] == bd) {
+                    cd[e] = VS_INF;
+                    ci[e] = 0x7fffffff;
+                }
+        }
+        if (lane < KCAP && lane >= rounds) {
+            od[lane] = VS_INF;
+            oi[lane] = -1;
         }
     }
+    VS_STAMP(6);
 }
 
 template <int NQH, int KCAP, int MODE>
 static hipError_t launch_scan_t(const ScanParams& p, int grid, hipStream_t s) {
-    size_t lds = (MODE == kModeTopK) ? (size_t)NQH * 16 * 32 * KCAP * 8 : 0;
     auto kfn = scan_kernel<NQH, KCAP, MODE>;
-    if (lds > 64 * 1024) {
+    static bool attr_set = false;
+    if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kScanLds);
         if (e != hipSuccess) return e;
+        attr_set = true;
     }
-    hipLaunchKernelGGL(kfn, dim3(grid), dim3(kScanThreads), lds, s, p);
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(kScanThreads), kScanLds, s, p);
     return hipGetLastError();
 }
 
@@ -353,9 +637,7 @@ __global__ __launch_bounds__(256) void merge_kernel(const MergeParams p, const M
     }
 }
 
-hipError_t launch_merge_layout(const MergeParams& p, int64_t stride_g, int64_t stride_q, hipStream_t s) {
-    if (p.kout < 1 || p.G < 1 || p.nq < 1) return hipErrorInvalidValue;
-    MergeLayout L{stride_g, stride_q};
+static hipError_t launch_merge_heads(const MergeParams& p, const MergeLayout& L, hipStream_t s) {
     const int lpt = (p.G + 255) / 256;
     if (lpt <= 1) hipLaunchKernelGGL(merge_kernel<1>, dim3(p.nq), dim3(256), 0, s, p, L);
     else if (lpt <= 2) hipLaunchKernelGGL(merge_kernel<2>, dim3(p.nq), dim3(256), 0, s, p, L);
@@ -366,13 +648,240 @@ hipError_t launch_merge_layout(const MergeParams& p, int64_t stride_g, int64_t s
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Compacting merge (fast path, G*kin <= kCompactCap).  With the threshold exchange most partial
+// lists are empty, so the finite entries are first compacted into LDS (one atomic append each);
+// a handful of candidates is then ranked by a single wave with DPP/shuffle argmin rounds and no
+// barriers.  Larger candidate sets use workgroup-wide rounds over the LDS array.
+// ------------------------------------------------------------------------------------------------
+constexpr int kCompactCap = 4096;
+
+// kout rounds of wave-wide (dist, id) argmin over M <= 64*EPL candidates parked in LDS; lane-local
+// candidates live in registers, the wave reduction is DPP only (no LDS traffic, no barriers).
+template <int EPL>
+__device__ __forceinline__ void wave_rank_and_emit(const MergeParams& p, int q, const float* cd, const int* ci, int M,
+                                                   float* outd, int lane) {
+    float d[EPL];
+    int id[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        const int idx = e * 64 + lane;
+        d[e] = idx < M ? cd[idx] : VS_INF;
+        id[e] = idx < M ? ci[idx] : 0x7fffffff;
+    }
+    for (int round = 0; round < p.kout; ++round) {
+        float md = d[0];
+        int mi = id[0];
+#pragma unroll
+        for (int e = 1; e < EPL; ++e)
+            if (lex_lt(d[e], id[e], md, mi)) {
+                md = d[e];
+                mi = id[e];
+            }
+        float bd;
+        int bi;
+        wave_lexmin(md, mi, bd, bi);
+        const bool none = bi == 0x7fffffff;
+        if (lane == 0) {
+            if (round < kMergeTrack) outd[round] = none ? VS_INF : bd;
+            if (p.out_d) p.out_d[(int64_t)q * p.kout + round] = none ? VS_INF : bd;
+            if (p.out_i) p.out_i[(int64_t)q * p.kout + round] = none ? -1 : (p.id_map ? p.id_map[bi] : bi);
+        }
+#pragma unroll
+        for (int e = 0; e < EPL; ++e)
+            if (id[e] == bi && d[e] == bd) {
+                d[e] = VS_INF;
+                id[e] = 0x7fffffff;
+            }
+    }
+}
+
+__global__ __launch_bounds__(256) void merge_compact_kernel(const MergeParams p, const MergeLayout L) {
+    __shared__ float cd[kCompactCap];
+    __shared__ int ci[kCompactCap];
+    __shared__ int cnt;
+    __shared__ float wbd[4];
+    __shared__ int wbi[4];
+    __shared__ int wbp[4];
+    __shared__ float outd[kMergeTrack];
+    const int q = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) cnt = 0;
+    __syncthreads();
+    for (int g = tid; g < p.G; g += 256) {
+        const int64_t off = (int64_t)g * L.stride_g + (int64_t)q * L.stride_q;
+        for (int j = 0; j < p.kin; ++j) {
+            const float d = p.part_d[off + j];
+            const int id = p.part_i ? p.part_i[off + j] : (g * p.kin + j);
+            if (!(d < VS_INF) || id < 0) {
+                if (p.part_i) break;  // sorted list: the rest is padding
+                continue;
+            }
+            const int pos = atomicAdd(&cnt, 1);
+            cd[pos] = d;
+            ci[pos] = id;
+        }
+    }
+    __syncthreads();
+    const int M = cnt;
+    const int n_track = p.kout < kMergeTrack ? p.kout : kMergeTrack;
+
+    if (M <= 1024) {
+        if (wave == 0) {
+            if (M <= 64) wave_rank_and_emit<1>(p, q, cd, ci, M, outd, lane);
+            else if (M <= 256) wave_rank_and_emit<4>(p, q, cd, ci, M, outd, lane);
+            else wave_rank_and_emit<16>(p, q, cd, ci, M, outd, lane);
+        }
+    } else {
+        for (int round = 0; round < p.kout; ++round) {
+            float bd = VS_INF;
+            int bi = -1, bp = -1;
+            for (int e = tid; e < M; e += 256) {
+                const float d = cd[e];
+                const int id = ci[e];
+                if (id >= 0 && lex_lt(d, id, bd, bi < 0 ? 0x7fffffff : bi)) {
+                    bd = d;
+                    bi = id;
+                    bp = e;
+                }
+            }
+#pragma unroll
+            for (int m = 1; m < 64; m <<= 1) {
+                const float od2 = __shfl_xor(bd, m);
+                const int oi2 = __shfl_xor(bi, m);
+                const int op2 = __shfl_xor(bp, m);
+                if (oi2 >= 0 && (bi < 0 || lex_lt(od2, oi2, bd, bi))) {
+                    bd = od2;
+                    bi = oi2;
+                    bp = op2;
+                }
+            }
+            if (lane == 0) {
+                wbd[wave] = bd;
+                wbi[wave] = bi;
+                wbp[wave] = bp;
+            }
+            __syncthreads();
+            bd = wbd[0];
+            bi = wbi[0];
+            bp = wbp[0];
+#pragma unroll
+            for (int w = 1; w < 4; ++w)
+                if (wbi[w] >= 0 && (bi < 0 || lex_lt(wbd[w], wbi[w], bd, bi))) {
+                    bd = wbd[w];
+                    bi = wbi[w];
+                    bp = wbp[w];
+                }
+            if (bi < 0) bd = VS_INF;
+            __syncthreads();
+            if (tid == 0) {
+                if (bp >= 0) ci[bp] = -1;  // consumed
+                if (round < kMergeTrack) outd[round] = bd;
+                if (p.out_d) p.out_d[(int64_t)q * p.kout + round] = bd;
+                if (p.out_i) p.out_i[(int64_t)q * p.kout + round] = (bi >= 0 && p.id_map) ? p.id_map[bi] : bi;
+            }
+            __syncthreads();
+        }
+    }
+    if (tid == 0) {
+        if (p.flags) {
+            int f = 0;
+            for (int i = 0; i + 1 < n_track; ++i)
+                if (outd[i] == outd[i + 1] && outd[i] < VS_INF) f = 1;
+            p.flags[q] = f;
+        }
+        if (p.tau_out) {
+            const float kth = outd[n_track - 1];
+            p.tau_out[q] = kth < VS_INF ? next_up(kth) : VS_INF;
+        }
+    }
+}
+
+hipError_t launch_merge_layout(const MergeParams& p, int64_t stride_g, int64_t stride_q, hipStream_t s) {
+    if (p.kout < 1 || p.G < 1 || p.nq < 1) return hipErrorInvalidValue;
+    MergeLayout L{stride_g, stride_q};
+    if ((int64_t)p.G * p.kin <= kCompactCap) {
+        hipLaunchKernelGGL(merge_compact_kernel, dim3(p.nq), dim3(256), 0, s, p, L);
+        return hipGetLastError();
+    }
+    return launch_merge_heads(p, L, s);
+}
+
 hipError_t launch_merge(const MergeParams& p, hipStream_t s) {
     // scan partial layout: [G][nq_stride][kin]
     return launch_merge_layout(p, (int64_t)p.nq_stride * p.kin, p.kin, s);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Probe selection (std::nth_element at IVFIndex.cpp:711, made deterministic): one wave per query.
+// Each lane sorts its 16 strided scores in registers (bitonic network, static indices), parks the
+// sorted run in LDS and the wave then pops nprobe winners with shuffle argmin rounds.
+// ------------------------------------------------------------------------------------------------
+constexpr int kPickVPL = 16;  // values per lane -> nlist <= 1024
+
+__global__ __launch_bounds__(256) void pick_probes_kernel(const float* __restrict__ scores, int64_t ld, int B, int nlist,
+                                                          int nprobe, int32_t* __restrict__ probes) {
+    __shared__ float sv[4][64][kPickVPL + 1];
+    __shared__ int si[4][64][kPickVPL + 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = blockIdx.x * 4 + wave;
+    if (q >= B) return;
+    float v[kPickVPL];
+    int id[kPickVPL];
+#pragma unroll
+    for (int i = 0; i < kPickVPL; ++i) {
+        const int c = i * 64 + lane;
+        float x = c < nlist ? scores[(int64_t)q * ld + c] : VS_INF;
+        const bool ok = c < nlist && x == x;
+        v[i] = ok ? x : VS_INF;
+        id[i] = ok ? c : 0x7fffffff;
+    }
+#pragma unroll
+    for (int k = 2; k <= kPickVPL; k <<= 1)
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1)
+#pragma unroll
+            for (int i = 0; i < kPickVPL; ++i) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const bool up = (i & k) == 0;
+                    const bool sw = up ? lex_lt(v[l], id[l], v[i], id[i]) : lex_lt(v[i], id[i], v[l], id[l]);
+                    const float tv = sw ? v[l] : v[i];
+                    const int ti = sw ? id[l] : id[i];
+                    v[l] = sw ? v[i] : v[l];
+                    id[l] = sw ? id[i] : id[l];
+                    v[i] = tv;
+                    id[i] = ti;
+                }
+            }
+#pragma unroll
+    for (int i = 0; i < kPickVPL; ++i) {
+        sv[wave][lane][i] = v[i];
+        si[wave][lane][i] = id[i];
+    }
+    int ptr = 0;
+    float hd = v[0];
+    int hi = id[0];
+    for (int round = 0; round < nprobe; ++round) {
+        float bd;
+        int bi;
+        wave_lexmin(hd, hi, bd, bi);
+        if (lane == 0) probes[(int64_t)q * nprobe + round] = bi == 0x7fffffff ? -1 : bi;
+        if (hi == bi && bi != 0x7fffffff) {
+            ++ptr;
+            hd = ptr < kPickVPL ? sv[wave][lane][ptr] : VS_INF;
+            hi = ptr < kPickVPL ? si[wave][lane][ptr] : 0x7fffffff;
+        }
+    }
+}
+
 hipError_t launch_pick_probes(const float* scores, int64_t ld, int B, int nlist, int nprobe,
                               int32_t* probes, hipStream_t s) {
+    if (nlist <= 64 * kPickVPL) {
+        hipLaunchKernelGGL(pick_probes_kernel, dim3((B + 3) / 4), dim3(256), 0, s, scores, ld, B, nlist, nprobe, probes);
+        return hipGetLastError();
+    }
     MergeParams p{};
     p.part_d = scores;
     p.part_i = nullptr;
@@ -419,30 +928,6 @@ hipError_t launch_row_sqnorm(const float* v, int64_t rows, int dim, float* out, 
     return hipGetLastError();
 }
 
-// Pad to 32 x 128 with zero rows (main.cpp:206-211, main_ivf.cpp:149-153) + norms, one workgroup.
-__global__ __launch_bounds__(256) void prep_queries_kernel(const float* __restrict__ q, int B,
-                                                           float* __restrict__ qpad, float* __restrict__ qnorm) {
-    const int row = threadIdx.x >> 3;  // 32 rows x 8 lanes
-    const int j = threadIdx.x & 7;
-    float acc = 0.f;
-    for (int i = 0; i < kDim; i += 8) {
-        const float x = row < B ? q[row * kDim + i + j] : 0.f;
-        qpad[row * kDim + i + j] = x;
-        acc = fmaf(x, x, acc);
-    }
-    const int lane = threadIdx.x & 63;
-    const int b = lane & ~7;
-    float sum = __shfl(acc, b);
-#pragma unroll
-    for (int u = 1; u < 8; ++u) sum = sum + __shfl(acc, b + u);
-    if (j == 0) qnorm[row] = sum;
-}
-
-hipError_t launch_prep_queries(const float* q, int B, float* qpad, float* qnorm, hipStream_t s) {
-    hipLaunchKernelGGL(prep_queries_kernel, dim3(1), dim3(256), 0, s, q, B, qpad, qnorm);
-    return hipGetLastError();
-}
-
 // ------------------------------------------------------------------------------------------------
 // IVF list scan.  One 256-thread workgroup per (query, probe) item; the four waves take
 // alternating groups of 8 rows.  8 lanes share a row: every wave-instruction reads 8 rows x 128
@@ -478,6 +963,7 @@ template <int KCAP>
 __global__ __launch_bounds__(256) void ivf_scan_kernel(const IvfScanParams p) {
     __shared__ float sld[4][KCAP];
     __shared__ int sli[4][KCAP];
+    __shared__ float s_qn;
     const int item = blockIdx.x;
     const int b = item / p.nprobe;
     const int pr = item - b * p.nprobe;
@@ -496,7 +982,20 @@ __global__ __launch_bounds__(256) void ivf_scan_kernel(const IvfScanParams p) {
     f32x4 qf[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) qf[m] = *reinterpret_cast<const f32x4*>(p.q + b * kDim + 4 * (s8 + 8 * m));
-    const float qn = p.qnorm[b];
+    if (threadIdx.x < 8) {  // ||q||^2 in the reference's AVX2 order (cpu_baseline.cpp:95-114)
+        float a = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float x = p.q[b * kDim + 8 * i + threadIdx.x];
+            a = fmaf(x, x, a);
+        }
+        float sum = __shfl(a, 0);
+#pragma unroll
+        for (int u = 1; u < 8; ++u) sum = sum + __shfl(a, u);
+        if (threadIdx.x == 0) s_qn = sum;
+    }
+    __syncthreads();
+    const float qn = s_qn;
 
     float ld = VS_INF;
     int li = -1;

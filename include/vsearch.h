@@ -123,6 +123,15 @@ VS_API int vs_bf_search(vs_index* h, const float* queries_host, int64_t nq, int 
 VS_API int vs_bf_search_dev(vs_index* h, const float* queries_dev, int B, int k,
                             int32_t* ids_dev, float* dists_dev, int32_t* flags_dev, void* stream);
 
+/* The same for n_batches consecutive batches of exactly B queries each
+ * (queries_dev [n_batches*B x d], outputs [n_batches*B x (k+1)], flags [n_batches*B]):
+ * the harness loop of main.cpp:201-251 in one call.  Batches still stream the
+ * base once each, but consecutive batches run on different internal HIP
+ * streams so that one batch's start-up and tail overlap its neighbours'
+ * streaming phase; the call forks from and joins into `stream`. */
+VS_API int vs_bf_search_dev_multi(vs_index* h, const float* queries_dev, int n_batches, int B, int k,
+                                  int32_t* ids_dev, float* dists_dev, int32_t* flags_dev, void* stream);
+
 /* QnnRunner::executeBatchRaw proper (QnnRunner.cpp:683-724): the raw
  * [B x ld] score matrix, scores_dev[b*ld + j] = dist(query b, row j), ld >= n_rows. */
 VS_API int vs_bf_scores_dev(vs_index* h, const float* queries_dev, int B,
