@@ -117,8 +117,7 @@ def main():
 
     # ---------------------------------------------------------------- data (synthetic, deterministic)
     t0 = time.time()
-    bounds = np.linspace(0, n_rows, world + 1).astype(np.int64)
-    bounds[1:-1] = (bounds[1:-1] // 16) * 16
+    bounds = pkg.row_shard_bounds(n_rows, world)
     r0, r1 = int(bounds[rank]), int(bounds[rank + 1])
     shard = pkg.synth_sift(r1 - r0, seed=SEED_BASE, row_begin=r0)
     n_queries = 4096
@@ -130,11 +129,12 @@ def main():
     stream = torch.cuda.current_stream()
     sptr = stream.cuda_stream
 
-    # per-rank result ring: [2][S][B][K1] words (dists as float bits | ids) -> one all-gather per S steps
-    loc = torch.zeros((2, S, BATCH, K1), dtype=torch.int32, device=dev)
+    # per-rank result buffer: [2][S][B][K1] words (dists as float bits | ids) -> one all-gather per S steps
+    lay = pkg.GatherLayout(S, BATCH, K1)
+    loc = torch.zeros((lay.words,), dtype=torch.int32, device=dev)
     loc_d_ptr = loc.data_ptr()
-    loc_i_ptr = loc.data_ptr() + S * BATCH * K1 * 4
-    gath = torch.zeros((world, 2, S, BATCH, K1), dtype=torch.int32, device=dev) if world > 1 else None
+    loc_i_ptr = loc.data_ptr() + lay.ids_offset * 4
+    gath = torch.zeros((world * lay.words,), dtype=torch.int32, device=dev) if world > 1 else None
     out_d = torch.zeros((S * BATCH, K1), dtype=torch.float32, device=dev)
     out_i = torch.zeros((S * BATCH, K1), dtype=torch.int32, device=dev)
     flags = torch.zeros((S * BATCH,), dtype=torch.int32, device=dev)
@@ -155,9 +155,8 @@ def main():
         else:
             bf.search_dev_multi(qp, S, BATCH, K, loc_i_ptr, loc_d_ptr, 0, sptr)
             dist.all_gather_into_tensor(gath, loc)
-            pkg.topk_merge_dev(gath.data_ptr(), gath.data_ptr() + S * BATCH * K1 * 4, world, S * BATCH, K1, K1,
-                               out_d.data_ptr(), out_i.data_ptr(), flags.data_ptr(), sptr,
-                               stride_g=2 * S * BATCH * K1)
+            pkg.topk_merge_dev(gath.data_ptr(), gath.data_ptr() + lay.ids_offset * 4, world, S * BATCH, K1, K1,
+                               out_d.data_ptr(), out_i.data_ptr(), flags.data_ptr(), sptr, stride_g=lay.stride_g)
 
     def barrier():
         if dist is not None:
@@ -231,8 +230,9 @@ def main():
         sizes = np.diff(off)
         log(f"IVF index: nlist={nlist}, list sizes min/avg/max = {sizes.min()}/{sizes.mean():.0f}/{sizes.max()}, "
             f"built in {time.time() - t0:.1f}s")
-        iloc = torch.zeros((2, S, BATCH, K), dtype=torch.int32, device=dev)
-        igath = torch.zeros((world, 2, S, BATCH, K), dtype=torch.int32, device=dev) if world > 1 else None
+        ilay = pkg.GatherLayout(S, BATCH, K)
+        iloc = torch.zeros((ilay.words,), dtype=torch.int32, device=dev)
+        igath = torch.zeros((world * ilay.words,), dtype=torch.int32, device=dev) if world > 1 else None
         iout_d = torch.zeros((S * BATCH, K), dtype=torch.float32, device=dev)
         iout_i = torch.zeros((S * BATCH, K), dtype=torch.int32, device=dev)
 
@@ -243,12 +243,12 @@ def main():
                 ivf.search_dev(qp, BATCH, K, NPROBE, iout_i.data_ptr() + s * BATCH * K * 4,
                                iout_d.data_ptr() + s * BATCH * K * 4, sptr)
             else:
-                ivf.search_dev(qp, BATCH, K, NPROBE, iloc.data_ptr() + (S + s) * BATCH * K * 4,
-                               iloc.data_ptr() + s * BATCH * K * 4, sptr)
+                ivf.search_dev(qp, BATCH, K, NPROBE, iloc.data_ptr() + ilay.id_offset(s) * 4,
+                               iloc.data_ptr() + ilay.dist_offset(s) * 4, sptr)
                 if s == S - 1:
                     dist.all_gather_into_tensor(igath, iloc)
-                    pkg.topk_merge_dev(igath.data_ptr(), igath.data_ptr() + S * BATCH * K * 4, world, S * BATCH, K, K,
-                                       iout_d.data_ptr(), iout_i.data_ptr(), 0, sptr, stride_g=2 * S * BATCH * K)
+                    pkg.topk_merge_dev(igath.data_ptr(), igath.data_ptr() + ilay.ids_offset * 4, world, S * BATCH, K, K,
+                                       iout_d.data_ptr(), iout_i.data_ptr(), 0, sptr, stride_g=ilay.stride_g)
 
         ivf.prof_enable(True)
         iel = timed(ivf_step, steps, warmup)

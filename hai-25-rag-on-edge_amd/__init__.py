@@ -118,6 +118,7 @@ def lib():
         "vs_ivf_save": (i32, [vp, C.c_char_p]),
         "vs_ivf_search": (i32, [vp, vp, i64, i32, i32, vp, vp, C.POINTER(i64), C.POINTER(Timing)]),
         "vs_ivf_search_dev": (i32, [vp, vp, i32, i32, i32, vp, vp, vp]),
+        "vs_ivf_list_owners": (i32, [vp, i32, i32, vp]),
         "vs_topk_merge_dev": (i32, [vp, vp, i32, i32, i32, i64, i32, vp, vp, vp, vp]),
         "vs_prof_enable": (i32, [vp, i32]),
         "vs_prof_read": (i32, [vp, i32, C.POINTER(C.c_double), C.POINTER(i64)]),
@@ -361,3 +362,54 @@ def clamp_nlist(n_vectors: int, n_clusters: int) -> int:
     if n_clusters > n_vectors // 10:
         n_clusters = max(16, n_vectors // 100)
     return n_clusters
+
+
+# ------------------------------------------------------------------ multi-GPU host logic (no GPU needed)
+def row_shard_bounds(n_rows: int, world: int) -> np.ndarray:
+    """Contiguous row shards for brute force; interior bounds are multiples of 16 (one MFMA tile)."""
+    b = np.linspace(0, n_rows, world + 1).astype(np.int64)
+    b[1:-1] = (b[1:-1] // 16) * 16
+    return b
+
+
+def ivf_list_owners(cluster_offsets, world: int) -> np.ndarray:
+    """Rank owning each inverted list (longest-first round robin) -- the library's own assignment."""
+    off = np.ascontiguousarray(cluster_offsets, dtype=np.int32)
+    out = np.empty(len(off) - 1, dtype=np.int32)
+    _check(lib().vs_ivf_list_owners(_p(off), len(off) - 1, world, _p(out)))
+    return out
+
+
+class GatherLayout:
+    """The per-rank buffer that goes through the all-gather: [2][S][B][K] 32-bit words, plane 0 = distances
+    (f32 bits), plane 1 = ids.  After an all-gather into [world][2][S][B][K] the merge kernel reads shard g's
+    list of query (s, b) at g*stride_g + (s*B + b)*K (+ ids_offset words for the ids)."""
+
+    def __init__(self, S: int, B: int, K: int):
+        self.S, self.B, self.K = S, B, K
+        self.words = 2 * S * B * K
+        self.stride_g = 2 * S * B * K
+        self.ids_offset = S * B * K
+
+    def dist_offset(self, s: int) -> int:
+        return s * self.B * self.K
+
+    def id_offset(self, s: int) -> int:
+        return self.ids_offset + s * self.B * self.K
+
+    def merge_reference(self, gathered: np.ndarray, kout: int):
+        """numpy restatement of vs_topk_merge_dev on a gathered int32 buffer [world, words]."""
+        world = gathered.shape[0]
+        g = gathered.reshape(world, 2, self.S * self.B, self.K)
+        d = g[:, 0].view(np.float32)
+        i = g[:, 1]
+        nq = self.S * self.B
+        out_d = np.full((nq, kout), np.inf, dtype=np.float32)
+        out_i = np.full((nq, kout), -1, dtype=np.int32)
+        for q in range(nq):
+            cand = [(float(d[w, q, j]), int(i[w, q, j])) for w in range(world) for j in range(self.K)
+                    if i[w, q, j] >= 0 and np.isfinite(d[w, q, j])]
+            cand.sort()
+            for t, (dd, ii) in enumerate(cand[:kout]):
+                out_d[q, t], out_i[q, t] = dd, ii
+        return out_d, out_i

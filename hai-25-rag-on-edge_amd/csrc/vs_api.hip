@@ -593,6 +593,20 @@ int vs_bf_search(vs_index* h, const float* queries_host, int64_t nq, int k, int3
 }
 
 // --------------------------------------------------------------------------------------------- IVF
+int vs_ivf_list_owners(const int32_t* cluster_offsets, int nlist, int world, int32_t* owner_out) {
+    if (!cluster_offsets || !owner_out || nlist <= 0 || world < 1) {
+        set_error("vs_ivf_list_owners: bad arguments");
+        return VS_ERR_INVALID;
+    }
+    std::vector<int> order(nlist);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+        return (cluster_offsets[a + 1] - cluster_offsets[a]) > (cluster_offsets[b + 1] - cluster_offsets[b]);
+    });
+    for (int i = 0; i < nlist; ++i) owner_out[order[i]] = i % world;
+    return VS_OK;
+}
+
 static int ivf_create_impl(const float* vectors, int64_t n_rows, int dim, const float* centroids, int nlist,
                            const int32_t* offsets, const int32_t* r2o, int device, int rank, int world,
                            vs_index** out) {
@@ -630,13 +644,10 @@ static int ivf_create_impl(const float* vectors, int64_t n_rows, int dim, const 
 
     // Ownership: lists sorted by length (desc), dealt round-robin -> balanced bytes and probe hits
     // (SURVEY.md 8e).  Only owned lists are made resident; the others become empty ranges.
-    std::vector<int> order(nlist);
-    std::iota(order.begin(), order.end(), 0);
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
-        return (offsets[a + 1] - offsets[a]) > (offsets[b + 1] - offsets[b]);
-    });
+    std::vector<int32_t> owner(nlist);
+    vs_ivf_list_owners(offsets, nlist, world, owner.data());
     std::vector<uint8_t> owned(nlist, 0);
-    for (int i = 0; i < nlist; ++i) owned[order[i]] = (i % world) == rank;
+    for (int c = 0; c < nlist; ++c) owned[c] = owner[c] == rank;
     std::vector<int32_t> loc_off(nlist + 1, 0);
     for (int c = 0; c < nlist; ++c) loc_off[c + 1] = loc_off[c] + (owned[c] ? offsets[c + 1] - offsets[c] : 0);
     const int64_t n_local = loc_off[nlist];

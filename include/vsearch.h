@@ -167,6 +167,11 @@ VS_API int vs_ivf_search_dev(vs_index* h, const float* queries_dev, int B, int k
                              int32_t* ids_dev, float* dists_dev, void* stream);
 
 /* ---------------------------------------------------------------- multi-GPU */
+/* Which rank owns which inverted list in a cluster-sharded index (host only, no GPU needed):
+ * lists sorted by length, longest first, dealt round-robin -> owner_out[nlist] in [0, world).
+ * vs_ivf_create / vs_ivf_load use exactly this assignment. */
+VS_API int vs_ivf_list_owners(const int32_t* cluster_offsets, int nlist, int world, int32_t* owner_out);
+
 /* Merge G per-shard sorted lists (e.g. the receive buffer of an RCCL
  * all-gather) into [B x kout] by (dist, id) ascending; flags as above when
  * flags_dev != NULL.  Entry (g, b, j) lives at g*stride_g + b*kin + j in both
