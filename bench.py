@@ -81,13 +81,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=40)
-    ap.add_argument("--coll-every", type=int, default=16,
+    ap.add_argument("--coll-every", type=int, default=32,
                     help="batches per multi-batch call (and per all-gather + merge when N > 1)")
     ap.add_argument("--rows", type=int, default=N_BASE, help="base rows (default SIFT-1M)")
     ap.add_argument("--no-ivf", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not time the scan kernel with HIP events")
     ap.add_argument("--kmeans-iters", type=int, default=8)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo = rehearsal of the N > 1 path on ONE GPU (all ranks share cuda:0, gathers staged through host)")
     args = ap.parse_args()
 
     import torch
@@ -104,8 +106,12 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "gloo":
+            local_rank = 0
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if pkg.device_count() < 1:
@@ -154,7 +160,7 @@ def main():
             bf.search_dev_multi(qp, S, BATCH, K, out_i.data_ptr(), out_d.data_ptr(), flags.data_ptr(), sptr)
         else:
             bf.search_dev_multi(qp, S, BATCH, K, loc_i_ptr, loc_d_ptr, 0, sptr)
-            dist.all_gather_into_tensor(gath, loc)
+            all_gather(gath, loc)
             pkg.topk_merge_dev(gath.data_ptr(), gath.data_ptr() + lay.ids_offset * 4, world, S * BATCH, K1, K1,
                                out_d.data_ptr(), out_i.data_ptr(), flags.data_ptr(), sptr, stride_g=lay.stride_g)
 
@@ -162,6 +168,16 @@ def main():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def all_gather(dst, src):
+        """ONE collective for the per-shard top-k lists (RCCL over xGMI; gloo only in rehearsals)."""
+        if args.backend == "gloo":
+            torch.cuda.current_stream().synchronize()
+            hd = torch.empty(dst.shape, dtype=dst.dtype)
+            dist.all_gather_into_tensor(hd, src.cpu())
+            dst.copy_(hd)
+        else:
+            dist.all_gather_into_tensor(dst, src)
 
     def timed(step_fn, nsteps, nwarm):
         for i in range(nwarm):
@@ -246,7 +262,7 @@ def main():
                 ivf.search_dev(qp, BATCH, K, NPROBE, iloc.data_ptr() + ilay.id_offset(s) * 4,
                                iloc.data_ptr() + ilay.dist_offset(s) * 4, sptr)
                 if s == S - 1:
-                    dist.all_gather_into_tensor(igath, iloc)
+                    all_gather(igath, iloc)
                     pkg.topk_merge_dev(igath.data_ptr(), igath.data_ptr() + ilay.ids_offset * 4, world, S * BATCH, K, K,
                                        iout_d.data_ptr(), iout_i.data_ptr(), 0, sptr, stride_g=ilay.stride_g)
 

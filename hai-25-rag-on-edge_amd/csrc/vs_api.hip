@@ -36,6 +36,7 @@ constexpr int kMaxEvents = 8192;
 constexpr int kKcapMax = 16;       // largest per-lane list the scan kernels are compiled for
 constexpr int kMaxNprobe = 256;
 constexpr int kMaxLanes = 4;
+constexpr int kMaxMulti = 32;  // batches per persistent scan launch
 
 struct ProfSlot {
     std::vector<hipEvent_t> ev;  // pairs
@@ -80,10 +81,10 @@ struct vs_index {
     // (inside one launch all workgroups go through those phases in lock-step and HBM idles).
     struct Lane {
         hipStream_t s = nullptr;
-        hipEvent_t done = nullptr;
-        float* slots = nullptr;     // [2][32][kSlotStride] threshold-exchange slots (two parities), +inf when idle
-        int parity = 0;
-        float* part_d = nullptr;    // [max_grid][32][16]
+        hipEvent_t done_ev = nullptr;
+        float* slots = nullptr;     // [kMaxMulti][32][kSlotStride] threshold-exchange slots, reset per launch
+        int* done = nullptr;        // [kMaxMulti] arrival counters, reset per launch
+        float* part_d = nullptr;    // [kMaxMulti][32][kSlotStride][16]
         int32_t* part_i = nullptr;
     };
     Lane lane[kMaxLanes];
@@ -123,9 +124,10 @@ void free_all(vs_index* h) {
     (void)hipSetDevice(h->device);
     for (auto& L : h->lane) {
         if (L.slots) (void)hipFree(L.slots);
+        if (L.done) (void)hipFree(L.done);
         if (L.part_d) (void)hipFree(L.part_d);
         if (L.part_i) (void)hipFree(L.part_i);
-        if (L.done) (void)hipEventDestroy(L.done);
+        if (L.done_ev) (void)hipEventDestroy(L.done_ev);
         if (L.s) (void)hipStreamDestroy(L.s);
     }
     if (h->fork) (void)hipEventDestroy(h->fork);
@@ -169,24 +171,26 @@ int alloc_scratch(vs_index* h) {
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, h->device));
     h->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (const char* e = getenv("VSEARCH_GRID_CUS")) h->num_cus = std::max(1, std::min(h->num_cus, atoi(e)));  // tuning knob
     int tp;
     scan_geometry(std::max<int64_t>(h->n_rows, 1), h->num_cus, h->max_grid, tp);
     h->max_grid = std::max(h->max_grid, h->num_cus);
     if ((rc = dev_alloc(&h->d_q, 32 * vs::kDim))) return rc;
     {
         const char* e = getenv("VSEARCH_LANES");
-        h->n_lanes = e ? std::max(1, std::min(kMaxLanes, atoi(e))) : 3;
-        const size_t nslot = (size_t)2 * 32 * vs::kSlotStride;
-        std::vector<float> inf(nslot, std::numeric_limits<float>::infinity());
-        const size_t part = (size_t)h->max_grid * 32 * kKcapMax;
+        h->n_lanes = e ? std::max(1, std::min(kMaxLanes, atoi(e))) : 1;
+        const size_t nslot = (size_t)kMaxMulti * 32 * vs::kSlotStride;
+        const size_t part = (size_t)kMaxMulti * 32 * vs::kSlotStride * kKcapMax;
         for (int i = 0; i < h->n_lanes; ++i) {
             vs_index::Lane& L = h->lane[i];
             if ((rc = dev_alloc(&L.slots, nslot))) return rc;
-            HIPCHK(hipMemcpy(L.slots, inf.data(), nslot * sizeof(float), hipMemcpyHostToDevice));
-            if ((rc = dev_alloc(&L.part_d, part))) return rc;
-            if ((rc = dev_alloc(&L.part_i, part))) return rc;
+            if ((rc = dev_alloc(&L.done, kMaxMulti))) return rc;
+            if (h->kind == 0) {
+                if ((rc = dev_alloc(&L.part_d, part))) return rc;
+                if ((rc = dev_alloc(&L.part_i, part))) return rc;
+            }
             HIPCHK(hipStreamCreateWithFlags(&L.s, hipStreamNonBlocking));
-            HIPCHK(hipEventCreateWithFlags(&L.done, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&L.done_ev, hipEventDisableTiming));
         }
         HIPCHK(hipEventCreateWithFlags(&h->fork, hipEventDisableTiming));
     }
@@ -249,10 +253,10 @@ int* g_dbg = nullptr;
 
 int pick_kcap(int need) { return need <= 8 ? 8 : (need <= 16 ? 16 : 0); }
 
-// One batch of the brute-force pipeline on stream s: scan (prep + threshold exchange + top-k fused) -> merge.
-// Consecutive calls on one index must be stream-ordered: they alternate between the two slot parities.
-int bf_batch_dev(vs_index* h, vs_index::Lane& L, const float* q_dev, int B, int k1, float* out_d, int32_t* out_i,
-                 int32_t* flags, hipStream_t s) {
+// nb <= kMaxMulti batches of B queries in ONE persistent launch on stream s: scan + exchange + top-k +
+// last-arriver merge, outputs [nb][B][k1].  Consecutive calls on one lane must be stream-ordered.
+int bf_launch(vs_index* h, vs_index::Lane& L, const float* q_dev, int nb, int B, int k1, float* out_d, int32_t* out_i,
+              int32_t* flags, hipStream_t s) {
     const int kcap = pick_kcap(k1);
     if (!kcap) {
         set_error("k too large for the compiled scan kernels (k <= 15)");
@@ -263,20 +267,21 @@ int bf_batch_dev(vs_index* h, vs_index::Lane& L, const float* q_dev, int B, int 
     p.base = h->d_vecs;
     p.bnorm = h->d_norm;
     p.q = q_dev;
+    p.n_batches = nb;
+    p.q_batch_stride = (int64_t)B * vs::kDim;
     p.metric = h->metric;
     p.id_offset = (int32_t)h->id_offset;
     p.nq_valid = B;
     p.k1 = k1;
-    p.xchg_first_it = g_xchg_first_it;
     p.dbg = g_dbg;
     int grid, tp;
     scan_geometry(h->n_rows, h->num_cus, grid, tp);
-    // the exchange pays once every wave has a few tiles left after its first two
-    const bool exchange = grid >= 16 && grid <= vs::kSlotStride && tp >= 6 * vs::kScanWaves;
+    // the exchange pays once every wave has a few tiles left after its first three
+    const bool exchange = grid >= 16 && tp >= 6 * vs::kScanWaves && g_xchg_first_it >= 0;
     if (exchange) {
-        p.slots_cur = L.slots + (size_t)L.parity * 32 * vs::kSlotStride;
-        p.slots_next = L.slots + (size_t)(1 - L.parity) * 32 * vs::kSlotStride;
-        L.parity ^= 1;
+        // 0x7f800000 = +inf
+        HIPCHK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(L.slots), 0x7f800000, (size_t)nb * 32 * vs::kSlotStride, s));
+        p.slots_cur = L.slots;
     }
     p.row_begin = 0;
     p.row_end = h->n_rows;
@@ -286,37 +291,36 @@ int bf_batch_dev(vs_index* h, vs_index::Lane& L, const float* q_dev, int B, int 
     prof_begin(h, 0, s);
     HIPCHK(vs::launch_scan(p, grid, kcap, nqh, vs::kModeTopK, s));
     prof_end(h, 0, s);
-
+    // one merge launch ranks every (batch, query): lists are [batch*32 + q][workgroup][kcap]
     vs::MergeParams m{};
     m.part_d = L.part_d;
     m.part_i = L.part_i;
     m.G = grid;
-    m.nq_stride = 32;
     m.kin = kcap;
-    m.nq = B;
+    m.nq = nb * B;
     m.kout = k1;
     m.out_d = out_d;
     m.out_i = out_i;
     m.flags = flags;
-    HIPCHK(vs::launch_merge(m, s));
+    m.q_group_out = B;
+    m.q_group_in = vs::kMaxBatch;
+    HIPCHK(vs::launch_merge_layout(m, kcap, (int64_t)vs::kSlotStride * kcap, s));
     return VS_OK;
 }
 
-// nb batches of B queries: batch i runs on lane i % n_lanes; fork from / join into the caller's stream.
+int bf_batch_dev(vs_index* h, vs_index::Lane& L, const float* q_dev, int B, int k1, float* out_d, int32_t* out_i,
+                 int32_t* flags, hipStream_t s) {
+    return bf_launch(h, L, q_dev, 1, B, k1, out_d, out_i, flags, s);
+}
+
+// nb batches of B queries: chunks of kMaxMulti batches per persistent launch, on the caller's stream.
 int bf_multi_dev(vs_index* h, const float* q_dev, int nb, int B, int k1, float* out_d, int32_t* out_i, int32_t* flags,
                  hipStream_t user) {
-    const int nl = std::min(h->n_lanes, nb);
-    HIPCHK(hipEventRecord(h->fork, user));
-    for (int l = 0; l < nl; ++l) HIPCHK(hipStreamWaitEvent(h->lane[l].s, h->fork, 0));
-    for (int i = 0; i < nb; ++i) {
-        vs_index::Lane& L = h->lane[i % nl];
-        int rc = bf_batch_dev(h, L, q_dev + (size_t)i * B * vs::kDim, B, k1, out_d + (size_t)i * B * k1,
-                              out_i + (size_t)i * B * k1, flags ? flags + (size_t)i * B : h->d_flags, L.s);
+    for (int b0 = 0; b0 < nb; b0 += kMaxMulti) {
+        const int n = std::min(kMaxMulti, nb - b0);
+        int rc = bf_launch(h, h->lane[0], q_dev + (size_t)b0 * B * vs::kDim, n, B, k1, out_d + (size_t)b0 * B * k1,
+                           out_i + (size_t)b0 * B * k1, flags ? flags + (size_t)b0 * B : nullptr, user);
         if (rc) return rc;
-    }
-    for (int l = 0; l < nl; ++l) {
-        HIPCHK(hipEventRecord(h->lane[l].done, h->lane[l].s));
-        HIPCHK(hipStreamWaitEvent(user, h->lane[l].done, 0));
     }
     return VS_OK;
 }
@@ -329,6 +333,7 @@ int scores_dev(vs_index* h, const float* vecs, const float* norms, int64_t rows,
     p.q = q_dev;
     p.metric = h->metric;
     p.nq_valid = B;
+    p.n_batches = 1;
     p.row_begin = 0;
     p.row_end = rows;
     int grid, tp;

@@ -17,10 +17,11 @@ enum ScanMode { kModeTopK = 0, kModeStore = 1 };
 struct ScanParams {
     const float* base;       // [n_rows][128] row-major (the flat fvecs payload, cpu_baseline.cpp:48-49)
     const float* bnorm;      // [n_rows (+16 pad)] squared norms (cpu_baseline.cpp:116-125)
-    const float* q;          // [nq_valid][128] raw queries; rows up to 32 are zero-padded in-kernel (main.cpp:206-211)
-    float* slots_cur;        // [32][kSlotStride] per-workgroup minima of this launch (pre-set to +inf) or nullptr = no exchange
-    float* slots_next;       // [32][kSlotStride] reset to +inf for the next launch, or nullptr
-    int k1;                  // the exchange bounds the k1-th best distance
+    const float* q;          // [n_batches][nq_valid][128] raw queries; rows up to 32 are zero-padded in-kernel (main.cpp:206-211)
+    int n_batches;           // query batches served by this one persistent launch (1 for kModeStore)
+    int64_t q_batch_stride;  // floats between consecutive batches in q
+    float* slots_cur;        // [n_batches][32][kSlotStride] per-workgroup minima (pre-set to +inf) or nullptr = no exchange
+    int k1;                  // the exchange bounds the k1-th best distance; also entries kept per partial list
     int* dbg;                // optional debug counters [grid][16]
     int xchg_first_it;       // first loop iteration (2 tiles per wave each) at which the exchange is attempted
     int64_t row_begin;       // multiple of 16
@@ -29,8 +30,8 @@ struct ScanParams {
     int metric;              // 0 = L2, 1 = IP (scores negated so that smallest wins)
     int32_t id_offset;       // added to the row number
     int nq_valid;            // queries beyond this are padding
-    // kModeTopK outputs: per-workgroup sorted partial lists
-    float* part_d;           // [grid][32][KCAP]
+    // kModeTopK outputs: per-workgroup sorted partial lists, query-major (ranked by merge_compact_kernel)
+    float* part_d;           // [n_batches][32][kSlotStride][KCAP]
     int32_t* part_i;
     // kModeStore output
     float* store;            // [nq_valid][store_ld], column = row - row_begin
@@ -54,6 +55,7 @@ struct MergeParams {
     int32_t* flags;          // [nq] or nullptr: adjacent equal distances among the first kout
     float* tau_out;          // [32] or nullptr: nextafter(kout-th best) used as scan seed
     const int32_t* id_map;   // optional: out id = id_map[id] (IVF reorder_to_original)
+    int q_group_out, q_group_in;  // output query q reads input query (q / out) * in + q % out (0 = identity)
 };
 hipError_t launch_merge(const MergeParams& p, hipStream_t s);  // scan-partial layout [G][nq_stride][kin]
 // general layout: entry (g, q, j) at g*stride_g + q*stride_q + j

@@ -104,6 +104,51 @@ __device__ __forceinline__ float wave_kth_smallest(float a0, float a1, float a2,
     return res;
 }
 
+// kout rounds of wave-wide (dist, id) argmin over M <= 64*EPL candidates parked in LDS (cd/ci);
+// lane-local candidates live in registers, the reduction is DPP only.  Writes kout (dist, id)
+// pairs (padded with +inf / -1) and, if flag != nullptr, whether two emitted distances are equal.
+template <int EPL>
+__device__ __forceinline__ void wave_rank_emit(const float* cd, const int* ci, int M, int kout, float* out_d,
+                                               int32_t* out_i, int32_t* flag, const int32_t* id_map, int lane) {
+    float d[EPL];
+    int id[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        const int idx = e * 64 + lane;
+        d[e] = idx < M ? cd[idx] : VS_INF;
+        id[e] = idx < M ? ci[idx] : 0x7fffffff;
+    }
+    float prev = VS_INF;
+    int tie = 0;
+    for (int round = 0; round < kout; ++round) {
+        float md = d[0];
+        int mi = id[0];
+#pragma unroll
+        for (int e = 1; e < EPL; ++e)
+            if (lex_lt(d[e], id[e], md, mi)) {
+                md = d[e];
+                mi = id[e];
+            }
+        float bd;
+        int bi;
+        wave_lexmin(md, mi, bd, bi);
+        const bool none = bi == 0x7fffffff;
+        if (!none && round > 0 && bd == prev) tie = 1;
+        prev = none ? VS_INF : bd;
+        if (lane == 0) {
+            if (out_d) out_d[round] = none ? VS_INF : bd;
+            if (out_i) out_i[round] = none ? -1 : (id_map ? id_map[bi] : bi);
+        }
+#pragma unroll
+        for (int e = 0; e < EPL; ++e)
+            if (id[e] == bi && d[e] == bd) {
+                d[e] = VS_INF;
+                id[e] = 0x7fffffff;
+            }
+    }
+    if (flag && lane == 0) *flag = tie;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Brute-force scan: Q[<=32 x 128] x base^T on v_mfma_f32_16x16x4_f32, L2 epilogue and top-k fused.
 //
@@ -163,19 +208,36 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams 
     int* lds_flag = reinterpret_cast<int*>(lds_wmin + kScanWaves * 32); // [1]
     int* lds_cnt = lds_flag + 4;                                        // [32]
     int* lds_ticket = lds_cnt + 32;                                     // [1]
-    const int lane = threadIdx.x & 63;
+    const int lane0 = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably wave-uniform
-    const int r = lane & 15;
-    const int g = lane >> 4;
     VS_STAMP(0);
 
     const int64_t n_rows = p.row_end - p.row_begin;
     const int tiles_total = (int)((n_rows + kTileRows - 1) / kTileRows);
-    const int tile0 = blockIdx.x * p.tiles_per_wg;
-    const int tile1 = min(tile0 + p.tiles_per_wg, tiles_total);
+    // Tiles are dealt round-robin over the workgroups (ticket n of workgroup b is tile b + n*G): while
+    // the workgroups run in lock-step (start of every batch) they then read CONSECUTIVE tiles, which
+    // spread over all HBM channels.  Contiguous per-workgroup chunks put every workgroup on the same
+    // few channels at those moments (chunk stride = 245 tiles aliases 4-way at SIFT-1M).
+    const int tile0 = blockIdx.x;
+    const int tile_step = gridDim.x;
+    const int tile1 = tiles_total;
     const int64_t last_row = p.row_end - 1;
-    const int tlast = max(tile1 - 1, 0);
+    const int tlast = max(tiles_total - 1, 0);
 
+    // One persistent launch serves n_batches query batches back to back.  Workgroups are never
+    // synchronised with each other, so they drift apart and one workgroup's latency-bound batch
+    // start-up (query staging, first tiles, exchange) overlaps the others' streaming: HBM stays busy.
+#pragma clang loop unroll(disable)
+    for (int batch = 0; batch < p.n_batches; ++batch) {
+    // Lane-derived values are re-derived per batch from an opaque copy: otherwise hipcc hoists dozens
+    // of address registers out of the batch loop, they stay live across everything and the kernel
+    // falls off its 256-VGPR budget into scratch.
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const int r = lane & 15;
+    const int g = lane >> 4;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
     char* ring = smem + wave * (kDepth * kSlotBytes);
     // DMA source mapping: piece j (0..7) writes LDS chunks [64 j, 64 j + 64) of the slot; lane l
     // lands at row 2 j + (l >> 5), stored chunk (l & 31)  <-  source chunk (l & 31) ^ row
@@ -208,6 +270,8 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams 
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     };
+    const float* qb = p.q + (int64_t)batch * p.q_batch_stride;
+    float* slots = p.slots_cur ? p.slots_cur + (int64_t)batch * 32 * kSlotStride : nullptr;
     // queries -> LDS by DMA as well (2 pieces per wave): chunk c of row q lands at chunk c ^ (q & 15);
     // rows >= nq_valid read row 0 and are zeroed when used (main.cpp:206-211 zero padding)
 #pragma unroll
@@ -215,23 +279,21 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams 
         const int j = 2 * wave + u;
         const int row = 2 * j + (lane >> 5);
         const int c4 = lane & 31;
-        const float* src = p.q + (row < p.nq_valid ? row : 0) * kDim + 4 * (c4 ^ (row & 15));
+        const float* src = qb + (row < p.nq_valid ? row : 0) * kDim + 4 * (c4 ^ (row & 15));
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(q_s) + j * 1024),
                                          16, 0, 0);
     }
-    int t_a = tile0 + wave, t_b = tile0 + wave + kScanWaves;
+    int t_a = tile0 + wave * tile_step, t_b = tile0 + (wave + kScanWaves) * tile_step;
     issue_tile(min(t_a, tlast), 0);
     issue_tile(min(t_b, tlast), 1);
-    if (threadIdx.x == 0) lds_ticket[0] = 2 * kScanWaves;
-    if (threadIdx.x < 32) lds_cnt[threadIdx.x] = 0;
-    if (MODE == kModeTopK && p.slots_next && threadIdx.x >= 64 && threadIdx.x < 96)  // wave 1: keeps wave 0's queue short
-        p.slots_next[(threadIdx.x - 64) * kSlotStride + blockIdx.x] = VS_INF;  // reset the other parity for the next launch
-    asm volatile("s_waitcnt vmcnt(18)" ::: "memory");  // the two query pieces have landed (2 tiles + maybe a store follow)
+    if (tid == 0) lds_ticket[0] = 2 * kScanWaves;
+    if (tid < 32) lds_cnt[tid] = 0;
+    asm volatile("s_waitcnt vmcnt(18)" ::: "memory");  // the two query pieces have landed (two tiles follow)
     lds_barrier();
     // squared norms in the reference's AVX2 order (8 FMA lanes, then r0+...+r7): threads 0..255
-    if (threadIdx.x < 256) {
-        const int row = threadIdx.x >> 3, j = threadIdx.x & 7;
+    if (tid < 256) {
+        const int row = tid >> 3, j = tid & 7;
         float acc = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -331,10 +393,10 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams 
     auto next_ticket = [&]() -> int {
         int tk = 0;
         if (lane == 0) tk = atomicAdd(&lds_ticket[0], 1);
-        return tile0 + __builtin_amdgcn_readfirstlane(tk);
+        return tile0 + __builtin_amdgcn_readfirstlane(tk) * tile_step;
     };
 
-    const bool exchange = MODE == kModeTopK && p.slots_cur != nullptr;
+    const bool exchange = MODE == kModeTopK && slots != nullptr;
     int t_cur = t_a, t_nxt = t_b, slot = 0;
     if (exchange) {
         // ---- warm-up: three tiles per wave whose distances are only kept (no top-k work yet) ----
@@ -348,7 +410,9 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams 
             }
         };
         asm volatile("s_waitcnt vmcnt(9)" ::: "memory");  // A landed (B follows)
+        VS_STAMP(11);
         tile_distances(min(t_a, tlast), 0, w0);
+        VS_STAMP(12);
         kill(t_a >= tile1, w0);
         const int t_c = next_ticket();
         issue_tile(min(t_c, tlast), 0);  // queue: B C
@@ -361,24 +425,24 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams 
             if (g == 0) lds_wmin[wave * 32 + h * 16 + r] = m;
         }
         lds_barrier();
-        if (threadIdx.x >= 64 && threadIdx.x < 64 + NQH * 16) {  // wave 1 publishes (one extra op in its queue)
-            const int qx = threadIdx.x - 64;
+        if (tid >= 64 && tid < 64 + NQH * 16) {  // wave 1 publishes (one extra op in its queue)
+            const int qx = tid - 64;
             float m = lds_wmin[qx];
 #pragma unroll
             for (int w = 1; w < kScanWaves; ++w) m = fminf(m, lds_wmin[w * 32 + qx]);
-            __hip_atomic_store(p.slots_cur + qx * kSlotStride + blockIdx.x, m, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(slots + qx * kSlotStride + blockIdx.x, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         VS_STAMP(2);
         asm volatile("s_waitcnt vmcnt(9)" ::: "memory");  // B landed (C, and on wave 1 the store, follow)
         tile_distances(min(t_b, tlast), 1, w1);
         kill(t_b >= tile1, w1);
+        VS_STAMP(7);
         // DPP row `g` of wave w will reduce query 4w+g: its 16 lanes read that query's 1 KB row of
         // minima (write-through-coherent sc1 loads, 64 contiguous bytes per lane = workgroups
         // 16 l .. 16 l + 15).  Issued now, consumed after the next tile.
         f32x4 v0, v1, v2, v3;
         {
-            const float* s0 = p.slots_cur + (4 * wave + g) * kSlotStride + 16 * r;
+            const float* s0 = slots + (4 * wave + g) * kSlotStride + 16 * r;
             asm volatile(
                 "global_load_dwordx4 %0, %4, off sc1\n\t"
                 "global_load_dwordx4 %1, %4, off offset:16 sc1\n\t"
@@ -391,11 +455,14 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams 
         const int t_d = next_ticket();
         issue_tile(min(t_d, tlast), 1);  // queue: C loads(4) D
         asm volatile("s_waitcnt vmcnt(13)" ::: "memory");  // C landed
+        VS_STAMP(9);
         tile_distances(min(t_c, tlast), 0, w2);
         kill(t_c >= tile1, w2);
+        VS_STAMP(8);
         const int t_e = next_ticket();
         issue_tile(min(t_e, tlast), 0);  // queue: loads(4) D E
         asm volatile("s_waitcnt vmcnt(18)" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3)::"memory");  // the minima are here
+        VS_STAMP(10);
         {
             // Each lane folds its 16 workgroups into one minimum; the k1-th smallest of the row's
             // 16 lane minima is still backed by k1 distinct rows (one per lane group), and with
@@ -475,8 +542,9 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams 
             cd[e] = idx < M ? cand_d[qq * CAP + idx] : VS_INF;
             ci[e] = idx < M ? cand_i[qq * CAP + idx] : 0x7fffffff;
         }
-        float* od = p.part_d + ((int64_t)blockIdx.x * kMaxBatch + qq) * KCAP;
-        int32_t* oi = p.part_i + ((int64_t)blockIdx.x * kMaxBatch + qq) * KCAP;
+        // partial lists are query-major: [batch][query][workgroup][KCAP] (one merge launch ranks all batches)
+        float* od = p.part_d + (((int64_t)batch * kMaxBatch + qq) * kSlotStride + blockIdx.x) * KCAP;
+        int32_t* oi = p.part_i + (((int64_t)batch * kMaxBatch + qq) * kSlotStride + blockIdx.x) * KCAP;
         const int rounds = min(min(p.k1, KCAP), M);
         for (int round = 0; round < rounds; ++round) {
             float md = cd[0];
@@ -506,6 +574,8 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams 
             oi[lane] = -1;
         }
     }
+    __syncthreads();  // LDS (ring, counters, ticket, query stage) is reused by the next batch
+    }  // batch loop
     VS_STAMP(6);
 }
 
@@ -704,13 +774,14 @@ __global__ __launch_bounds__(256) void merge_compact_kernel(const MergeParams p,
     __shared__ int wbi[4];
     __shared__ int wbp[4];
     __shared__ float outd[kMergeTrack];
-    const int q = blockIdx.x;
+    const int q = blockIdx.x;  // output query; input lists may be grouped in padded batches
+    const int q_in = p.q_group_out > 0 ? (q / p.q_group_out) * p.q_group_in + (q % p.q_group_out) : q;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     if (tid == 0) cnt = 0;
     __syncthreads();
     for (int g = tid; g < p.G; g += 256) {
-        const int64_t off = (int64_t)g * L.stride_g + (int64_t)q * L.stride_q;
+        const int64_t off = (int64_t)g * L.stride_g + (int64_t)q_in * L.stride_q;
         for (int j = 0; j < p.kin; ++j) {
             const float d = p.part_d[off + j];
             const int id = p.part_i ? p.part_i[off + j] : (g * p.kin + j);
