@@ -99,6 +99,22 @@ struct vs_index {
     float* d_ipart_d = nullptr;  // [32][kMaxNprobe][16]
     int32_t* d_ipart_i = nullptr;
     unsigned long long* d_cand = nullptr;
+    // list-major IVF scan (grouped path)
+    int32_t* d_chunk_list = nullptr;   // [n_chunks] (list, 1024-row chunk) work items over the resident lists
+    int32_t* d_chunk_row0 = nullptr;
+    int32_t* d_chunk_rows = nullptr;
+    int n_chunks = 0;
+    int32_t max_list = 0;              // longest resident list
+    int32_t* d_lcnt = nullptr;         // [nlist]
+    int32_t* d_lq = nullptr;           // [nlist][32]
+    long long* d_lbase = nullptr;      // [nlist][32]
+    int32_t* d_qoff = nullptr;         // [32][257]
+    unsigned* d_bins = nullptr;        // [32][16]
+    float* d_gcand_d = nullptr;        // [32][4096]
+    int32_t* d_gcand_p = nullptr;
+    int32_t* d_gsel = nullptr;         // [3][32]: gcnt, gdone, govf
+    float* d_candbuf = nullptr;        // [32][cand_stride]
+    long long cand_stride = 0;
     int max_grid = 0;
 
     hipStream_t stream = nullptr;
@@ -133,7 +149,9 @@ void free_all(vs_index* h) {
     if (h->fork) (void)hipEventDestroy(h->fork);
     void* ptrs[] = {h->d_vecs, h->d_norm, h->d_centroids, h->d_cnorm, h->d_offsets, h->d_r2o, h->d_q,
                     h->d_out_d, h->d_out_i,
-                    h->d_flags, h->d_scores, h->d_probes, h->d_ipart_d, h->d_ipart_i, h->d_cand};
+                    h->d_flags, h->d_scores, h->d_probes, h->d_ipart_d, h->d_ipart_i, h->d_cand,
+                    h->d_chunk_list, h->d_chunk_row0, h->d_chunk_rows, h->d_lcnt, h->d_lq, h->d_lbase, h->d_qoff,
+                    h->d_candbuf, h->d_gcand_d, h->d_gcand_p};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& ps : h->prof_slot)
@@ -175,7 +193,7 @@ int alloc_scratch(vs_index* h) {
     int tp;
     scan_geometry(std::max<int64_t>(h->n_rows, 1), h->num_cus, h->max_grid, tp);
     h->max_grid = std::max(h->max_grid, h->num_cus);
-    if ((rc = dev_alloc(&h->d_q, 32 * vs::kDim))) return rc;
+    if ((rc = dev_alloc(&h->d_q, (size_t)kMaxMulti * 32 * vs::kDim))) return rc;
     {
         const char* e = getenv("VSEARCH_LANES");
         h->n_lanes = e ? std::max(1, std::min(kMaxLanes, atoi(e))) : 1;
@@ -194,9 +212,9 @@ int alloc_scratch(vs_index* h) {
         }
         HIPCHK(hipEventCreateWithFlags(&h->fork, hipEventDisableTiming));
     }
-    if ((rc = dev_alloc(&h->d_out_d, 32 * 64))) return rc;
-    if ((rc = dev_alloc(&h->d_out_i, 32 * 64))) return rc;
-    if ((rc = dev_alloc(&h->d_flags, 32))) return rc;
+    if ((rc = dev_alloc(&h->d_out_d, (size_t)kMaxMulti * 32 * 64))) return rc;
+    if ((rc = dev_alloc(&h->d_out_i, (size_t)kMaxMulti * 32 * 64))) return rc;
+    if ((rc = dev_alloc(&h->d_flags, (size_t)kMaxMulti * 32))) return rc;
     if (h->kind == 1) {
         h->scores_cap = (int64_t)32 * ((h->nlist + 15) & ~15);
         if ((rc = dev_alloc(&h->d_scores, (size_t)h->scores_cap))) return rc;
@@ -204,6 +222,16 @@ int alloc_scratch(vs_index* h) {
         if ((rc = dev_alloc(&h->d_ipart_d, (size_t)32 * kMaxNprobe * kKcapMax))) return rc;
         if ((rc = dev_alloc(&h->d_ipart_i, (size_t)32 * kMaxNprobe * kKcapMax))) return rc;
         if ((rc = dev_alloc(&h->d_cand, 1))) return rc;
+        // one zero-filled block per batch: [lcnt nlist][gsel 96][bins 512]
+        if ((rc = dev_alloc(&h->d_lcnt, (size_t)h->nlist + 96 + 512))) return rc;
+        h->d_gsel = h->d_lcnt + h->nlist;
+        h->d_bins = reinterpret_cast<unsigned*>(h->d_lcnt + h->nlist + 96);
+        if ((rc = dev_alloc(&h->d_lq, (size_t)h->nlist * 32))) return rc;
+        if ((rc = dev_alloc(&h->d_lbase, (size_t)h->nlist * 32))) return rc;
+        if ((rc = dev_alloc(&h->d_qoff, (size_t)32 * (vs::kIvfMaxProbe + 1)))) return rc;
+        if ((rc = dev_alloc(&h->d_gcand_d, (size_t)32 * 4096))) return rc;
+        if ((rc = dev_alloc(&h->d_gcand_p, (size_t)32 * 4096))) return rc;
+
     }
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     return VS_OK;
@@ -345,6 +373,12 @@ int scores_dev(vs_index* h, const float* vecs, const float* norms, int64_t rows,
     return VS_OK;
 }
 
+// tuning knob (VSEARCH_IVF_GROUPED=0): fall back to the (query, probe)-major scan
+int g_ivf_grouped = [] {
+    const char* e = getenv("VSEARCH_IVF_GROUPED");
+    return e ? atoi(e) : 1;
+}();
+
 int ivf_batch_dev(vs_index* h, const float* q_dev, int B, int k, int nprobe, float* out_d, int32_t* out_i,
                   hipStream_t s, double* t_marks /*optional host marks*/) {
     (void)t_marks;
@@ -354,11 +388,76 @@ int ivf_batch_dev(vs_index* h, const float* q_dev, int B, int k, int nprobe, flo
         return VS_ERR_UNSUPPORTED;
     }
     const int64_t ld = (h->nlist + 15) & ~15;
-    // coarse: Q x C^T + ||c||^2 epilogue on the MFMA scan kernel (IVFIndex.cpp:654-666)
-    int rc = scores_dev(h, h->d_centroids, h->d_cnorm, h->nlist, q_dev, B, h->d_scores, ld, s);
-    if (rc) return rc;
-    // top-nprobe (IVFIndex.cpp:711), deterministic ascending (dist, id)
-    HIPCHK(vs::launch_pick_probes(h->d_scores, ld, B, h->nlist, nprobe, h->d_probes, s));
+    const bool grouped = g_ivf_grouped && h->nlist <= 2048 && h->n_chunks > 0;
+    vs::IvfGroup grp{};
+    if (grouped) {
+        // candidate-score array: a query's probed lists back to back
+        const long long need = std::min<long long>(h->n_rows, (long long)nprobe * h->max_list);
+        const long long stride = (need + 63) & ~63ll;
+        if (h->cand_stride < stride) {
+            HIPCHK(hipStreamSynchronize(s));
+            if (h->d_candbuf) (void)hipFree(h->d_candbuf);
+            h->d_candbuf = nullptr;
+            h->cand_stride = 0;
+            int rc = dev_alloc(&h->d_candbuf, (size_t)32 * stride);
+            if (rc) return rc;
+            h->cand_stride = stride;
+        }
+        HIPCHK(hipMemsetAsync(h->d_lcnt, 0, ((size_t)h->nlist + 96 + 512) * sizeof(int32_t), s));
+        grp.offsets = h->d_offsets;
+        grp.lcnt = h->d_lcnt;
+        grp.lq = h->d_lq;
+        grp.lbase = h->d_lbase;
+        grp.qoff = h->d_qoff;
+        grp.cand_stride = h->cand_stride;
+        grp.cand_count = h->d_cand;
+    }
+    if (h->nlist <= 2048) {
+        // coarse scores + deterministic top-nprobe (+ grouping tables) in one launch (IVFIndex.cpp:654-666, :697-723)
+        HIPCHK(vs::launch_ivf_coarse_pick(q_dev, B, h->d_centroids, h->d_cnorm, h->nlist, nprobe, h->metric, h->d_probes, grp, s));
+    } else {
+        // large nlist: Q x C^T + ||c||^2 epilogue on the MFMA scan kernel, then a selection launch
+        int rc = scores_dev(h, h->d_centroids, h->d_cnorm, h->nlist, q_dev, B, h->d_scores, ld, s);
+        if (rc) return rc;
+        HIPCHK(vs::launch_pick_probes(h->d_scores, ld, B, h->nlist, nprobe, h->d_probes, s));
+    }
+    if (grouped) {
+        vs::IvfListScanParams lp{};
+        lp.vecs = h->d_vecs;
+        lp.vnorm = h->d_norm;
+        lp.offsets = h->d_offsets;
+        lp.chunk_list = h->d_chunk_list;
+        lp.chunk_row0 = h->d_chunk_row0;
+        lp.chunk_rows = h->d_chunk_rows;
+        lp.q = q_dev;
+        lp.lcnt = h->d_lcnt;
+        lp.lq = h->d_lq;
+        lp.lbase = h->d_lbase;
+        lp.cand = h->d_candbuf;
+        lp.metric = h->metric;
+        prof_begin(h, 1, s);
+        HIPCHK(vs::launch_ivf_list_scan(lp, h->n_chunks, s));
+        prof_end(h, 1, s);
+        vs::IvfSelectParams sp{};
+        sp.cand = h->d_candbuf;
+        sp.cand_stride = h->cand_stride;
+        sp.qoff = h->d_qoff;
+        sp.probes = h->d_probes;
+        sp.offsets = h->d_offsets;
+        sp.id_map = h->d_r2o;
+        sp.tq = h->d_bins;
+        sp.gcand_d = h->d_gcand_d;
+        sp.gcand_p = h->d_gcand_p;
+        sp.gcnt = h->d_gsel;
+        sp.gdone = h->d_gsel + 32;
+        sp.govf = h->d_gsel + 64;
+        sp.nprobe = nprobe;
+        sp.k = k;
+        sp.out_d = out_d;
+        sp.out_i = out_i;
+        HIPCHK(vs::launch_ivf_select(sp, B, s));
+        return VS_OK;
+    }
     vs::IvfScanParams ip{};
     ip.vecs = h->d_vecs;
     ip.vnorm = h->d_norm;
@@ -530,26 +629,38 @@ int vs_bf_search(vs_index* h, const float* queries_host, int64_t nq, int k, int3
         set_error("k too large for the compiled scan kernels (k <= 15)");
         return VS_ERR_UNSUPPORTED;
     }
-    std::vector<float> hd((size_t)32 * k1);
-    std::vector<int32_t> hi((size_t)32 * k1), hf(32);
+    // Queries go up in chunks of kMaxMulti batches: one persistent scan launch + one merge launch per
+    // chunk (the harness loop of main.cpp:201-251 collapsed into a call); a ragged tail batch gets its own.
+    const int64_t chunk = (int64_t)kMaxMulti * h->batch;
+    std::vector<float> hd((size_t)chunk * k1);
+    std::vector<int32_t> hi((size_t)chunk * k1), hf((size_t)chunk);
     std::vector<int64_t> flagged;
     const float inf = std::numeric_limits<float>::infinity();
-    for (int64_t q0 = 0; q0 < nq; q0 += h->batch) {
-        const int B = (int)std::min<int64_t>(h->batch, nq - q0);
+    for (int64_t q0 = 0; q0 < nq; q0 += chunk) {
+        const int64_t n = std::min<int64_t>(chunk, nq - q0);
+        const int full = (int)(n / h->batch), rem = (int)(n % h->batch);
         double t0 = now_ms();
-        HIPCHK(hipMemcpyAsync(h->d_q, queries_host + q0 * vs::kDim, (size_t)B * vs::kDim * sizeof(float),
+        HIPCHK(hipMemcpyAsync(h->d_q, queries_host + q0 * vs::kDim, (size_t)n * vs::kDim * sizeof(float),
                               hipMemcpyHostToDevice, h->stream));
         double t1 = now_ms();
-        rc = bf_batch_dev(h, h->lane[0], h->d_q, B, k1, h->d_out_d, h->d_out_i, h->d_flags, h->stream);
-        if (rc) return rc;
-        HIPCHK(hipMemcpyAsync(hd.data(), h->d_out_d, (size_t)B * k1 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipMemcpyAsync(hi.data(), h->d_out_i, (size_t)B * k1 * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipMemcpyAsync(hf.data(), h->d_flags, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+        if (full) {
+            rc = bf_launch(h, h->lane[0], h->d_q, full, h->batch, k1, h->d_out_d, h->d_out_i, h->d_flags, h->stream);
+            if (rc) return rc;
+        }
+        if (rem) {
+            const size_t o = (size_t)full * h->batch;
+            rc = bf_launch(h, h->lane[0], h->d_q + o * vs::kDim, 1, rem, k1, h->d_out_d + o * k1, h->d_out_i + o * k1,
+                           h->d_flags + o, h->stream);
+            if (rc) return rc;
+        }
+        HIPCHK(hipMemcpyAsync(hd.data(), h->d_out_d, (size_t)n * k1 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(hi.data(), h->d_out_i, (size_t)n * k1 * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(hf.data(), h->d_flags, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
         double t2 = now_ms();
         tm.h2d_ms += t1 - t0;
         tm.fine_search_ms += t2 - t1;
-        for (int b = 0; b < B; ++b) {
+        for (int64_t b = 0; b < n; ++b) {
             for (int t = 0; t < k; ++t) {
                 const int32_t id = hi[(size_t)b * k1 + t];
                 ids[(q0 + b) * k + t] = id;
@@ -557,7 +668,7 @@ int vs_bf_search(vs_index* h, const float* queries_host, int64_t nq, int k, int3
                 if (h->metric == VS_METRIC_IP && id >= 0) d = -d;
                 dists[(q0 + b) * k + t] = d;
             }
-            if (hf[b]) flagged.push_back(q0 + b);
+            if (hf[(size_t)b]) flagged.push_back(q0 + b);
         }
     }
     // Ties inside the k+1 best: the reference's order is history dependent (cpu_baseline.cpp:127-153),
@@ -691,6 +802,33 @@ static int ivf_create_impl(const float* vectors, int64_t n_rows, int dim, const 
         (e = hipDeviceSynchronize()) != hipSuccess) {
         set_error(std::string("ivf upload: ") + hipGetErrorString(e));
         return fail(VS_ERR_DEVICE);
+    }
+    {
+        // (list, 1024-row chunk) work items of the list-major scan, resident lists only
+        std::vector<int32_t> cl, cr0, crn;
+        int32_t mx = 0;
+        for (int c = 0; c < nlist; ++c) {
+            const int32_t n = loc_off[c + 1] - loc_off[c];
+            mx = std::max(mx, n);
+            for (int32_t r = 0; r < n; r += 1024) {
+                cl.push_back(c);
+                cr0.push_back(loc_off[c] + r);
+                crn.push_back(std::min<int32_t>(1024, n - r));
+            }
+        }
+        h->n_chunks = (int)cl.size();
+        h->max_list = mx;
+        if (h->n_chunks > 0) {
+            if ((rc = dev_alloc(&h->d_chunk_list, cl.size()))) return fail(rc);
+            if ((rc = dev_alloc(&h->d_chunk_row0, cl.size()))) return fail(rc);
+            if ((rc = dev_alloc(&h->d_chunk_rows, cl.size()))) return fail(rc);
+            if ((e = hipMemcpy(h->d_chunk_list, cl.data(), cl.size() * 4, hipMemcpyHostToDevice)) != hipSuccess ||
+                (e = hipMemcpy(h->d_chunk_row0, cr0.data(), cl.size() * 4, hipMemcpyHostToDevice)) != hipSuccess ||
+                (e = hipMemcpy(h->d_chunk_rows, crn.data(), cl.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) {
+                set_error(std::string("ivf chunk table: ") + hipGetErrorString(e));
+                return fail(VS_ERR_DEVICE);
+            }
+        }
     }
     if ((rc = alloc_scratch(h))) return fail(rc);
     *out = h;

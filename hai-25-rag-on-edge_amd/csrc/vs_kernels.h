@@ -69,6 +69,58 @@ hipError_t launch_row_sqnorm(const float* v, int64_t rows, int dim, float* out, 
 hipError_t launch_pick_probes(const float* scores, int64_t ld, int B, int nlist, int nprobe,
                               int32_t* probes /*[B][nprobe]*/, hipStream_t s);
 
+constexpr int kIvfMaxProbe = 256;
+
+// Grouping tables of the list-major IVF scan, filled by the coarse/pick kernel (all optional: lcnt == nullptr = off)
+struct IvfGroup {
+    const int32_t* offsets;          // [nlist+1] local list offsets
+    int32_t* lcnt;                   // [nlist] queries probing each list in this batch (pre-set to 0)
+    int32_t* lq;                     // [nlist][32] their query indices
+    long long* lbase;                // [nlist][32] where that (query, probe) window starts in the candidate array
+    int32_t* qoff;                   // [B][kIvfMaxProbe+1] window offsets per query, probe order; last = total
+    long long cand_stride;           // floats per query in the candidate array
+    unsigned long long* cand_count;  // += rows scanned (IVFIndex::searchBatch return value)
+};
+
+// Coarse L2 scores against the centroids + the nprobe nearest lists per query, one launch (nlist <= 2048).
+hipError_t launch_ivf_coarse_pick(const float* q, int B, const float* cents, const float* cnorm, int nlist, int nprobe,
+                                  int metric, int32_t* probes, const IvfGroup& grp, hipStream_t s);
+
+struct IvfListScanParams {
+    const float* vecs;        // [n_rows][128] cluster-reordered
+    const float* vnorm;       // [n_rows]
+    const int32_t* offsets;   // [nlist+1]
+    const int32_t* chunk_list;  // [n_chunks] list of each (list, 1024-row chunk) work item
+    const int32_t* chunk_row0;  // [n_chunks] first row (absolute, local array)
+    const int32_t* chunk_rows;  // [n_chunks] rows in the chunk
+    const float* q;           // [B][128]
+    const int32_t* lcnt;
+    const int32_t* lq;
+    const long long* lbase;
+    float* cand;              // [B][cand_stride] candidate scores, probe order
+    int metric;
+};
+hipError_t launch_ivf_list_scan(const IvfListScanParams& p, int n_chunks, hipStream_t s);
+
+struct IvfSelectParams {
+    const float* cand;
+    long long cand_stride;
+    const int32_t* qoff;      // [B][kIvfMaxProbe+1]
+    const int32_t* probes;    // [B][nprobe]
+    const int32_t* offsets;   // [nlist+1]
+    const int32_t* id_map;    // reorder_to_original (local)
+    unsigned* tq;             // [B] complemented ordered-float bound per query (pre-set to 0)
+    float* gcand_d;           // [B][4096] gathered candidates under the bound
+    int32_t* gcand_p;
+    int32_t* gcnt;            // [B] (pre-set to 0)
+    int32_t* gdone;           // [B] arrival counters (pre-set to 0)
+    int32_t* govf;            // [B] overflow flags (pre-set to 0)
+    int nprobe, k;
+    float* out_d;             // [B][k]
+    int32_t* out_i;
+};
+hipError_t launch_ivf_select(const IvfSelectParams& p, int B, hipStream_t s);
+
 struct IvfScanParams {
     const float* vecs;        // [n_rows][128] cluster-reordered (vectors_reordered.npy)
     const float* vnorm;       // [n_rows]

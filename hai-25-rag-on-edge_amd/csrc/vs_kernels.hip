@@ -1000,6 +1000,175 @@ hipError_t launch_row_sqnorm(const float* v, int64_t rows, int dim, float* out, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// IVF coarse stage + probe selection in one launch (IVFIndex.cpp:654-666 centroid scores, :697-723
+// top-nprobe): one 256-thread workgroup per query.  Distances to all centroids with the same
+// 8-lanes-per-row dot product as the list scan (centroids are L2 resident), then selection without
+// sorting rounds: the nprobe-th smallest of the 256 per-thread minima bounds the answer, the few
+// scores under that bound are compacted and ranked by counting (every candidate counts how many
+// others precede it in (dist, id) order and writes itself to that slot).  Deterministic.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float dpp_add_xor1(float x);
+__device__ __forceinline__ float dpp_add_xor2(float x);
+__device__ __forceinline__ float dpp_add_half_mirror(float x);
+
+template <int EPT>
+__global__ __launch_bounds__(1024) void ivf_coarse_pick_kernel(const float* __restrict__ q, const float* __restrict__ cents,
+                                                               const float* __restrict__ cnorm, int nlist, int nprobe,
+                                                               int metric, int32_t* __restrict__ probes, const IvfGroup grp) {
+    __shared__ float sc[256 * EPT];
+    __shared__ int s_probe[256];
+    __shared__ int s_off[257];
+    __shared__ float mn_d[256];
+    __shared__ int mn_i[256];
+    __shared__ float cd[256 * EPT];
+    __shared__ int ci[256 * EPT];
+    __shared__ float s_qn, s_td;
+    __shared__ int s_ti, s_cnt;
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;  // 16 waves
+    if (tid < 8) {  // ||q||^2 in the reference's AVX2 order (cpu_baseline.cpp:95-114)
+        float a = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float x = q[b * kDim + 8 * i + tid];
+            a = fmaf(x, x, a);
+        }
+        float sum = __shfl(a, 0);
+#pragma unroll
+        for (int u = 1; u < 8; ++u) sum = sum + __shfl(a, u);
+        if (tid == 0) {
+            s_qn = sum;
+            s_cnt = 0;
+            s_td = VS_INF;
+            s_ti = 0x7fffffff;
+        }
+    }
+    const int rr = lane >> 3, s8 = lane & 7;
+    f32x4 qf[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) qf[m] = *reinterpret_cast<const f32x4*>(q + b * kDim + 4 * (s8 + 8 * m));
+    __syncthreads();
+    const float qn = s_qn;
+    // 16 waves x 8 rows = 128 rows per sweep; four sweeps are loaded together so that the loop pays
+    // two L2 round trips instead of one per sweep
+    constexpr int U = 4;
+    for (int row0 = wave * 8; row0 < nlist; row0 += 128 * U) {
+        f32x4 v[U][4];
+        float cn[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int row = row0 + 128 * u + rr;
+            const int rowc = row < nlist ? row : nlist - 1;
+            const float* src = cents + (int64_t)rowc * kDim + 4 * s8;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) v[u][m] = *reinterpret_cast<const f32x4*>(src + 32 * m);
+            cn[u] = cnorm[rowc];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int row = row0 + 128 * u + rr;
+            float acc = 0.f;
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc = fmaf(v[u][m][i], qf[m][i], acc);
+            acc = dpp_add_xor1(acc);
+            acc = dpp_add_xor2(acc);
+            acc = dpp_add_half_mirror(acc);
+            float d = metric ? -acc : fmaf(-2.0f, acc, qn + cn[u]);
+            if (!(d == d)) d = VS_INF;
+            if (row < nlist && s8 == 0) sc[row] = d;
+        }
+    }
+    __syncthreads();
+    // ---- selection by the first 256 threads (everyone keeps hitting the barriers) ----
+    float md = VS_INF;
+    int mi = 0x7fffffff;
+    float mine[EPT];
+    if (tid < 256) {
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int idx = tid + 256 * e;
+            mine[e] = idx < nlist ? sc[idx] : VS_INF;
+            if (idx < nlist && lex_lt(mine[e], idx, md, mi)) {
+                md = mine[e];
+                mi = idx;
+            }
+        }
+        mn_d[tid] = md;
+        mn_i[tid] = mi;
+    }
+    __syncthreads();
+    if (tid < 256 && nprobe <= 256) {
+        int rank = 0;
+        for (int j = 0; j < 256; ++j) rank += lex_lt(mn_d[j], mn_i[j], md, mi) ? 1 : 0;
+        if (rank == nprobe - 1) {  // unique: the order is strict
+            s_td = md;
+            s_ti = mi;
+        }
+    }
+    __syncthreads();
+    if (tid < 256) {
+        const float td = s_td;
+        const int ti = s_ti;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int idx = tid + 256 * e;
+            if (idx < nlist && !lex_lt(td, ti, mine[e], idx)) {  // (d, idx) <= bound
+                const int pos = atomicAdd(&s_cnt, 1);
+                cd[pos] = mine[e];
+                ci[pos] = idx;
+            }
+        }
+    }
+    __syncthreads();
+    const int C = s_cnt;
+    for (int c = tid; c < C; c += 1024) {
+        const float d = cd[c];
+        const int id = ci[c];
+        int rank = 0;
+        for (int j = 0; j < C; ++j) rank += lex_lt(cd[j], ci[j], d, id) ? 1 : 0;
+        if (rank < nprobe) {
+            probes[(int64_t)b * nprobe + rank] = id;
+            s_probe[rank] = id;
+        }
+    }
+    for (int c = C + tid; c < nprobe; c += 1024) {
+        probes[(int64_t)b * nprobe + c] = -1;
+        s_probe[c] = -1;
+    }
+    if (!grp.lcnt) return;
+    // ---- grouping for the list-major scan: every (query, probe) takes a slot in its list's query set and
+    //      a window [qoff[p], qoff[p+1]) in the query's candidate-score array (probe order) ----
+    __syncthreads();
+    __shared__ int s_sz[256];
+    for (int pp = tid; pp < nprobe; pp += 1024) {
+        const int c = s_probe[pp];
+        s_sz[pp] = c >= 0 ? grp.offsets[c + 1] - grp.offsets[c] : 0;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int acc = 0;
+        for (int pp = 0; pp < nprobe; ++pp) {
+            s_off[pp] = acc;
+            acc += s_sz[pp];
+        }
+        s_off[nprobe] = acc;
+        if (grp.cand_count) atomicAdd(grp.cand_count, (unsigned long long)acc);
+    }
+    __syncthreads();
+    for (int pp = tid; pp <= nprobe; pp += 1024) grp.qoff[(int64_t)b * (kIvfMaxProbe + 1) + pp] = s_off[pp];
+    for (int pp = tid; pp < nprobe; pp += 1024) {
+        const int c = s_probe[pp];
+        if (c < 0 || s_off[pp + 1] == s_off[pp]) continue;
+        const int slot = atomicAdd(&grp.lcnt[c], 1);  // < 32: a list is probed at most once per query, B <= 32
+        grp.lq[c * kMaxBatch + slot] = b;
+        grp.lbase[c * kMaxBatch + slot] = (int64_t)b * grp.cand_stride + s_off[pp];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // IVF list scan.  One 256-thread workgroup per (query, probe) item; the four waves take
 // alternating groups of 8 rows.  8 lanes share a row: every wave-instruction reads 8 rows x 128
 // contiguous bytes (whole cache lines), four instructions cover the 512-byte rows, nothing is
@@ -1127,6 +1296,331 @@ __global__ __launch_bounds__(256) void ivf_scan_kernel(const IvfScanParams p) {
             p.part_i[o] = li;
         }
     }
+}
+
+hipError_t launch_ivf_coarse_pick(const float* q, int B, const float* cents, const float* cnorm, int nlist, int nprobe,
+                                  int metric, int32_t* probes, const IvfGroup& grp, hipStream_t s) {
+    if (nprobe > 256) return hipErrorInvalidValue;
+    if (nlist <= 1024) hipLaunchKernelGGL(ivf_coarse_pick_kernel<4>, dim3(B), dim3(1024), 0, s, q, cents, cnorm, nlist, nprobe, metric, probes, grp);
+    else if (nlist <= 2048) hipLaunchKernelGGL(ivf_coarse_pick_kernel<8>, dim3(B), dim3(1024), 0, s, q, cents, cnorm, nlist, nprobe, metric, probes, grp);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// List-major IVF scan.  One workgroup per (list, 1024-row chunk); it runs only if some query of
+// the batch probes the list and then serves ALL of them: the rows are read from HBM once per batch
+// instead of once per (query, probe).  8 lanes share a row (whole 128-byte lines per
+// wave-instruction, as in ivf_scan_kernel); the rows of a step stay in registers while the
+// workgroup's queries (staged in LDS) are applied one after the other.  Distances are not ranked
+// here: they go to the query's candidate-score array in probe order (computeDotProductsContiguous
+// writes `scores[i]` the same way, IVFIndex.cpp:313-320) and ivf_select_kernel picks the top-k.
+// ------------------------------------------------------------------------------------------------
+// order-preserving map float -> unsigned (for atomicMin on distances of either sign)
+__device__ __forceinline__ unsigned f32_ordered(float x) {
+    const unsigned b = __builtin_bit_cast(unsigned, x);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float f32_unordered(unsigned u) {
+    const unsigned b = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    return __builtin_bit_cast(float, b);
+}
+
+constexpr int kIvfScanThreads = 1024;  // 16 waves: a popular list's rows are spread thin
+
+__global__ __launch_bounds__(kIvfScanThreads) void ivf_list_scan_kernel(const IvfListScanParams p, int n_chunks) {
+    __shared__ __attribute__((aligned(16))) float q_s[kMaxBatch * kDim];
+    __shared__ float qn_s[kMaxBatch];
+    __shared__ long long base_s[kMaxBatch];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int rr = lane >> 3, s8 = lane & 7;
+    // A few hundred resident workgroups walk the (list, chunk) table; items nobody probes cost one
+    // cached load (dispatching a workgroup per item would cost more than the skipped items' work).
+    for (int chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+        const int c = p.chunk_list[chunk];
+        const int nq = min(p.lcnt[c], kMaxBatch);
+        if (nq <= 0) continue;  // workgroup-uniform
+        const int list_start = p.offsets[c];
+        const int r_begin = p.chunk_row0[chunk];
+        const int r_end = r_begin + p.chunk_rows[chunk];
+        __syncthreads();  // previous item's LDS readers are done
+        // stage the list's queries (gathered by index) and their norms (reference order)
+        {
+            const int s = tid >> 5, c4 = tid & 31;  // 32 x 32 float4 chunks
+            if (s < nq) {
+                const int qi = p.lq[c * kMaxBatch + s];
+                *reinterpret_cast<f32x4*>(q_s + s * kDim + 4 * c4) = *reinterpret_cast<const f32x4*>(p.q + (int64_t)qi * kDim + 4 * c4);
+                if (c4 == 0) base_s[s] = p.lbase[c * kMaxBatch + s];
+            }
+        }
+        __syncthreads();
+        if (tid < 256) {
+            const int s = tid >> 3, j = tid & 7;
+            float acc = 0.f;
+            if (s < nq) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float x = q_s[s * kDim + 8 * i + j];
+                    acc = fmaf(x, x, acc);
+                }
+            }
+            const int b8 = lane & ~7;
+            float sum = __shfl(acc, b8);
+#pragma unroll
+            for (int u = 1; u < 8; ++u) sum = sum + __shfl(acc, b8 + u);
+            if (j == 0 && s < nq) qn_s[s] = sum;
+        }
+        __syncthreads();
+        constexpr int U = 2;  // row groups in flight per wave
+        for (int row0 = r_begin + wave * 8; row0 < r_end; row0 += 128 * U) {
+            f32x4 v[U][4];
+            float vn[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int row = row0 + 128 * u + rr;
+                const int rowc = row < r_end ? row : r_end - 1;
+                const float* src = p.vecs + (int64_t)rowc * kDim + 4 * s8;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) v[u][m] = *reinterpret_cast<const f32x4*>(src + 32 * m);
+                vn[u] = p.vnorm[rowc];
+            }
+            for (int s = 0; s < nq; ++s) {
+                f32x4 qf[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) qf[m] = *reinterpret_cast<const f32x4*>(q_s + s * kDim + 4 * (s8 + 8 * m));
+                const float qn = qn_s[s];
+                float* dst = p.cand + base_s[s];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc = fmaf(v[u][m][i], qf[m][i], acc);
+                    acc = dpp_add_xor1(acc);
+                    acc = dpp_add_xor2(acc);
+                    acc = dpp_add_half_mirror(acc);
+                    const float d = p.metric ? -acc : fmaf(-2.0f, acc, qn + vn[u]);
+                    const int row = row0 + 128 * u + rr;
+                    if (s8 == 0 && row < r_end) dst[row - list_start] = d;
+                }
+            }
+        }
+    }
+}
+
+hipError_t launch_ivf_list_scan(const IvfListScanParams& p, int n_chunks, hipStream_t s) {
+    if (n_chunks <= 0) return hipSuccess;
+    hipLaunchKernelGGL(ivf_list_scan_kernel, dim3(n_chunks < 512 ? n_chunks : 512), dim3(kIvfScanThreads), 0, s, p, n_chunks);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Top-k of a query's candidate scores (the heap loop of IVFIndex.cpp:750-767 as a two-pass
+// selection): pass 1 finds the 16 wave minima, whose k-th smallest bounds the k-th best score;
+// pass 2 collects the few scores under the bound, maps them back to reordered positions and ranks
+// them by counting in (dist, position) order; ids go through reorder_to_original (:774-779).
+// ------------------------------------------------------------------------------------------------
+constexpr int kSelSplit = 8;      // workgroups per query
+constexpr int kSelCap = 4096;     // global candidate slots per query
+
+// Pass 1 of the selection: every workgroup takes 1/8 of a query's candidate scores, computes its 256
+// thread minima and their k-th smallest -- a bound backed by k distinct candidates -- and folds it
+// into the query's bound with an atomic (complemented ordered floats: 0 = no bound yet, atomicMax).
+__global__ __launch_bounds__(256) void ivf_bound_kernel(const IvfSelectParams p) {
+    __shared__ float mn[256];
+    const int q = blockIdx.x / kSelSplit, part = blockIdx.x % kSelSplit;
+    const int tid = threadIdx.x;
+    const int S = p.qoff[(int64_t)q * (kIvfMaxProbe + 1) + p.nprobe];
+    const float* sc = p.cand + (int64_t)q * p.cand_stride;
+    const int S4 = S >> 2;
+    const int per = (S4 + kSelSplit - 1) / kSelSplit;
+    const int a4 = part * per, b4 = min(S4, a4 + per);
+    const f32x4* sc4 = reinterpret_cast<const f32x4*>(sc);
+    float m = VS_INF;
+    for (int i0 = a4 + tid; i0 < b4; i0 += 1024) {
+        f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + 256 * u;
+            v[u] = i < b4 ? sc4[i] : (f32x4){VS_INF, VS_INF, VS_INF, VS_INF};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) m = fminf(m, fminf(fminf(v[u][0], v[u][1]), fminf(v[u][2], v[u][3])));
+    }
+    if (part == kSelSplit - 1)
+        for (int i = 4 * S4 + tid; i < S; i += 256) m = fminf(m, sc[i]);
+    mn[tid] = m;
+    __syncthreads();
+    int rank = 0;
+    for (int j = 0; j < 256; ++j) rank += (mn[j] < m || (mn[j] == m && j < tid)) ? 1 : 0;
+    if (rank == min(p.k, 256) - 1 && m < VS_INF) atomicMax(p.tq + q, ~f32_ordered(m));
+}
+
+
+__global__ __launch_bounds__(256) void ivf_select_kernel(const IvfSelectParams p) {
+    __shared__ float s_t;
+    __shared__ int s_cnt, s_base, s_last;
+    __shared__ float cd[1024];
+    __shared__ int cpos[1024];
+    __shared__ int s_off[257];
+    __shared__ int s_probe[256];
+    const int q = blockIdx.x / kSelSplit, part = blockIdx.x % kSelSplit;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int S = p.qoff[(int64_t)q * (kIvfMaxProbe + 1) + p.nprobe];
+    const float* sc = p.cand + (int64_t)q * p.cand_stride;
+    for (int pp = tid; pp <= p.nprobe; pp += 256) s_off[pp] = p.qoff[(int64_t)q * (kIvfMaxProbe + 1) + pp];
+    for (int pp = tid; pp < p.nprobe; pp += 256) s_probe[pp] = p.probes[(int64_t)q * p.nprobe + pp];
+    if (tid == 0) {
+        s_cnt = 0;
+        const unsigned u = p.tq[q];  // bound from ivf_bound_kernel (0 = none)
+        s_t = u ? f32_unordered(~u) : VS_INF;
+    }
+    __syncthreads();
+    const float T = s_t;
+    auto pos_of = [&](int i) {  // candidate index -> probe (windows are in probe order) -> reordered position
+        int lo = 0, hi = p.nprobe - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (s_off[mid] <= i) lo = mid; else hi = mid - 1;
+        }
+        return p.offsets[s_probe[lo]] + (i - s_off[lo]);
+    };
+    auto consider = [&](int i, float d) {
+        if (d <= T) {
+            const int pos = atomicAdd(&s_cnt, 1);
+            if (pos < 1024) {
+                cd[pos] = d;
+                cpos[pos] = pos_of(i);
+            }
+        }
+    };
+    // this workgroup's slice of the candidate array (16-byte loads, four in flight per thread)
+    const int S4 = S >> 2;
+    const int per = (S4 + kSelSplit - 1) / kSelSplit;
+    const int a4 = part * per, b4 = min(S4, a4 + per);
+    const f32x4* sc4 = reinterpret_cast<const f32x4*>(sc);  // the candidate array is 64-float aligned
+    for (int i0 = a4 + tid; i0 < b4; i0 += 1024) {
+        f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + 256 * u;
+            v[u] = i < b4 ? sc4[i] : (f32x4){VS_INF, VS_INF, VS_INF, VS_INF};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + 256 * u;
+            if (i < b4 && (v[u][0] <= T || v[u][1] <= T || v[u][2] <= T || v[u][3] <= T)) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) consider(4 * i + e, v[u][e]);
+            }
+        }
+    }
+    if (part == kSelSplit - 1)
+        for (int i = 4 * S4 + tid; i < S; i += 256) consider(i, sc[i]);
+    __syncthreads();
+    // append to the query's global candidate list (write-through), then take an arrival ticket
+    const int C = s_cnt;
+    if (tid == 0) s_base = atomicAdd(p.gcnt + q, C);
+    __syncthreads();
+    const int base = s_base;
+    const bool overflow = C > 1024 || base + C > kSelCap;
+    float* gd = p.gcand_d + (int64_t)q * kSelCap;
+    int* gp = p.gcand_p + (int64_t)q * kSelCap;
+    if (!overflow)
+        for (int c = tid; c < C; c += 256) {
+            __hip_atomic_store(gd + base + c, cd[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(gp + base + c, cpos[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        if (overflow) __hip_atomic_store(p.govf + q, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int old = __hip_atomic_fetch_add(p.gdone + q, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = old == kSelSplit - 1;
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        s_last = last;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    // ---- the last workgroup of the query ranks the gathered candidates ----
+    const int total = __hip_atomic_load(p.gcnt + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int ovf = __hip_atomic_load(p.govf + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!ovf && total <= kSelCap) {
+        for (int c = tid; c < total; c += 256) {
+            const float d = gd[c];
+            const int id = gp[c];
+            int rank = 0;
+            for (int j = 0; j < total; ++j) rank += lex_lt(gd[j], gp[j], d, id) ? 1 : 0;
+            if (rank < p.k) {
+                p.out_d[(int64_t)q * p.k + rank] = d;
+                p.out_i[(int64_t)q * p.k + rank] = p.id_map ? p.id_map[id] : id;
+            }
+        }
+        for (int c = total + tid; c < p.k; c += 256) {
+            p.out_d[(int64_t)q * p.k + c] = VS_INF;
+            p.out_i[(int64_t)q * p.k + c] = -1;
+        }
+        return;
+    }
+    // Too many scores under the bound (massive ties / no usable bound): exact but slow path -- k rounds of a
+    // workgroup-wide minimum in (dist, position) order over everything not emitted yet.
+    {
+        __shared__ float r_d[4];
+        __shared__ int r_p[4];
+        float last_d = -VS_INF;
+        int last_p = -1;
+        for (int round = 0; round < p.k; ++round) {
+            float bd = VS_INF;
+            int bp = 0x7fffffff;
+            for (int i = tid; i < S; i += 256) {
+                const float d = sc[i];
+                if (!(d == d) || d < last_d || d > bd) continue;
+                const int ps = pos_of(i);
+                if (d == last_d && ps <= last_p) continue;
+                if (lex_lt(d, ps, bd, bp)) {
+                    bd = d;
+                    bp = ps;
+                }
+            }
+            float wd;
+            int wp;
+            wave_lexmin(bd, bp, wd, wp);
+            if (lane == 0) {
+                r_d[wave] = wd;
+                r_p[wave] = wp;
+            }
+            __syncthreads();
+            bd = r_d[0];
+            bp = r_p[0];
+            for (int w = 1; w < 4; ++w)
+                if (lex_lt(r_d[w], r_p[w], bd, bp)) {
+                    bd = r_d[w];
+                    bp = r_p[w];
+                }
+            const bool none = bp == 0x7fffffff;
+            if (tid == 0) {
+                p.out_d[(int64_t)q * p.k + round] = none ? VS_INF : bd;
+                p.out_i[(int64_t)q * p.k + round] = none ? -1 : (p.id_map ? p.id_map[bp] : bp);
+            }
+            last_d = none ? VS_INF : bd;
+            last_p = none ? 0x7fffffff : bp;
+            __syncthreads();
+        }
+    }
+}
+
+hipError_t launch_ivf_select(const IvfSelectParams& p, int B, hipStream_t s) {
+    if (p.k > 16 || p.nprobe > 256) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(ivf_bound_kernel, dim3(B * kSelSplit), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(ivf_select_kernel, dim3(B * kSelSplit), dim3(256), 0, s, p);
+    return hipGetLastError();
 }
 
 hipError_t launch_ivf_scan(const IvfScanParams& p, hipStream_t s) {
