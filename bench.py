@@ -87,7 +87,8 @@ def main():
     ap.add_argument("--no-ivf", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not time the scan kernel with HIP events")
-    ap.add_argument("--kmeans-iters", type=int, default=8)
+    ap.add_argument("--kmeans-iters", type=int, default=20)
+    ap.add_argument("--torch-kmeans", action="store_true", help="build the index with torch instead of vs_ivf_build")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N > 1 path on ONE GPU (all ranks share cuda:0, gathers staged through host)")
     args = ap.parse_args()
@@ -234,13 +235,18 @@ def main():
         # every rank builds the same index deterministically from the full base (index build is
         # outside the timed region and outside the graded path)
         full = shard if world == 1 else pkg.synth_sift(n_rows, seed=SEED_BASE)
-        full_dev = torch.from_numpy(full).to(dev)
         nlist = pkg.clamp_nlist(n_rows, NLIST)
-        cents, assign = build_ivf_torch(full_dev, nlist, args.kmeans_iters, seed=42)
-        vr, off, r2o = pkg.ivf_layout_from_assignment(full, assign.cpu().numpy(), nlist)
-        cents_h = cents.cpu().numpy()
-        del full_dev, assign
-        torch.cuda.empty_cache()
+        if args.torch_kmeans:
+            full_dev = torch.from_numpy(full).to(dev)
+            cents, assign = build_ivf_torch(full_dev, nlist, args.kmeans_iters, seed=42)
+            vr, off, r2o = pkg.ivf_layout_from_assignment(full, assign.cpu().numpy(), nlist)
+            cents_h = cents.cpu().numpy()
+            del full_dev, assign
+            torch.cuda.empty_cache()
+        else:
+            # native builder: k-means on the library's own MFMA scan kernel, deterministic
+            vr, off, r2o, cents_h, n_it = pkg.ivf_build(full, nlist, max_iter=args.kmeans_iters, seed=42, device=local_rank)
+            log(f"vs_ivf_build: {n_it} Lloyd iterations")
         ivf = pkg.IVFIndex(vectors_reordered=vr, centroids=cents_h, cluster_offsets=off, reorder_to_original=r2o,
                            device=local_rank, rank=rank, world=world)
         sizes = np.diff(off)

@@ -115,6 +115,7 @@ def lib():
         "vs_bf_scores_dev": (i32, [vp, vp, i32, vp, i64, vp]),
         "vs_ivf_load": (i32, [C.c_char_p, i32, i32, i32, C.POINTER(vp)]),
         "vs_ivf_create": (i32, [vp, i64, i32, vp, i32, vp, vp, i32, i32, i32, C.POINTER(vp)]),
+        "vs_ivf_build": (i32, [vp, i64, i32, i32, i32, C.c_double, C.c_uint64, i32, vp, vp, C.POINTER(i32)]),
         "vs_ivf_save": (i32, [vp, C.c_char_p]),
         "vs_ivf_search": (i32, [vp, vp, i64, i32, i32, vp, vp, C.POINTER(i64), C.POINTER(Timing)]),
         "vs_ivf_search_dev": (i32, [vp, vp, i32, i32, i32, vp, vp, vp]),
@@ -355,6 +356,20 @@ def ivf_layout_from_assignment(vectors: np.ndarray, cluster_ids: np.ndarray, n_c
     offsets = np.zeros(n_clusters + 1, dtype=np.int32)
     offsets[1:] = np.cumsum(sizes)
     return np.ascontiguousarray(vectors[order], dtype=np.float32), offsets, order
+
+
+def ivf_build(base, n_clusters: int, max_iter: int = 100, tol: float = 1e-4, seed: int = 42, device: int = 0):
+    """build_ivf_index_reordered (create_ivf_model_reordered.py:82-177) on the GPU: k-means (vs_ivf_build),
+    then the reordered layout.  Returns (vectors_reordered, cluster_offsets, reorder_to_original, centroids, n_iter)."""
+    base = _f32c(base)
+    n, d = base.shape
+    n_clusters = clamp_nlist(n, n_clusters)
+    cents = np.empty((n_clusters, d), dtype=np.float32)
+    assign = np.empty(n, dtype=np.int32)
+    it = C.c_int(0)
+    _check(lib().vs_ivf_build(_p(base), n, d, n_clusters, max_iter, tol, seed, device, _p(cents), _p(assign), C.byref(it)))
+    vr, off, r2o = ivf_layout_from_assignment(base, assign, n_clusters)
+    return vr, off, r2o, cents, int(it.value)
 
 
 def clamp_nlist(n_vectors: int, n_clusters: int) -> int:

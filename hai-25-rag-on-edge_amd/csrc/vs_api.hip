@@ -835,6 +835,150 @@ static int ivf_create_impl(const float* vectors, int64_t n_rows, int dim, const 
     return VS_OK;
 }
 
+// GPU index builder: Lloyd k-means on the scan kernel (assignment = the brute-force MFMA scan with the
+// centroids as "queries", 32 per pass) + deterministic fixed-point update.
+int vs_ivf_build(const float* base_host, int64_t n_rows, int dim, int nlist, int max_iter, double tol, uint64_t seed,
+                 int device, float* centroids_out, int32_t* assign_out, int* iters_done) {
+    if (!base_host || !centroids_out || !assign_out || n_rows <= 0 || nlist <= 0 || nlist > n_rows || max_iter < 0) {
+        set_error("vs_ivf_build: bad arguments");
+        return VS_ERR_INVALID;
+    }
+    if (dim != vs::kDim) {
+        set_error("only dim == 128 is compiled in");
+        return VS_ERR_UNSUPPORTED;
+    }
+    int rc = check_device(device);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    const int num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    float *d_x = nullptr, *d_norm = nullptr, *d_cents = nullptr, *d_best_d = nullptr;
+    int32_t *d_best_i = nullptr, *d_counts = nullptr;
+    unsigned long long* d_acc = nullptr;
+    double* d_shift = nullptr;
+    auto cleanup = [&]() {
+        void* ptrs[] = {d_x, d_norm, d_cents, d_best_d, d_best_i, d_counts, d_acc, d_shift};
+        for (void* p : ptrs)
+            if (p) (void)hipFree(p);
+    };
+#define BUILD_CHK(expr)                                                                \
+    do {                                                                               \
+        hipError_t _e = (expr);                                                        \
+        if (_e != hipSuccess) {                                                        \
+            set_error(std::string(#expr) + ": " + hipGetErrorString(_e));              \
+            cleanup();                                                                 \
+            return VS_ERR_DEVICE;                                                      \
+        }                                                                              \
+    } while (0)
+    const int nlist_pad = (nlist + 31) & ~31;
+    BUILD_CHK(hipMalloc(&d_x, (size_t)n_rows * dim * sizeof(float)));
+    BUILD_CHK(hipMalloc(&d_norm, ((size_t)n_rows + 64) * sizeof(float)));
+    BUILD_CHK(hipMalloc(&d_cents, (size_t)nlist_pad * dim * sizeof(float)));
+    BUILD_CHK(hipMalloc(&d_best_d, (size_t)n_rows * sizeof(float)));
+    BUILD_CHK(hipMalloc(&d_best_i, (size_t)n_rows * sizeof(int32_t)));
+    BUILD_CHK(hipMalloc(&d_counts, (size_t)nlist * sizeof(int32_t)));
+    BUILD_CHK(hipMalloc(&d_acc, (size_t)nlist * dim * sizeof(unsigned long long)));
+    BUILD_CHK(hipMalloc(&d_shift, (size_t)nlist * sizeof(double)));
+    BUILD_CHK(hipMemcpy(d_x, base_host, (size_t)n_rows * dim * sizeof(float), hipMemcpyHostToDevice));
+    BUILD_CHK(hipMemset(d_norm, 0, ((size_t)n_rows + 64) * sizeof(float)));
+    BUILD_CHK(vs::launch_row_sqnorm(d_x, n_rows, dim, d_norm, nullptr));
+    // initial centroids: nlist distinct rows drawn with splitmix64 (the reference's KMeans uses k-means++ with
+    // random_state=42, create_ivf_model_reordered.py:97-103; its RNG stream cannot be reproduced, so the
+    // initialisation is documented as different)
+    {
+        std::vector<float> init((size_t)nlist_pad * dim, 0.f);
+        std::vector<int64_t> picked;
+        uint64_t st = seed * 0x9E3779B97F4A7C15ull + 0x1234567ull;
+        auto next = [&]() {
+            uint64_t z = (st += 0x9E3779B97F4A7C15ull);
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+            return z ^ (z >> 31);
+        };
+        std::vector<bool> used((size_t)n_rows, false);
+        for (int c = 0; c < nlist; ++c) {
+            int64_t r;
+            do r = (int64_t)(next() % (uint64_t)n_rows); while (used[(size_t)r]);
+            used[(size_t)r] = true;
+            std::memcpy(&init[(size_t)c * dim], base_host + r * dim, (size_t)dim * sizeof(float));
+        }
+        BUILD_CHK(hipMemcpy(d_cents, init.data(), init.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    // sklearn's stopping rule: sum of squared centre shifts <= tol * mean per-feature variance
+    double tol_abs = 0.0;
+    if (tol > 0) {
+        std::vector<double> sum(dim, 0.0), sq(dim, 0.0);
+        for (int64_t i = 0; i < n_rows; ++i)
+            for (int t = 0; t < dim; ++t) {
+                const double v = base_host[i * dim + t];
+                sum[t] += v;
+                sq[t] += v * v;
+            }
+        double mv = 0;
+        for (int t = 0; t < dim; ++t) {
+            const double m = sum[t] / n_rows;
+            mv += sq[t] / n_rows - m * m;
+        }
+        tol_abs = tol * mv / dim;
+    }
+    int grid, tp;
+    scan_geometry(n_rows, num_cus, grid, tp);
+    auto assign_pass = [&]() -> hipError_t {
+        hipError_t e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_best_d), 0x7f800000, (size_t)n_rows, nullptr);
+        if (e != hipSuccess) return e;
+        e = hipMemsetAsync(d_best_i, 0xff, (size_t)n_rows * sizeof(int32_t), nullptr);
+        if (e != hipSuccess) return e;
+        vs::ScanParams p{};
+        p.base = d_x;
+        p.bnorm = d_norm;
+        p.metric = 0;
+        p.row_begin = 0;
+        p.row_end = n_rows;
+        p.tiles_per_wg = tp;
+        p.best_d = d_best_d;
+        p.best_i = d_best_i;
+        p.q_batch_stride = (int64_t)32 * dim;
+        const int full = nlist / 32, rem = nlist % 32;
+        if (full) {
+            p.q = d_cents;
+            p.n_batches = full;
+            p.nq_valid = 32;
+            p.assign_base = 0;
+            e = vs::launch_scan(p, grid, 8, 2, vs::kModeAssign, nullptr);
+            if (e != hipSuccess) return e;
+        }
+        if (rem) {
+            p.q = d_cents + (size_t)full * 32 * dim;
+            p.n_batches = 1;
+            p.nq_valid = rem;
+            p.assign_base = full * 32;
+            e = vs::launch_scan(p, grid, 8, 2, vs::kModeAssign, nullptr);
+        }
+        return e;
+    };
+    int it = 0;
+    std::vector<double> shift((size_t)nlist);
+    for (; it < max_iter; ++it) {
+        BUILD_CHK(assign_pass());
+        BUILD_CHK(vs::launch_kmeans_update(d_x, d_best_i, n_rows, nlist, d_cents, d_acc, d_counts, d_shift, nullptr));
+        BUILD_CHK(hipMemcpy(shift.data(), d_shift, (size_t)nlist * sizeof(double), hipMemcpyDeviceToHost));
+        double total = 0;
+        for (double v : shift) total += v;
+        if (total <= tol_abs) {
+            ++it;
+            break;
+        }
+    }
+    BUILD_CHK(assign_pass());  // labels consistent with the final centroids
+    BUILD_CHK(hipMemcpy(assign_out, d_best_i, (size_t)n_rows * sizeof(int32_t), hipMemcpyDeviceToHost));
+    BUILD_CHK(hipMemcpy(centroids_out, d_cents, (size_t)nlist * dim * sizeof(float), hipMemcpyDeviceToHost));
+#undef BUILD_CHK
+    cleanup();
+    if (iters_done) *iters_done = it;
+    return VS_OK;
+}
+
 int vs_ivf_create(const float* vectors_reordered, int64_t n_rows, int dim, const float* centroids, int nlist,
                   const int32_t* cluster_offsets, const int32_t* reorder_to_original, int device, int rank, int world,
                   vs_index** out) {

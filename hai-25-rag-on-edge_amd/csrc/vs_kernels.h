@@ -12,7 +12,7 @@ constexpr int kScanWaves = 8;
 constexpr int kMaxBatch = 32;      // queries per scan pass (two 16-query MFMA column blocks)
 constexpr int kSlotStride = 256;   // threshold-exchange slots: [32 queries][256 workgroups]
 
-enum ScanMode { kModeTopK = 0, kModeStore = 1 };
+enum ScanMode { kModeTopK = 0, kModeStore = 1, kModeAssign = 2 };
 
 struct ScanParams {
     const float* base;       // [n_rows][128] row-major (the flat fvecs payload, cpu_baseline.cpp:48-49)
@@ -36,6 +36,10 @@ struct ScanParams {
     // kModeStore output
     float* store;            // [nq_valid][store_ld], column = row - row_begin
     int64_t store_ld;
+    // kModeAssign (k-means): running nearest "query" (centroid) per base row, id = assign_base + batch*32 + column
+    float* best_d;           // [n_rows] (pre-set to +inf)
+    int32_t* best_i;         // [n_rows] (pre-set to -1)
+    int assign_base;
 };
 
 // Brute-force / coarse scan.  kcap in {8, 16}; nqh = 1 (<=16 queries) or 2.
@@ -60,6 +64,10 @@ struct MergeParams {
 hipError_t launch_merge(const MergeParams& p, hipStream_t s);  // scan-partial layout [G][nq_stride][kin]
 // general layout: entry (g, q, j) at g*stride_g + q*stride_q + j
 hipError_t launch_merge_layout(const MergeParams& p, int64_t stride_g, int64_t stride_q, hipStream_t s);
+
+// One Lloyd update: deterministic fixed-point cluster sums -> new centroids; shift[c] = ||new - old||^2.
+hipError_t launch_kmeans_update(const float* x, const int32_t* assign, int64_t rows, int nlist, float* cents,
+                                unsigned long long* acc, int32_t* counts, double* shift, hipStream_t s);
 
 // ||v||^2 per row in the reference's AVX2 summation order (cpu_baseline.cpp:95-114).
 hipError_t launch_row_sqnorm(const float* v, int64_t rows, int dim, float* out, hipStream_t s);

@@ -379,13 +379,50 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams 
                             tau[h] = fminf(tau[h], ld[h][KCAP - 1]);
                         }
                 }
-            } else {
+            } else if (MODE == kModeStore) {
                 const int qidx = h * 16 + r;
                 if (qidx < p.nq_valid) {
                     float* dst = p.store + (int64_t)qidx * p.store_ld + (rbase - p.row_begin);
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         if (rbase + j <= last_row) dst[j] = d[h][j];
+                }
+            }
+        }
+        if (MODE == kModeAssign) {
+            // k-means assignment: "queries" are a block of 32 centroids; every base row keeps its nearest
+            // centroid so far in best_d/best_i.  A lane holds rows 4g..4g+3 for columns r and 16+r: fold
+            // its columns, then the 16 lanes of the DPP row (same rows, different columns).
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float bd = VS_INF;
+                int bi = 0x7fffffff;
+#pragma unroll
+                for (int h = 0; h < NQH; ++h) {
+                    const int cid = p.assign_base + batch * kMaxBatch + h * 16 + r;
+                    if (h * 16 + r < p.nq_valid && lex_lt(d[h][j], cid, bd, bi)) {
+                        bd = d[h][j];
+                        bi = cid;
+                    }
+                }
+                float od;
+                int oi;
+                od = dpp_mov_f<0xB1>(bd); oi = dpp_mov_i<0xB1>(bi);
+                if (lex_lt(od, oi, bd, bi)) { bd = od; bi = oi; }
+                od = dpp_mov_f<0x4E>(bd); oi = dpp_mov_i<0x4E>(bi);
+                if (lex_lt(od, oi, bd, bi)) { bd = od; bi = oi; }
+                od = dpp_mov_f<0x141>(bd); oi = dpp_mov_i<0x141>(bi);
+                if (lex_lt(od, oi, bd, bi)) { bd = od; bi = oi; }
+                od = dpp_mov_f<0x140>(bd); oi = dpp_mov_i<0x140>(bi);
+                if (lex_lt(od, oi, bd, bi)) { bd = od; bi = oi; }
+                const int64_t row = rbase + j;
+                if (r == 0 && row <= last_row && bi != 0x7fffffff) {
+                    const float cur_d = p.best_d[row];
+                    const int cur_i = p.best_i[row];
+                    if (lex_lt(bd, bi, cur_d, cur_i < 0 ? 0x7fffffff : cur_i)) {
+                        p.best_d[row] = bd;
+                        p.best_i[row] = bi;
+                    }
                 }
             }
         }
@@ -510,7 +547,11 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams 
     }
     VS_STAMP(5);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // retire the discarded tail prefetches: LDS is reused below
-    if (MODE != kModeTopK) return;
+    if (MODE == kModeStore) return;
+    if (MODE == kModeAssign) {
+        __syncthreads();  // LDS is reused by the next centroid block
+        continue;
+    }
     __syncthreads();
     VS_STAMP(4);
 
@@ -594,6 +635,7 @@ static hipError_t launch_scan_t(const ScanParams& p, int grid, hipStream_t s) {
 }
 
 hipError_t launch_scan(const ScanParams& p, int grid, int kcap, int nqh, int mode, hipStream_t s) {
+    if (mode == kModeAssign) return launch_scan_t<2, 8, kModeAssign>(p, grid, s);
     if (mode == kModeStore) {
         return nqh == 1 ? launch_scan_t<1, 8, kModeStore>(p, grid, s) : launch_scan_t<2, 8, kModeStore>(p, grid, s);
     }
@@ -996,6 +1038,60 @@ hipError_t launch_row_sqnorm(const float* v, int64_t rows, int dim, float* out, 
     const int64_t threads = rows * 8;
     const int grid = (int)((threads + 255) / 256);
     hipLaunchKernelGGL(row_sqnorm_kernel, dim3(grid), dim3(256), 0, s, v, rows, dim, out);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// k-means update (index builder, create_ivf_model_reordered.py:96-105): cluster sums are accumulated
+// in 44.20 fixed point with 64-bit integer atomics, so the result does not depend on the order in
+// which rows arrive (float atomics would make the index differ from run to run).
+// ------------------------------------------------------------------------------------------------
+constexpr double kFix = 1048576.0;  // 2^20
+
+__global__ __launch_bounds__(256) void kmeans_accum_kernel(const float* __restrict__ x, const int32_t* __restrict__ assign,
+                                                           int64_t rows, unsigned long long* __restrict__ acc,
+                                                           int32_t* __restrict__ counts) {
+    // 128 threads per row, 2 rows per workgroup pass
+    const int t = threadIdx.x & 127;
+    for (int64_t row = (int64_t)blockIdx.x * 2 + (threadIdx.x >> 7); row < rows; row += (int64_t)gridDim.x * 2) {
+        const int c = assign[row];
+        if (c < 0) continue;
+        const long long v = __double2ll_rn((double)x[row * kDim + t] * kFix);
+        atomicAdd(acc + (int64_t)c * kDim + t, (unsigned long long)v);
+        if (t == 0) atomicAdd(counts + c, 1);
+    }
+}
+
+__global__ __launch_bounds__(128) void kmeans_finalize_kernel(float* __restrict__ cents, const unsigned long long* __restrict__ acc,
+                                                              const int32_t* __restrict__ counts, double* __restrict__ shift) {
+    const int c = blockIdx.x, t = threadIdx.x;
+    const int n = counts[c];
+    float delta2 = 0.f;
+    if (n > 0) {
+        const double mean = (double)(long long)acc[(int64_t)c * kDim + t] / kFix / (double)n;
+        const float nv = (float)mean;
+        const float ov = cents[c * kDim + t];
+        cents[c * kDim + t] = nv;
+        delta2 = (nv - ov) * (nv - ov);
+    }  // an empty cluster keeps its centroid
+    __shared__ float red[128];
+    red[t] = delta2;
+    __syncthreads();
+    for (int sft = 64; sft > 0; sft >>= 1) {
+        if (t < sft) red[t] += red[t + sft];
+        __syncthreads();
+    }
+    if (t == 0) shift[c] = (double)red[0];
+}
+
+hipError_t launch_kmeans_update(const float* x, const int32_t* assign, int64_t rows, int nlist, float* cents,
+                                unsigned long long* acc, int32_t* counts, double* shift, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(acc, 0, (size_t)nlist * kDim * sizeof(unsigned long long), s);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(counts, 0, (size_t)nlist * sizeof(int32_t), s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kmeans_accum_kernel, dim3(4096), dim3(256), 0, s, x, assign, rows, acc, counts);
+    hipLaunchKernelGGL(kmeans_finalize_kernel, dim3(nlist), dim3(128), 0, s, cents, acc, counts, shift);
     return hipGetLastError();
 }
 

@@ -174,3 +174,51 @@ def test_cluster_shards_merge_to_unsharded(gpu_pkg, world):
     a, b = i_all.cpu().numpy(), oi.cpu().numpy()
     for i in range(32):
         assert sorted(a[i].tolist()) == sorted(b[i].tolist())
+
+
+def test_gpu_index_builder(gpu_pkg):
+    """vs_ivf_build: Lloyd k-means on the MFMA scan kernel + deterministic update, then the
+    reordered layout of create_ivf_model_reordered.py:108-128."""
+    base = gpu_pkg.synth_sift(30000, seed=21)
+    vr, off, r2o, cents, n_iter = gpu_pkg.ivf_build(base, 64, max_iter=25, seed=42)
+    assert cents.shape == (64, 128) and off.shape == (65,) and off[0] == 0 and off[-1] == 30000
+    assert 1 <= n_iter <= 25
+    assert np.array_equal(np.sort(r2o), np.arange(30000))          # a permutation
+    assert np.array_equal(vr, base[r2o])                           # vectors[sorted_indices] (:112)
+    # every row sits in the list of its nearest centroid (final E-step), up to fp32 rounding of the distance
+    d = (base.astype(np.float64) ** 2).sum(1)[:, None] - 2 * base.astype(np.float64) @ cents.astype(np.float64).T \
+        + (cents.astype(np.float64) ** 2).sum(1)[None]
+    assign = np.empty(30000, dtype=np.int64)
+    for c in range(64):
+        assign[r2o[off[c]:off[c + 1]]] = c
+    best = d.min(1)
+    chosen = d[np.arange(30000), assign]
+    assert np.all(chosen - best <= 1e-3 * np.maximum(best, 1.0))
+    assert (assign == d.argmin(1)).mean() > 0.999
+    # stable argsort: original ids ascend inside every list (:111)
+    for c in (0, 17, 63):
+        seg = r2o[off[c]:off[c + 1]]
+        assert np.all(np.diff(seg) > 0)
+    # deterministic: same seed -> bit-identical index; other seed -> different
+    vr2, off2, r2o2, cents2, _ = gpu_pkg.ivf_build(base, 64, max_iter=25, seed=42)
+    assert np.array_equal(cents, cents2) and np.array_equal(r2o, r2o2) and np.array_equal(off, off2)
+    _, _, _, cents3, _ = gpu_pkg.ivf_build(base, 64, max_iter=25, seed=7)
+    assert not np.array_equal(cents, cents3)
+    # k-means quality: inertia far below that of random centres, lists reasonably balanced
+    inertia = chosen.sum()
+    rnd = base[np.random.default_rng(0).choice(30000, 64, replace=False)].astype(np.float64)
+    d0 = (base.astype(np.float64) ** 2).sum(1)[:, None] - 2 * base.astype(np.float64) @ rnd.T + (rnd ** 2).sum(1)[None]
+    assert inertia < 0.9 * d0.min(1).sum()
+    # the nlist clamp of create_ivf_model_reordered.py:92-94
+    _, off_c, _, cents_c, _ = gpu_pkg.ivf_build(base[:2000], 1024, max_iter=3)
+    assert cents_c.shape[0] == gpu_pkg.clamp_nlist(2000, 1024) == 20
+    # and the index it builds searches correctly
+    q = gpu_pkg.synth_sift(64, seed=22)
+    gt, _ = oracle.search_bf(base, q, 5)
+    with gpu_pkg.IVFIndex(vectors_reordered=vr, centroids=cents, cluster_offsets=off, reorder_to_original=r2o) as ivf:
+        ids, _, _ = ivf.searchBatch(q, len(q), 5, 64)
+        assert np.array_equal(np.sort(ids, 1), np.sort(gt, 1)) or oracle.recall(ids, gt, 5) > 0.995
+        ids8, _, _ = ivf.searchBatch(q, len(q), 5, 8)
+        ids32, _, _ = ivf.searchBatch(q, len(q), 5, 32)
+    r8, r32 = oracle.recall(ids8[:, :1], gt[:, :1], 1), oracle.recall(ids32[:, :1], gt[:, :1], 1)
+    assert 0.5 < r8 <= r32 and r32 >= 0.91
