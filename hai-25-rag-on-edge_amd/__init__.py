@@ -109,6 +109,7 @@ def lib():
         "vs_select_topk_slots": (i32, [vp, vp, i64, i32, vp, vp]),
         "vs_bf_create": (i32, [vp, i64, i32, i32, i32, i64, C.POINTER(vp)]),
         "vs_set_batch": (i32, [vp, i32]),
+        "vs_set_precision": (i32, [vp, i32]),
         "vs_bf_search": (i32, [vp, vp, i64, i32, vp, vp, C.POINTER(Timing)]),
         "vs_bf_search_dev": (i32, [vp, vp, i32, i32, vp, vp, vp, vp]),
         "vs_bf_search_dev_multi": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp]),
@@ -240,6 +241,10 @@ class _Index:
 
     def set_batch(self, batch: int):
         _check(lib().vs_set_batch(self._h, batch))
+
+    def set_precision(self, precision: int):
+        """0 = auto (int8 scan when the base is integer valued in [0, 255]), 1 = fp32, 2 = require int8."""
+        _check(lib().vs_set_precision(self._h, precision))
 
     # QnnRunner-style getters (QnnRunner.h:37-39)
     def getNumDocs(self) -> int:

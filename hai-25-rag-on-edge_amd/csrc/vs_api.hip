@@ -62,7 +62,12 @@ struct vs_index {
     int num_cus = 256;
 
     float* d_vecs = nullptr;   // [n_rows][128]
-    float* d_norm = nullptr;   // [n_rows + 16]
+    float* d_norm = nullptr;   // [n_rows + 64]
+    // int8 data path: only when every base value is an integer in [0, 255]
+    int8_t* d_vecs_u8 = nullptr;   // [n_rows][128] bytes (x - 128)
+    int32_t* d_rterm = nullptr;    // [n_rows + 64] ||b||^2 - 256 * sum(b - 128)
+    int32_t* d_invalid = nullptr;  // [kMaxMulti] batches the int8 scan had to skip
+    int precision = 0;             // 0 = auto (int8 when possible), 1 = fp32, 2 = int8
 
     // IVF
     int nlist = 0;
@@ -147,7 +152,7 @@ void free_all(vs_index* h) {
         if (L.s) (void)hipStreamDestroy(L.s);
     }
     if (h->fork) (void)hipEventDestroy(h->fork);
-    void* ptrs[] = {h->d_vecs, h->d_norm, h->d_centroids, h->d_cnorm, h->d_offsets, h->d_r2o, h->d_q,
+    void* ptrs[] = {h->d_vecs, h->d_norm, h->d_vecs_u8, h->d_rterm, h->d_invalid, h->d_centroids, h->d_cnorm, h->d_offsets, h->d_r2o, h->d_q,
                     h->d_out_d, h->d_out_i,
                     h->d_flags, h->d_scores, h->d_probes, h->d_ipart_d, h->d_ipart_i, h->d_cand,
                     h->d_chunk_list, h->d_chunk_row0, h->d_chunk_rows, h->d_lcnt, h->d_lq, h->d_lbase, h->d_qoff,
@@ -251,6 +256,32 @@ int upload_vectors(vs_index* h, const float* host, int64_t rows) {
     return VS_OK;
 }
 
+// int8 copy of the base when it is exactly representable: bytes (x - 128) and the per-row term
+// ||b||^2 - 256 * sum(b - 128); dist = [||q||^2 - 256 sum(q-128) - 2*128^3] + rterm - 2 * sum((q-128)(b-128)).
+int build_u8_copy(vs_index* h, const float* host, int64_t rows) {
+    std::vector<int8_t> bytes((size_t)rows * vs::kDim);
+    std::vector<int32_t> rterm((size_t)rows + 64, 0);
+    for (int64_t i = 0; i < rows; ++i) {
+        int32_t n2 = 0, sb = 0;
+        for (int t = 0; t < vs::kDim; ++t) {
+            const float x = host[i * vs::kDim + t];
+            const int xi = (int)x;
+            if (!((float)xi == x) || xi < 0 || xi > 255) return VS_OK;  // not representable: fp32 path only
+            bytes[(size_t)i * vs::kDim + t] = (int8_t)(xi - 128);
+            n2 += xi * xi;
+            sb += xi - 128;
+        }
+        rterm[(size_t)i] = n2 - 256 * sb;
+    }
+    int rc;
+    if ((rc = dev_alloc(&h->d_vecs_u8, bytes.size()))) return rc;
+    if ((rc = dev_alloc(&h->d_rterm, rterm.size()))) return rc;
+    if ((rc = dev_alloc(&h->d_invalid, (size_t)kMaxMulti))) return rc;
+    HIPCHK(hipMemcpy(h->d_vecs_u8, bytes.data(), bytes.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_rterm, rterm.data(), rterm.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    return VS_OK;
+}
+
 void prof_begin(vs_index* h, int which, hipStream_t s) {
     if (!h->prof) return;
     ProfSlot& ps = h->prof_slot[which];
@@ -284,7 +315,7 @@ int pick_kcap(int need) { return need <= 8 ? 8 : (need <= 16 ? 16 : 0); }
 // nb <= kMaxMulti batches of B queries in ONE persistent launch on stream s: scan + exchange + top-k +
 // last-arriver merge, outputs [nb][B][k1].  Consecutive calls on one lane must be stream-ordered.
 int bf_launch(vs_index* h, vs_index::Lane& L, const float* q_dev, int nb, int B, int k1, float* out_d, int32_t* out_i,
-              int32_t* flags, hipStream_t s) {
+              int32_t* flags, hipStream_t s, bool force_f32 = false) {
     const int kcap = pick_kcap(k1);
     if (!kcap) {
         set_error("k too large for the compiled scan kernels (k <= 15)");
@@ -304,8 +335,9 @@ int bf_launch(vs_index* h, vs_index::Lane& L, const float* q_dev, int nb, int B,
     p.dbg = g_dbg;
     int grid, tp;
     scan_geometry(h->n_rows, h->num_cus, grid, tp);
-    // the exchange pays once every wave has a few tiles left after its first three
-    const bool exchange = grid >= 16 && tp >= 6 * vs::kScanWaves && g_xchg_first_it >= 0;
+    // the exchange pays once every wave has a few tiles left after its warm-up tiles (int8 tiles hold 64 rows)
+    const bool u8_path = h->d_vecs_u8 && h->precision != 1 && !force_f32;
+    const bool exchange = grid >= 16 && tp >= (u8_path ? 16 : 6) * vs::kScanWaves && g_xchg_first_it >= 0;
     if (exchange) {
         // 0x7f800000 = +inf
         HIPCHK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(L.slots), 0x7f800000, (size_t)nb * 32 * vs::kSlotStride, s));
@@ -316,6 +348,13 @@ int bf_launch(vs_index* h, vs_index::Lane& L, const float* q_dev, int nb, int B,
     p.tiles_per_wg = tp;
     p.part_d = L.part_d;
     p.part_i = L.part_i;
+    const bool use_u8 = h->d_vecs_u8 && h->precision != 1 && !force_f32;
+    if (use_u8) {
+        p.base_u8 = h->d_vecs_u8;
+        p.rterm = h->d_rterm;
+        p.invalid = h->d_invalid;
+        HIPCHK(hipMemsetAsync(h->d_invalid, 0, (size_t)nb * sizeof(int32_t), s));
+    }
     prof_begin(h, 0, s);
     HIPCHK(vs::launch_scan(p, grid, kcap, nqh, vs::kModeTopK, s));
     prof_end(h, 0, s);
@@ -332,6 +371,7 @@ int bf_launch(vs_index* h, vs_index::Lane& L, const float* q_dev, int nb, int B,
     m.flags = flags;
     m.q_group_out = B;
     m.q_group_in = vs::kMaxBatch;
+    m.invalid = use_u8 ? h->d_invalid : nullptr;
     HIPCHK(vs::launch_merge_layout(m, kcap, (int64_t)vs::kSlotStride * kcap, s));
     return VS_OK;
 }
@@ -573,7 +613,24 @@ int vs_bf_create(const float* base_host, int64_t n_rows, int dim, int metric, in
         free_all(h);
         return rc;
     }
+    if (metric == VS_METRIC_L2 && (rc = build_u8_copy(h, base_host, n_rows))) {
+        free_all(h);
+        return rc;
+    }
     *out = h;
+    return VS_OK;
+}
+
+int vs_set_precision(vs_index* h, int precision) {
+    if (!h || precision < 0 || precision > 2) {
+        set_error("vs_set_precision: 0 = auto, 1 = fp32, 2 = int8");
+        return VS_ERR_INVALID;
+    }
+    if (precision == 2 && !h->d_vecs_u8) {
+        set_error("int8 path unavailable: the base is not integer valued in [0, 255] (or the index is not brute-force L2)");
+        return VS_ERR_UNSUPPORTED;
+    }
+    h->precision = precision;
     return VS_OK;
 }
 
@@ -657,6 +714,25 @@ int vs_bf_search(vs_index* h, const float* queries_host, int64_t nq, int k, int3
         HIPCHK(hipMemcpyAsync(hi.data(), h->d_out_i, (size_t)n * k1 * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipMemcpyAsync(hf.data(), h->d_flags, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
+        bool rerun = false;
+        for (int64_t b = 0; b < n; ++b) rerun = rerun || hf[(size_t)b] == 2;
+        if (rerun) {
+            // a query of this chunk is not an integer in [0, 255]: the int8 scan skipped its batch -> fp32 path
+            if (full) {
+                rc = bf_launch(h, h->lane[0], h->d_q, full, h->batch, k1, h->d_out_d, h->d_out_i, h->d_flags, h->stream, true);
+                if (rc) return rc;
+            }
+            if (rem) {
+                const size_t o = (size_t)full * h->batch;
+                rc = bf_launch(h, h->lane[0], h->d_q + o * vs::kDim, 1, rem, k1, h->d_out_d + o * k1, h->d_out_i + o * k1,
+                               h->d_flags + o, h->stream, true);
+                if (rc) return rc;
+            }
+            HIPCHK(hipMemcpyAsync(hd.data(), h->d_out_d, (size_t)n * k1 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipMemcpyAsync(hi.data(), h->d_out_i, (size_t)n * k1 * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipMemcpyAsync(hf.data(), h->d_flags, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+        }
         double t2 = now_ms();
         tm.h2d_ms += t1 - t0;
         tm.fine_search_ms += t2 - t1;

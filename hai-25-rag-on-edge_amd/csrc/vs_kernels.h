@@ -16,7 +16,10 @@ enum ScanMode { kModeTopK = 0, kModeStore = 1, kModeAssign = 2 };
 
 struct ScanParams {
     const float* base;       // [n_rows][128] row-major (the flat fvecs payload, cpu_baseline.cpp:48-49)
-    const float* bnorm;      // [n_rows (+16 pad)] squared norms (cpu_baseline.cpp:116-125)
+    const float* bnorm;      // [n_rows (+64 pad)] squared norms (cpu_baseline.cpp:116-125)
+    const int8_t* base_u8;   // int8 path: [n_rows][128] bytes (x - 128), or nullptr = fp32 path
+    const int32_t* rterm;    // int8 path: [n_rows (+64 pad)] ||b||^2 - 256 * sum(b - 128)
+    int32_t* invalid;        // int8 path: [n_batches], set to 1 for a batch whose queries are not integers in [0, 255]
     const float* q;          // [n_batches][nq_valid][128] raw queries; rows up to 32 are zero-padded in-kernel (main.cpp:206-211)
     int n_batches;           // query batches served by this one persistent launch (1 for kModeStore)
     int64_t q_batch_stride;  // floats between consecutive batches in q
@@ -60,6 +63,7 @@ struct MergeParams {
     float* tau_out;          // [32] or nullptr: nextafter(kout-th best) used as scan seed
     const int32_t* id_map;   // optional: out id = id_map[id] (IVF reorder_to_original)
     int q_group_out, q_group_in;  // output query q reads input query (q / out) * in + q % out (0 = identity)
+    const int32_t* invalid;  // optional [nq / q_group_out]: batches skipped by the int8 scan -> flags = 2
 };
 hipError_t launch_merge(const MergeParams& p, hipStream_t s);  // scan-partial layout [G][nq_stride][kin]
 // general layout: entry (g, q, j) at g*stride_g + q*stride_q + j

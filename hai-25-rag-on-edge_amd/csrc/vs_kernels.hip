@@ -198,8 +198,16 @@ constexpr int kScanLds = kRingBytes + kQStageBytes + kScratchBytes;  // 153600 <
 #define VS_STAMP(i)
 #endif
 
-template <int NQH, int KCAP, int MODE>
+// PREC = 0: fp32 rows, v_mfma_f32_16x16x4_f32, 16-row tiles.
+// PREC = 1: u8 rows stored as (x - 128) int8, v_mfma_i32_16x16x64_i8, 64-row tiles; exact for integer-valued data in
+//           [0, 255] (SIFT): dist = qterm + rterm - 2 * sum((q-128)(b-128)) in int32, then converted (< 2^24).
+template <int NQH, int KCAP, int MODE, int PREC>
 __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams p) {
+    static_assert(PREC == 0 || MODE == kModeTopK, "the int8 data path only serves the top-k scan");
+    constexpr int TR = PREC ? 64 : kTileRows;  // rows per tile (a slot is 8 KB of rows + 256 B of row terms either way)
+    constexpr int NRG = TR / 16;               // 16-row MFMA blocks per tile
+    constexpr int NKEEP = PREC ? 2 : 3;        // warm-up tiles whose distances are only kept
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* q_s = reinterpret_cast<float*>(smem + kRingBytes);           // [32][128], chunk-swizzled
     float* lds_qn = reinterpret_cast<float*>(smem + kRingBytes + kQStageBytes);  // [32]
@@ -213,7 +221,7 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams 
     VS_STAMP(0);
 
     const int64_t n_rows = p.row_end - p.row_begin;
-    const int tiles_total = (int)((n_rows + kTileRows - 1) / kTileRows);
+    const int tiles_total = (int)((n_rows + TR - 1) / TR);
     // Tiles are dealt round-robin over the workgroups (ticket n of workgroup b is tile b + n*G): while
     // the workgroups run in lock-step (start of every batch) they then read CONSECUTIVE tiles, which
     // spread over all HBM channels.  Contiguous per-workgroup chunks put every workgroup on the same
@@ -244,19 +252,35 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams 
     const int dma_rhalf = lane >> 5;
     const int dma_c = lane & 31;
     auto issue_tile = [&](int tile, int slot) {
-        const int64_t row0 = p.row_begin + (int64_t)tile * kTileRows;
+        const int64_t row0 = p.row_begin + (int64_t)tile * TR;
         char* dst = ring + slot * kSlotBytes;
+        if (PREC == 0) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int row_in = 2 * j + dma_rhalf;
-            const int64_t row = min(row0 + row_in, last_row);  // tail rows re-read the last row, masked below
-            const float* src = p.base + row * kDim + 4 * (dma_c ^ row_in);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, 0, 0);
+            for (int j = 0; j < 8; ++j) {
+                const int row_in = 2 * j + dma_rhalf;
+                const int64_t row = min(row0 + row_in, last_row);  // tail rows re-read the last row, masked below
+                const float* src = p.base + row * kDim + 4 * (dma_c ^ row_in);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, 0, 0);
+            }
+            // norms of rows row0 .. row0+63 (the first 16 are this tile's); bnorm is padded by 64
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.bnorm + row0 + lane),
+                                             (__attribute__((address_space(3))) void*)(dst + 8192), 4, 0, 0);
+        } else {
+            // 128-byte rows: piece j moves rows 8j..8j+7; lane l lands at row 8j + (l >> 3), stored chunk l & 7
+            //   <-  source chunk (l & 7) ^ ((row >> 1) & 7): makes the ds_read_b128 of the A fragments conflict free
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int row_in = 8 * j + (lane >> 3);
+                const int64_t row = min(row0 + row_in, last_row);
+                const int8_t* src = p.base_u8 + row * kDim + 16 * ((lane & 7) ^ ((row_in >> 1) & 7));
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, 0, 0);
+            }
+            // row terms (||b||^2 - 256 * sum(b - 128)) of the tile's 64 rows; rterm is padded by 64
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.rterm + row0 + lane),
+                                             (__attribute__((address_space(3))) void*)(dst + 8192), 4, 0, 0);
         }
-        // norms of rows row0 .. row0+63 (the first 16 are this tile's); bnorm is padded by 64
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.bnorm + row0 + lane),
-                                         (__attribute__((address_space(3))) void*)(dst + kTileRows * kDim * 4), 4, 0, 0);
     };
 
     // Tiles of the workgroup's chunk are handed out through an LDS ticket counter, so a wave that
@@ -308,21 +332,78 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams 
         if (j == 0) lds_qn[row] = sum;
     }
     // query fragments (B operand): qf[h][c][i] = Q[16 h + r][16 c + 4 g + i]
-    f32x4 qf[NQH][8];
+    f32x4 qf[PREC ? 1 : NQH][PREC ? 1 : 8];
+    i32x4 qi8[NQH][2];   // int8 path: bytes (q - 128) of k = 16 g + j and 64 + 16 g + j
+    int qpart[NQH];      // int8 path: this lane's share of sum(q - 128)
+    bool q_ok = true;    // int8 path: every query element is an integer in [0, 255]
+    if (PREC == 0) {
 #pragma unroll
-    for (int h = 0; h < NQH; ++h)
+        for (int h = 0; h < NQH; ++h)
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(q_s + (h * 16 + r) * kDim + 4 * ((4 * c + g) ^ r));
-            qf[h][c] = (h * 16 + r) < p.nq_valid ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int c = 0; c < 8; ++c) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(q_s + (h * 16 + r) * kDim + 4 * ((4 * c + g) ^ r));
+                qf[h][c] = (h * 16 + r) < p.nq_valid ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+    } else {
+#pragma unroll
+        for (int h = 0; h < NQH; ++h) {
+            const bool live = (h * 16 + r) < p.nq_valid;
+            int part = 0;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                i32x4 packed;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {  // 4 floats -> one dword of 4 signed bytes
+                    const int c16 = (half * 16 + 4 * g + w);  // 16-byte float chunk index: k = 4 * c16 .. + 3
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(q_s + (h * 16 + r) * kDim + 4 * (c16 ^ r));
+                    unsigned word = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float x = live ? v[e] : 128.f;  // padding queries become all-zero int8 rows
+                        const int xi = (int)x;
+                        q_ok = q_ok && ((float)xi == x) && xi >= 0 && xi <= 255;
+                        const int sb = xi - 128;
+                        part += sb;
+                        word |= ((unsigned)(sb & 0xff)) << (8 * e);
+                    }
+                    packed[w] = (int)word;
+                }
+                qi8[h][half] = packed;
+            }
+            qpart[h] = part;
         }
+    }
     lds_barrier();
     float qn[NQH], tau[NQH], tq[NQH];
+    int qterm[NQH];
 #pragma unroll
     for (int h = 0; h < NQH; ++h) {
         qn[h] = lds_qn[h * 16 + r];
         tau[h] = VS_INF;
         tq[h] = VS_INF;
+        qterm[h] = 0;
+    }
+    if (PREC == 1) {
+        // sum(q - 128) over the 4 lanes (g = 0..3) that share a query column; qterm = ||q||^2 - 256 sum - 2 * 128 * 128^2
+#pragma unroll
+        for (int h = 0; h < NQH; ++h) {
+            int sq = qpart[h];
+            sq += __shfl_xor(sq, 16);
+            sq += __shfl_xor(sq, 32);
+            qterm[h] = (int)qn[h] - 256 * sq - 4194304;
+        }
+        // a batch with a non-integer query cannot use this path: flag it, skip it (the caller reruns it in fp32)
+        const bool all_ok = __all(q_ok);
+        if (wave == 0 && lane == 0) lds_flag[0] = 1;
+        lds_barrier();
+        if (!all_ok && lane == 0) lds_flag[0] = 0;
+        lds_barrier();
+        if (!lds_flag[0]) {  // workgroup-uniform
+            if (blockIdx.x == 0 && tid == 0 && p.invalid) p.invalid[batch] = 1;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            continue;
+        }
     }
     VS_STAMP(1);
 
@@ -336,50 +417,84 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams 
             li[h][j] = -1;
         }
 
-    // distances of one tile: d[h][j] for query column 16 h + r, base rows 4 g + j
-    auto tile_distances = [&](int tt, int slot, float (&d)[NQH][4]) {
+    // distances of one tile: d[rg][h][j] for query column 16 h + r, base rows 16 rg + 4 g + j
+    auto tile_distances = [&](int tt, int slot, float (&d)[NRG][NQH][4]) {
         const char* src = ring + slot * kSlotBytes;
-        f32x4 a[8];
+        if (PREC == 0) {
+            f32x4 a[8];
 #pragma unroll
-        for (int c = 0; c < 8; ++c)
-            a[c] = *reinterpret_cast<const f32x4*>(src + r * 512 + (((4 * c + g) ^ r) << 4));
-        const f32x4 bn = *reinterpret_cast<const f32x4*>(src + kTileRows * kDim * 4 + 16 * g);
-        f32x4 acc[NQH];
+            for (int c = 0; c < 8; ++c)
+                a[c] = *reinterpret_cast<const f32x4*>(src + r * 512 + (((4 * c + g) ^ r) << 4));
+            const f32x4 bn = *reinterpret_cast<const f32x4*>(src + 8192 + 16 * g);
+            f32x4 acc[NQH];
 #pragma unroll
-        for (int h = 0; h < NQH; ++h) acc[h] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int h = 0; h < NQH; ++h) acc[h] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int c = 0; c < 8; ++c)
+            for (int c = 0; c < 8; ++c)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int h = 0; h < NQH; ++h)
-                    acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][i], qf[h][c][i], acc[h], 0, 0, 0);
-        const int64_t rbase = p.row_begin + (int64_t)tt * kTileRows + 4 * g;  // this lane's first row
+                    for (int h = 0; h < NQH; ++h)
+                        acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][i], qf[h][c][i], acc[h], 0, 0, 0);
+            const int64_t rbase = p.row_begin + (int64_t)tt * TR + 4 * g;  // this lane's first row
 #pragma unroll
-        for (int h = 0; h < NQH; ++h)
+            for (int h = 0; h < NQH; ++h)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                // cpu_baseline.cpp:241  dist = qn + bn - 2*dot  (gcc contracts to fnmadd(2, dot, qn+bn))
-                const float l2 = fmaf(-2.0f, acc[h][j], qn[h] + bn[j]);
-                const float v = p.metric ? -acc[h][j] : l2;
-                d[h][j] = (rbase + j <= last_row) ? v : VS_INF;
+                for (int j = 0; j < 4; ++j) {
+                    // cpu_baseline.cpp:241  dist = qn + bn - 2*dot  (gcc contracts to fnmadd(2, dot, qn+bn))
+                    const float l2 = fmaf(-2.0f, acc[h][j], qn[h] + bn[j]);
+                    const float v = p.metric ? -acc[h][j] : l2;
+                    d[0][h][j] = (rbase + j <= last_row) ? v : VS_INF;
+                }
+        } else {
+#pragma unroll
+            for (int rg = 0; rg < NRG; ++rg) {
+                const int row_in = 16 * rg + r;
+                const int sw = (row_in >> 1) & 7;
+                const i32x4 a0 = *reinterpret_cast<const i32x4*>(src + row_in * 128 + ((g ^ sw) << 4));
+                const i32x4 a1 = *reinterpret_cast<const i32x4*>(src + row_in * 128 + (((4 + g) ^ sw) << 4));
+                const i32x4 rt = *reinterpret_cast<const i32x4*>(src + 8192 + 4 * (16 * rg + 4 * g));
+                const int64_t rbase = p.row_begin + (int64_t)tt * TR + 16 * rg + 4 * g;
+#pragma unroll
+                for (int h = 0; h < NQH; ++h) {
+                    i32x4 acc = (i32x4){0, 0, 0, 0};
+                    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, qi8[h][0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, qi8[h][1], acc, 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        // the same integer the fp32 path computes exactly: ||q||^2 + ||b||^2 - 2 q.b
+                        const int di = qterm[h] + rt[j] - 2 * acc[j];
+                        d[rg][h][j] = (rbase + j <= last_row) ? (float)di : VS_INF;
+                    }
+                }
             }
+        }
     };
-    auto consume = [&](int tt, const float (&d)[NQH][4]) {
-        const int64_t rbase = p.row_begin + (int64_t)tt * kTileRows + 4 * g;
+    auto consume = [&](int tt, const float (&dd)[NRG][NQH][4]) {
+      if (MODE == kModeTopK) {
 #pragma unroll
-        for (int h = 0; h < NQH; ++h) {
-            if (MODE == kModeTopK) {
-                const float dmin = fminf(fminf(d[h][0], d[h][1]), fminf(d[h][2], d[h][3]));
+        for (int rg = 0; rg < NRG; ++rg) {
+            const int64_t rbase = p.row_begin + (int64_t)tt * TR + 16 * rg + 4 * g;
+#pragma unroll
+            for (int h = 0; h < NQH; ++h) {
+                const float dmin = fminf(fminf(dd[rg][h][0], dd[rg][h][1]), fminf(dd[rg][h][2], dd[rg][h][3]));
                 if (dmin < tau[h]) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        if (d[h][j] < tau[h]) {
-                            list_insert<KCAP>(ld[h], li[h], d[h][j], (int)(rbase + j) + p.id_offset);
+                        if (dd[rg][h][j] < tau[h]) {
+                            list_insert<KCAP>(ld[h], li[h], dd[rg][h][j], (int)(rbase + j) + p.id_offset);
                             tau[h] = fminf(tau[h], ld[h][KCAP - 1]);
                         }
                 }
-            } else if (MODE == kModeStore) {
+            }
+        }
+        return;
+      }
+        const float (&d)[NQH][4] = dd[0];
+        const int64_t rbase = p.row_begin + (int64_t)tt * TR + 4 * g;
+#pragma unroll
+        for (int h = 0; h < NQH; ++h) {
+            if (MODE == kModeStore) {
                 const int qidx = h * 16 + r;
                 if (qidx < p.nq_valid) {
                     float* dst = p.store + (int64_t)qidx * p.store_ld + (rbase - p.row_begin);
@@ -436,27 +551,32 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams 
     const bool exchange = MODE == kModeTopK && slots != nullptr;
     int t_cur = t_a, t_nxt = t_b, slot = 0;
     if (exchange) {
-        // ---- warm-up: three tiles per wave whose distances are only kept (no top-k work yet) ----
-        float w0[NQH][4], w1[NQH][4], w2[NQH][4];
-        auto kill = [&](bool dead, float (&w)[NQH][4]) {
+        // ---- warm-up: NKEEP tiles per wave whose distances are only kept (no top-k work yet) ----
+        float wk[NKEEP][NRG][NQH][4];
+        auto kill = [&](bool dead, float (&w)[NRG][NQH][4]) {
             if (dead) {
 #pragma unroll
-                for (int h = 0; h < NQH; ++h)
+                for (int rg = 0; rg < NRG; ++rg)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) w[h][j] = VS_INF;
+                    for (int h = 0; h < NQH; ++h)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) w[rg][h][j] = VS_INF;
             }
         };
         asm volatile("s_waitcnt vmcnt(9)" ::: "memory");  // A landed (B follows)
         VS_STAMP(11);
-        tile_distances(min(t_a, tlast), 0, w0);
+        tile_distances(min(t_a, tlast), 0, wk[0]);
         VS_STAMP(12);
-        kill(t_a >= tile1, w0);
+        kill(t_a >= tile1, wk[0]);
         const int t_c = next_ticket();
         issue_tile(min(t_c, tlast), 0);  // queue: B C
         // publish this workgroup's per-query minimum (distinct workgroups hold distinct rows)
 #pragma unroll
         for (int h = 0; h < NQH; ++h) {
-            float m = fminf(fminf(w0[h][0], w0[h][1]), fminf(w0[h][2], w0[h][3]));
+            float m = VS_INF;
+#pragma unroll
+            for (int rg = 0; rg < NRG; ++rg)
+                m = fminf(m, fminf(fminf(wk[0][rg][h][0], wk[0][rg][h][1]), fminf(wk[0][rg][h][2], wk[0][rg][h][3])));
             m = fminf(m, __shfl_xor(m, 16));
             m = fminf(m, __shfl_xor(m, 32));
             if (g == 0) lds_wmin[wave * 32 + h * 16 + r] = m;
@@ -471,8 +591,8 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams 
         }
         VS_STAMP(2);
         asm volatile("s_waitcnt vmcnt(9)" ::: "memory");  // B landed (C, and on wave 1 the store, follow)
-        tile_distances(min(t_b, tlast), 1, w1);
-        kill(t_b >= tile1, w1);
+        tile_distances(min(t_b, tlast), 1, wk[1]);
+        kill(t_b >= tile1, wk[1]);
         VS_STAMP(7);
         // DPP row `g` of wave w will reduce query 4w+g: its 16 lanes read that query's 1 KB row of
         // minima (write-through-coherent sc1 loads, 64 contiguous bytes per lane = workgroups
@@ -491,14 +611,19 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams 
         }
         const int t_d = next_ticket();
         issue_tile(min(t_d, tlast), 1);  // queue: C loads(4) D
-        asm volatile("s_waitcnt vmcnt(13)" ::: "memory");  // C landed
-        VS_STAMP(9);
-        tile_distances(min(t_c, tlast), 0, w2);
-        kill(t_c >= tile1, w2);
-        VS_STAMP(8);
-        const int t_e = next_ticket();
-        issue_tile(min(t_e, tlast), 0);  // queue: loads(4) D E
-        asm volatile("s_waitcnt vmcnt(18)" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3)::"memory");  // the minima are here
+        int t_e = t_d;
+        if (NKEEP == 3) {
+            asm volatile("s_waitcnt vmcnt(13)" ::: "memory");  // C landed
+            VS_STAMP(9);
+            tile_distances(min(t_c, tlast), 0, wk[NKEEP - 1]);
+            kill(t_c >= tile1, wk[NKEEP - 1]);
+            VS_STAMP(8);
+            t_e = next_ticket();
+            issue_tile(min(t_e, tlast), 0);  // queue: loads(4) D E
+            asm volatile("s_waitcnt vmcnt(18)" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3)::"memory");  // the minima are here
+        } else {
+            asm volatile("s_waitcnt vmcnt(9)" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3)::"memory");  // minima (and C) are here
+        }
         VS_STAMP(10);
         {
             // Each lane folds its 16 workgroups into one minimum; the k1-th smallest of the row's
@@ -527,17 +652,23 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams 
         }
         VS_STAMP(3);
         // replay the kept tiles against the bound (almost nothing passes)
-        consume(min(t_a, tlast), w0);
-        consume(min(t_b, tlast), w1);
-        consume(min(t_c, tlast), w2);
-        t_cur = t_d;
-        t_nxt = t_e;
-        slot = 1;
+        consume(min(t_a, tlast), wk[0]);
+        consume(min(t_b, tlast), wk[1]);
+        if (NKEEP == 3) {
+            consume(min(t_c, tlast), wk[NKEEP - 1]);
+            t_cur = t_d;  // slot 1
+            t_nxt = t_e;  // slot 0
+            slot = 1;
+        } else {
+            t_cur = t_c;  // slot 0
+            t_nxt = t_d;  // slot 1
+            slot = 0;
+        }
     }
     // ---- steady state: t_cur sits in `slot` (landed or landing), t_nxt in the other slot ----
     while (t_cur < tile1) {
         asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-        float d[NQH][4];
+        float d[NRG][NQH][4];
         tile_distances(t_cur, slot, d);
         consume(t_cur, d);
         t_cur = t_nxt;
@@ -620,9 +751,9 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams 
     VS_STAMP(6);
 }
 
-template <int NQH, int KCAP, int MODE>
+template <int NQH, int KCAP, int MODE, int PREC = 0>
 static hipError_t launch_scan_t(const ScanParams& p, int grid, hipStream_t s) {
-    auto kfn = scan_kernel<NQH, KCAP, MODE>;
+    auto kfn = scan_kernel<NQH, KCAP, MODE, PREC>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
@@ -635,6 +766,11 @@ static hipError_t launch_scan_t(const ScanParams& p, int grid, hipStream_t s) {
 }
 
 hipError_t launch_scan(const ScanParams& p, int grid, int kcap, int nqh, int mode, hipStream_t s) {
+    if (mode == kModeTopK && p.base_u8) {  // int8 data path
+        if (kcap == 8) return nqh == 1 ? launch_scan_t<1, 8, kModeTopK, 1>(p, grid, s) : launch_scan_t<2, 8, kModeTopK, 1>(p, grid, s);
+        if (kcap == 16) return nqh == 1 ? launch_scan_t<1, 16, kModeTopK, 1>(p, grid, s) : launch_scan_t<2, 16, kModeTopK, 1>(p, grid, s);
+        return hipErrorInvalidValue;
+    }
     if (mode == kModeAssign) return launch_scan_t<2, 8, kModeAssign>(p, grid, s);
     if (mode == kModeStore) {
         return nqh == 1 ? launch_scan_t<1, 8, kModeStore>(p, grid, s) : launch_scan_t<2, 8, kModeStore>(p, grid, s);
@@ -820,6 +956,15 @@ __global__ __launch_bounds__(256) void merge_compact_kernel(const MergeParams p,
     const int q_in = p.q_group_out > 0 ? (q / p.q_group_out) * p.q_group_in + (q % p.q_group_out) : q;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
+    if (p.invalid && p.q_group_out > 0 && p.invalid[q / p.q_group_out]) {
+        // the int8 scan skipped this batch (a query was not an integer in [0, 255]): tell the caller to rerun it
+        for (int t = tid; t < p.kout; t += 256) {
+            if (p.out_d) p.out_d[(int64_t)q * p.kout + t] = VS_INF;
+            if (p.out_i) p.out_i[(int64_t)q * p.kout + t] = -1;
+        }
+        if (tid == 0 && p.flags) p.flags[q] = 2;
+        return;
+    }
     if (tid == 0) cnt = 0;
     __syncthreads();
     for (int g = tid; g < p.G; g += 256) {

@@ -107,6 +107,14 @@ VS_API int vs_bf_create(const float* base_host, int64_t n_rows, int dim, int met
  * zero-padded (main.cpp:206-211). */
 VS_API int vs_set_batch(vs_index* h, int batch);
 
+/* Data path of the scan.  0 = auto (default): when every base value is an integer in [0, 255] -- true for
+ * SIFT -- the index also keeps the rows as bytes and scans them with int8 MFMA; distances are then
+ * computed in int32 and are the same integers the fp32 path produces exactly, at a quarter of the memory
+ * traffic.  A batch containing a non-integer query is detected on the device, skipped and rerun in fp32
+ * (vs_bf_search does that itself; the *_dev calls report it as flags == 2).  1 = force fp32 (the reference
+ * arithmetic, cblas_sgemm + epilogue); 2 = require int8 (VS_ERR_UNSUPPORTED when the base does not allow it). */
+VS_API int vs_set_precision(vs_index* h, int precision);
+
 /* Host-buffer search with the reference's exact semantics: ids/dists are
  * [nq x k], ascending distance, ties ordered exactly as select_topk leaves
  * them (flagged queries are re-resolved, see DESIGN.md "Ties").  k clamps to
@@ -116,8 +124,9 @@ VS_API int vs_bf_search(vs_index* h, const float* queries_host, int64_t nq, int 
 
 /* Device-level, asynchronous on `stream`: one batch (B <= batch) of queries
  * already in HBM -> the k+1 best (dist, id) per query by (dist, id) ascending,
- * [B x (k+1)], plus flags[B] != 0 where two of those distances are equal (the
- * caller must then use vs_bf_search for reference tie order).  This is the
+ * [B x (k+1)], plus flags[B]: 1 where two of those distances are equal (the
+ * caller must then use vs_bf_search for reference tie order), 2 where the int8
+ * path had to skip the batch (rerun with vs_set_precision(h, 1)).  This is the
  * analogue of QnnRunner::executeBatchRaw + getRawOutputBuffer (QnnRunner.h:28-30)
  * with the top-k fused in, so the B x N score matrix never exists. */
 VS_API int vs_bf_search_dev(vs_index* h, const float* queries_dev, int B, int k,

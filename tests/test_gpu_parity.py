@@ -18,13 +18,17 @@ def _int_data(rng, n, nq, hi=219):
 
 
 def _check_exact(pkg, base, q, k, batch=None):
+    """Both data paths: precision 1 = fp32 rows + fp32 MFMA (the reference arithmetic), 0 = auto, which
+    scans integer-valued bases as bytes with int8 MFMA.  Both must reproduce the oracle bit for bit."""
+    oi, od = oracle.search_bf(base, q, k)
     with pkg.BruteForceIndex(base) as idx:
         if batch:
             idx.set_batch(batch)
-        ids, d = idx.search(q, k)
-    oi, od = oracle.search_bf(base, q, k)
-    assert np.array_equal(ids, oi), f"ids differ (N={len(base)}, nq={len(q)}, k={k}, batch={batch})"
-    assert np.array_equal(d, od)
+        for precision in (1, 0):
+            idx.set_precision(precision)
+            ids, d = idx.search(q, k)
+            assert np.array_equal(ids, oi), f"ids differ (N={len(base)}, nq={len(q)}, k={k}, batch={batch}, precision={precision})"
+            assert np.array_equal(d, od), f"dists differ (precision={precision})"
 
 
 @pytest.mark.parametrize("tag", ["fwd", "rev"])
@@ -109,6 +113,49 @@ def test_seeded_large_base_exact(gpu_pkg):
     q[4] = base[17]
     _check_exact(gpu_pkg, base, q, 5)
     _check_exact(gpu_pkg, base, q[:5], 10)
+
+
+def test_int8_path_selection_and_fallback(gpu_pkg):
+    import torch
+    rng = np.random.default_rng(11)
+    base, q = _int_data(rng, 20000, 40)
+    base[:, 5] = 255.0  # exercise the top of the byte range
+    base[7] = 0.0
+    q[3] = 255.0
+    oi, od = oracle.search_bf(base, q, 5)
+    with gpu_pkg.BruteForceIndex(base) as idx:
+        idx.set_precision(2)  # int8 required: available for integer data in [0, 255]
+        ids, d = idx.search(q, 5)
+        assert np.array_equal(ids, oi) and np.array_equal(d, od)
+        # a non-integer query in a batch: the device flags the batch (2) and vs_bf_search reruns it in fp32
+        q2 = q.copy()
+        q2[17, 3] += 0.5
+        o2i, o2d = oracle.search_bf(base, q2, 5)
+        idx.set_precision(0)
+        ids2, d2 = idx.search(q2, 5)
+        assert np.array_equal(ids2, o2i) and np.allclose(d2, o2d, rtol=0, atol=1e-2)
+        dev = torch.device("cuda:0")
+        qd = torch.from_numpy(q2[:32]).to(dev)
+        oid = torch.zeros((32, 6), dtype=torch.int32, device=dev)
+        odd = torch.zeros((32, 6), dtype=torch.float32, device=dev)
+        fl = torch.zeros((32,), dtype=torch.int32, device=dev)
+        idx.search_dev(qd.data_ptr(), 32, 5, oid.data_ptr(), odd.data_ptr(), fl.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert (fl.cpu().numpy() == 2).all() and (oid.cpu().numpy() == -1).all()
+        # out-of-range query values take the same route
+        q3 = q.copy()
+        q3[0, 0] = 300.0
+        o3i, o3d = oracle.search_bf(base, q3, 5)
+        ids3, d3 = idx.search(q3, 5)
+        assert np.array_equal(ids3, o3i) and np.array_equal(d3, o3d)
+    # a base that is not byte valued has no int8 copy
+    with gpu_pkg.BruteForceIndex(base + 0.25) as idx:
+        with pytest.raises(gpu_pkg.VSearchError) as e:
+            idx.set_precision(2)
+        assert e.value.status == -5
+    with gpu_pkg.BruteForceIndex(base * 2.0) as idx:  # integers, but up to 436 > 255
+        with pytest.raises(gpu_pkg.VSearchError):
+            idx.set_precision(2)
 
 
 def test_non_integer_data_within_tolerance(gpu_pkg):
