@@ -324,10 +324,27 @@ def main():
                     "avg_candidates": avg_cand,
                     "scan_kernel_us": round(ikern_ms / max(ikern_n, 1) * 1e3, 2)}
         if avg_cand:
-            ib = (4 * DIM + 8) * avg_cand * BATCH  # (4d + 4 + 4) * S_q per query
+            # The list-major scan reads every probed list ONCE per batch, so its algorithmic bytes are
+            # (4d + 4) * rows of the distinct lists probed by the batch (+ 4 B per (query, row) score written),
+            # not SURVEY 8(d)'s per-query (4d + 8) * S_q, which assumes one pass per query.
+            cn = (cents_h.astype(np.float64) ** 2).sum(1)
+            uniq_rows, nb_s = 0, 8
+            for b0 in range(nb_s):
+                qs = queries[b0 * BATCH:(b0 + 1) * BATCH].astype(np.float64)
+                pr = np.argsort(cn[None, :] - 2.0 * qs @ cents_h.astype(np.float64).T, axis=1)[:, :NPROBE]
+                uniq_rows += int(sizes[np.unique(pr)].sum())
+            uniq_rows /= nb_s
+            ib = (4 * DIM + 4) * uniq_rows + 4 * avg_cand * BATCH
             ks = ikern_ms / max(ikern_n, 1) * 1e-3
+            itraffic = None
+            ipath = os.path.join(ROOT, "profiles", "traffic_ivf_list_scan.json")
+            if os.path.exists(ipath) and n_rows == N_BASE:
+                itraffic = json.load(open(ipath)).get("hbm_bytes_per_launch")
             ivf_info["roofline"] = {"bound": "hbm", "achieved": round(ib / ks / 1e9, 1), "peak": HBM_PEAK_GBS,
-                                    "unit": "GB/s", "frac": round(ib / ks / 1e9 / HBM_PEAK_GBS, 4), "traffic": None}
+                                    "unit": "GB/s", "frac": round(ib / ks / 1e9 / HBM_PEAK_GBS, 4), "traffic": itraffic,
+                                    "kernel": "vs::ivf_list_scan_kernel", "algorithmic_bytes_per_launch": int(ib),
+                                    "distinct_rows_per_batch": int(uniq_rows),
+                                    "per_query_pass_bytes": int((4 * DIM + 8) * avg_cand * BATCH)}
         log(f"IVF: {ivf_qps:.0f} QPS, recall@1={rec1}, recall@5={rec5}, avg candidates={avg_cand}")
         ivf.close()
 
@@ -335,10 +352,11 @@ def main():
     cpu_info = None
     if world == 1 and rank == 0 and not args.no_cpu:
         import oracle
+        oracle.search_bf(shard, queries[:2], K)  # thread pool + page-in warm-up
         tq = time.perf_counter()
-        oracle.search_bf(shard, queries[:4], K)
-        per_q = (time.perf_counter() - tq) / 4
-        nq_cpu = int(min(n_queries, max(8, 12.0 / max(per_q, 1e-4))))
+        oracle.search_bf(shard, queries[:8], K)
+        per_q = (time.perf_counter() - tq) / 8
+        nq_cpu = int(min(2048, max(16, 15.0 / max(per_q, 1e-4))))  # ~15 s of CPU work
         tm = {}
         tq = time.perf_counter()
         cid, cd = oracle.search_bf(shard, queries[:nq_cpu], K, tm)
