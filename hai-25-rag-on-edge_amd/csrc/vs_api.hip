@@ -245,7 +245,8 @@ int alloc_scratch(vs_index* h) {
 // upload `rows x dim` floats in chunks through the default pageable path and compute norms
 int upload_vectors(vs_index* h, const float* host, int64_t rows) {
     int rc;
-    if ((rc = dev_alloc(&h->d_vecs, (size_t)std::max<int64_t>(rows, 1) * vs::kDim))) return rc;
+    if ((rc = dev_alloc(&h->d_vecs, ((size_t)std::max<int64_t>(rows, 1) + vs::kScanPadRows) * vs::kDim))) return rc;
+    HIPCHK(hipMemset(h->d_vecs + (size_t)std::max<int64_t>(rows, 1) * vs::kDim, 0, (size_t)vs::kScanPadRows * vs::kDim * sizeof(float)));
     if ((rc = dev_alloc(&h->d_norm, (size_t)rows + 64))) return rc;
     HIPCHK(hipMemset(h->d_norm, 0, ((size_t)rows + 64) * sizeof(float)));
     if (rows > 0) {
@@ -259,7 +260,7 @@ int upload_vectors(vs_index* h, const float* host, int64_t rows) {
 // int8 copy of the base when it is exactly representable: bytes (x - 128) and the per-row term
 // ||b||^2 - 256 * sum(b - 128); dist = [||q||^2 - 256 sum(q-128) - 2*128^3] + rterm - 2 * sum((q-128)(b-128)).
 int build_u8_copy(vs_index* h, const float* host, int64_t rows) {
-    std::vector<int8_t> bytes((size_t)rows * vs::kDim);
+    std::vector<int8_t> bytes(((size_t)rows + vs::kScanPadRows) * vs::kDim, 0);  // spare rows: tile DMAs are not clamped
     std::vector<int32_t> rterm((size_t)rows + 64, 0);
     for (int64_t i = 0; i < rows; ++i) {
         int32_t n2 = 0, sb = 0;
@@ -308,6 +309,15 @@ int g_xchg_first_it = [] {
 }();
 
 int* g_dbg = nullptr;
+// tuning knobs: VSEARCH_STAGGER_US (spread of the workgroup start phases), VSEARCH_STAGGER_PH (number of phases)
+int g_stagger_us = [] {
+    const char* e = getenv("VSEARCH_STAGGER_US");
+    return e ? atoi(e) : 0;
+}();
+int g_stagger_ph = [] {
+    const char* e = getenv("VSEARCH_STAGGER_PH");
+    return e ? atoi(e) : 4;
+}();
 
 
 int pick_kcap(int need) { return need <= 8 ? 8 : (need <= 16 ? 16 : 0); }
@@ -342,6 +352,10 @@ int bf_launch(vs_index* h, vs_index::Lane& L, const float* q_dev, int nb, int B,
         // 0x7f800000 = +inf
         HIPCHK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(L.slots), 0x7f800000, (size_t)nb * 32 * vs::kSlotStride, s));
         p.slots_cur = L.slots;
+    }
+    if (exchange && nb >= 4 && g_stagger_us > 0) {
+        p.stagger_ticks = g_stagger_us * 100;
+        p.stagger_phases = g_stagger_ph;
     }
     p.row_begin = 0;
     p.row_end = h->n_rows;
@@ -865,7 +879,8 @@ static int ivf_create_impl(const float* vectors, int64_t n_rows, int dim, const 
         return code;
     };
     if ((rc = upload_vectors(h, up, n_local))) return fail(rc);
-    if ((rc = dev_alloc(&h->d_centroids, (size_t)nlist * dim))) return fail(rc);
+    if ((rc = dev_alloc(&h->d_centroids, ((size_t)nlist + vs::kScanPadRows) * dim))) return fail(rc);
+    if (hipMemset(h->d_centroids + (size_t)nlist * dim, 0, (size_t)vs::kScanPadRows * dim * sizeof(float)) != hipSuccess) return fail(VS_ERR_DEVICE);
     if ((rc = dev_alloc(&h->d_cnorm, (size_t)nlist + 64))) return fail(rc);
     if ((rc = dev_alloc(&h->d_offsets, (size_t)nlist + 1))) return fail(rc);
     if ((rc = dev_alloc(&h->d_r2o, (size_t)std::max<int64_t>(n_local, 1)))) return fail(rc);
@@ -948,7 +963,8 @@ int vs_ivf_build(const float* base_host, int64_t n_rows, int dim, int nlist, int
         }                                                                              \
     } while (0)
     const int nlist_pad = (nlist + 31) & ~31;
-    BUILD_CHK(hipMalloc(&d_x, (size_t)n_rows * dim * sizeof(float)));
+    BUILD_CHK(hipMalloc(&d_x, ((size_t)n_rows + vs::kScanPadRows) * dim * sizeof(float)));
+    BUILD_CHK(hipMemset(d_x + (size_t)n_rows * dim, 0, (size_t)vs::kScanPadRows * dim * sizeof(float)));
     BUILD_CHK(hipMalloc(&d_norm, ((size_t)n_rows + 64) * sizeof(float)));
     BUILD_CHK(hipMalloc(&d_cents, (size_t)nlist_pad * dim * sizeof(float)));
     BUILD_CHK(hipMalloc(&d_best_d, (size_t)n_rows * sizeof(float)));

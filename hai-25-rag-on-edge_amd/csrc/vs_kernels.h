@@ -10,6 +10,7 @@ constexpr int kTileRows = 16;      // base rows per MFMA tile (v_mfma_f32_16x16x
 constexpr int kScanThreads = 512;  // 8 waves: 2 per SIMD
 constexpr int kScanWaves = 8;
 constexpr int kMaxBatch = 32;      // queries per scan pass (two 16-query MFMA column blocks)
+constexpr int kScanPadRows = 64;  // every row array handed to the scan is allocated with this many spare rows (tile DMAs are not clamped)
 constexpr int kSlotStride = 256;   // threshold-exchange slots: [32 queries][256 workgroups]
 
 enum ScanMode { kModeTopK = 0, kModeStore = 1, kModeAssign = 2 };
@@ -26,7 +27,8 @@ struct ScanParams {
     float* slots_cur;        // [n_batches][32][kSlotStride] per-workgroup minima (pre-set to +inf) or nullptr = no exchange
     int k1;                  // the exchange bounds the k1-th best distance; also entries kept per partial list
     int* dbg;                // optional debug counters [grid][16]
-    int xchg_first_it;       // first loop iteration (2 tiles per wave each) at which the exchange is attempted
+    int stagger_ticks;       // multi-batch top-k scan: start phases of the workgroups are spread over this many 10 ns ticks
+    int stagger_phases;      // number of distinct start phases (0/1 = none)
     int64_t row_begin;       // multiple of 16
     int64_t row_end;         // exclusive
     int tiles_per_wg;

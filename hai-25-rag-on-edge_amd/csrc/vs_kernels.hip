@@ -194,13 +194,22 @@ constexpr int kScanLds = kRingBytes + kQStageBytes + kScratchBytes;  // 153600 <
         if (p.dbg && threadIdx.x == 0)                                                                 \
             p.dbg[blockIdx.x * 16 + (i)] = (int)(__builtin_amdgcn_s_memrealtime() & 0x7fffffff);       \
     } while (0)
+#define VS_STAMPC(i)                                                                                   \
+    do {                                                                                               \
+        if (p.dbg && threadIdx.x == 0)                                                                 \
+            p.dbg[blockIdx.x * 16 + (i)] = (int)(__builtin_amdgcn_s_memtime() & 0x7fffffff);           \
+    } while (0)
 #else
 #define VS_STAMP(i)
+#define VS_STAMPC(i)
 #endif
 
 // PREC = 0: fp32 rows, v_mfma_f32_16x16x4_f32, 16-row tiles.
 // PREC = 1: u8 rows stored as (x - 128) int8, v_mfma_i32_16x16x64_i8, 64-row tiles; exact for integer-valued data in
 //           [0, 255] (SIFT): dist = qterm + rterm - 2 * sum((q-128)(b-128)) in int32, then converted (< 2^24).
+#ifndef VS_ROW_CPOL
+#define VS_ROW_CPOL 2  // nt: the rows are streamed once per batch and 512 MB never fits a cache
+#endif
 template <int NQH, int KCAP, int MODE, int PREC>
 __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams p) {
     static_assert(PREC == 0 || MODE == kModeTopK, "the int8 data path only serves the top-k scan");
@@ -235,6 +244,14 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams 
     // One persistent launch serves n_batches query batches back to back.  Workgroups are never
     // synchronised with each other, so they drift apart and one workgroup's latency-bound batch
     // start-up (query staging, first tiles, exchange) overlaps the others' streaming: HBM stays busy.
+    if (MODE == kModeTopK && p.stagger_phases > 1) {
+        // Every workgroup has the same work per batch, so they would otherwise stay in lock-step and all be in
+        // their low-bandwidth phase (query staging, warm-up tiles, exchange, merge) at the same moments.
+        const int phase = (blockIdx.x >> 3) % p.stagger_phases;  // blockIdx & 7 = XCD: every XCD gets every phase
+        const long long wait = (long long)p.stagger_ticks * phase / p.stagger_phases;
+        const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
+        while ((long long)__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+    }
 #pragma clang loop unroll(disable)
     for (int batch = 0; batch < p.n_batches; ++batch) {
     // Lane-derived values are re-derived per batch from an opaque copy: otherwise hipcc hoists dozens
@@ -247,40 +264,46 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams 
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
     char* ring = smem + wave * (kDepth * kSlotBytes);
-    // DMA source mapping: piece j (0..7) writes LDS chunks [64 j, 64 j + 64) of the slot; lane l
-    // lands at row 2 j + (l >> 5), stored chunk (l & 31)  <-  source chunk (l & 31) ^ row
-    const int dma_rhalf = lane >> 5;
-    const int dma_c = lane & 31;
-    auto issue_tile = [&](int tile, int slot) {
+    // DMA source mapping: piece j (0..7) writes LDS chunks [64 j, 64 j + 64) of the slot.
+    //   fp32: lane l lands at row 2 j + (l >> 5), stored chunk (l & 31)  <-  source chunk (l & 31) ^ row
+    //   int8: 128-byte rows, piece j moves rows 8j..8j+7; lane l lands at row 8j + (l >> 3), stored chunk l & 7
+    //         <-  source chunk (l & 7) ^ ((row >> 1) & 7)
+    // (the XOR makes the ds_read_b128 of the A fragments conflict free).  The per-lane byte offsets inside a
+    // tile are fixed, so a DMA is "scalar tile base + 32-bit lane offset" with no address arithmetic in the
+    // loop: while the other wave of the SIMD streams MFMAs, every extra VALU instruction here costs about one
+    // MFMA slot.  Rows past row_end are fetched unclamped (every row array has kScanPadRows spare rows) and
+    // masked in the epilogue of the last tile.
+    unsigned voff[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if (PREC == 0) {
+            const int row_in = 2 * j + (lane >> 5);
+            voff[j] = (unsigned)(row_in * 512 + 16 * ((lane & 31) ^ row_in));
+        } else {
+            const int row_in = 8 * j + (lane >> 3);
+            voff[j] = (unsigned)(row_in * 128 + 16 * ((lane & 7) ^ ((row_in >> 1) & 7)));
+        }
+    }
+    const unsigned voff_n = (unsigned)lane * 4u;
+    auto issue_tile = [&](int tile, int slot) __attribute__((always_inline)) {
         const int64_t row0 = p.row_begin + (int64_t)tile * TR;
         char* dst = ring + slot * kSlotBytes;
-        if (PREC == 0) {
+        const char* tb = PREC ? reinterpret_cast<const char*>(p.base_u8) + row0 * kDim
+                              : reinterpret_cast<const char*>(p.base) + row0 * (kDim * 4);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int row_in = 2 * j + dma_rhalf;
-                const int64_t row = min(row0 + row_in, last_row);  // tail rows re-read the last row, masked below
-                const float* src = p.base + row * kDim + 4 * (dma_c ^ row_in);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, 0, 0);
-            }
-            // norms of rows row0 .. row0+63 (the first 16 are this tile's); bnorm is padded by 64
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.bnorm + row0 + lane),
-                                             (__attribute__((address_space(3))) void*)(dst + 8192), 4, 0, 0);
-        } else {
-            // 128-byte rows: piece j moves rows 8j..8j+7; lane l lands at row 8j + (l >> 3), stored chunk l & 7
-            //   <-  source chunk (l & 7) ^ ((row >> 1) & 7): makes the ds_read_b128 of the A fragments conflict free
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int row_in = 8 * j + (lane >> 3);
-                const int64_t row = min(row0 + row_in, last_row);
-                const int8_t* src = p.base_u8 + row * kDim + 16 * ((lane & 7) ^ ((row_in >> 1) & 7));
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, 0, 0);
-            }
-            // row terms (||b||^2 - 256 * sum(b - 128)) of the tile's 64 rows; rterm is padded by 64
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.rterm + row0 + lane),
-                                             (__attribute__((address_space(3))) void*)(dst + 8192), 4, 0, 0);
+        for (int j = 0; j < 8; ++j) {
+            unsigned vo = voff[j];
+            asm volatile("" : "+v"(vo));  // keep the zero-extension here: "scalar base + 32-bit lane offset" addressing
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tb + vo),
+                                             (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, 0,
+                                             PREC ? 0 : VS_ROW_CPOL);
         }
+        // norms (fp32) / row terms (int8) of rows row0 .. row0+63; both arrays are padded by 64
+        const char* nb = PREC ? reinterpret_cast<const char*>(p.rterm + row0) : reinterpret_cast<const char*>(p.bnorm + row0);
+        unsigned vn = voff_n;
+        asm volatile("" : "+v"(vn));
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(nb + vn),
+                                         (__attribute__((address_space(3))) void*)(dst + 8192), 4, 0, 0);
     };
 
     // Tiles of the workgroup's chunk are handed out through an LDS ticket counter, so a wave that
@@ -418,14 +441,28 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams 
         }
 
     // distances of one tile: d[rg][h][j] for query column 16 h + r, base rows 16 rg + 4 g + j
-    auto tile_distances = [&](int tt, int slot, float (&d)[NRG][NQH][4]) {
-        const char* src = ring + slot * kSlotBytes;
+    // LDS byte offsets of this lane's A fragments inside slot 0 of its wave's ring (slot 1: + kSlotBytes, an
+    // immediate once the slot is a compile-time constant): no address arithmetic in the loop
+    unsigned fa[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        if (PREC == 0) {
+            fa[c] = (unsigned)(wave * (kDepth * kSlotBytes) + r * 512 + (((4 * c + g) ^ r) << 4));
+        } else {
+            // c = 2 rg + half: row 16 rg + r, chunk (4 half + g) ^ ((row >> 1) & 7)
+            const int row_in = 16 * (c >> 1) + r;
+            fa[c] = (unsigned)(wave * (kDepth * kSlotBytes) + row_in * 128 + ((((c & 1) * 4 + g) ^ ((row_in >> 1) & 7)) << 4));
+        }
+    }
+    const unsigned fa_n = (unsigned)(wave * (kDepth * kSlotBytes) + 8192 + 16 * g);  // norms / row terms of rows 4g..4g+3 (+16 rg)
+    // distances of one tile: d[rg][h][j] for query column 16 h + r, base rows 16 rg + 4 g + j
+    auto tile_distances = [&](int tt, int slot, float (&d)[NRG][NQH][4]) __attribute__((always_inline)) {
+        const char* src = smem + slot * kSlotBytes;
         if (PREC == 0) {
             f32x4 a[8];
 #pragma unroll
-            for (int c = 0; c < 8; ++c)
-                a[c] = *reinterpret_cast<const f32x4*>(src + r * 512 + (((4 * c + g) ^ r) << 4));
-            const f32x4 bn = *reinterpret_cast<const f32x4*>(src + 8192 + 16 * g);
+            for (int c = 0; c < 8; ++c) a[c] = *reinterpret_cast<const f32x4*>(src + fa[c]);
+            const f32x4 bn = *reinterpret_cast<const f32x4*>(src + fa_n);
             f32x4 acc[NQH];
 #pragma unroll
             for (int h = 0; h < NQH; ++h) acc[h] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -436,37 +473,50 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams 
 #pragma unroll
                     for (int h = 0; h < NQH; ++h)
                         acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][i], qf[h][c][i], acc[h], 0, 0, 0);
-            const int64_t rbase = p.row_begin + (int64_t)tt * TR + 4 * g;  // this lane's first row
+            // all nine LDS reads first, then the MFMA stream (the waits become counted lgkmcnt(N))
+            __builtin_amdgcn_sched_group_barrier(0x100, 9, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 32 * NQH, 0);
 #pragma unroll
             for (int h = 0; h < NQH; ++h)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     // cpu_baseline.cpp:241  dist = qn + bn - 2*dot  (gcc contracts to fnmadd(2, dot, qn+bn))
                     const float l2 = fmaf(-2.0f, acc[h][j], qn[h] + bn[j]);
-                    const float v = p.metric ? -acc[h][j] : l2;
-                    d[0][h][j] = (rbase + j <= last_row) ? v : VS_INF;
+                    d[0][h][j] = p.metric ? -acc[h][j] : l2;
                 }
         } else {
+            i32x4 a0[NRG], a1[NRG], rtv[NRG];
 #pragma unroll
             for (int rg = 0; rg < NRG; ++rg) {
-                const int row_in = 16 * rg + r;
-                const int sw = (row_in >> 1) & 7;
-                const i32x4 a0 = *reinterpret_cast<const i32x4*>(src + row_in * 128 + ((g ^ sw) << 4));
-                const i32x4 a1 = *reinterpret_cast<const i32x4*>(src + row_in * 128 + (((4 + g) ^ sw) << 4));
-                const i32x4 rt = *reinterpret_cast<const i32x4*>(src + 8192 + 4 * (16 * rg + 4 * g));
-                const int64_t rbase = p.row_begin + (int64_t)tt * TR + 16 * rg + 4 * g;
+                a0[rg] = *reinterpret_cast<const i32x4*>(src + fa[2 * rg]);
+                a1[rg] = *reinterpret_cast<const i32x4*>(src + fa[2 * rg + 1]);
+                rtv[rg] = *reinterpret_cast<const i32x4*>(src + fa_n + 64 * rg);
+            }
+#pragma unroll
+            for (int rg = 0; rg < NRG; ++rg) {
 #pragma unroll
                 for (int h = 0; h < NQH; ++h) {
                     i32x4 acc = (i32x4){0, 0, 0, 0};
-                    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, qi8[h][0], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, qi8[h][1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0[rg], qi8[h][0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1[rg], qi8[h][1], acc, 0, 0, 0);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         // the same integer the fp32 path computes exactly: ||q||^2 + ||b||^2 - 2 q.b
-                        const int di = qterm[h] + rt[j] - 2 * acc[j];
-                        d[rg][h][j] = (rbase + j <= last_row) ? (float)di : VS_INF;
+                        const int di = qterm[h] + rtv[rg][j] - 2 * acc[j];
+                        d[rg][h][j] = (float)di;
                     }
                 }
+            }
+        }
+        if (tt >= tlast) {  // only the last tile can hold rows past row_end (wave-uniform branch)
+#pragma unroll
+            for (int rg = 0; rg < NRG; ++rg) {
+                const int64_t rbase = p.row_begin + (int64_t)tt * TR + 16 * rg + 4 * g;
+#pragma unroll
+                for (int h = 0; h < NQH; ++h)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (rbase + j > last_row) d[rg][h][j] = VS_INF;
             }
         }
     };
@@ -651,6 +701,7 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams 
             tau[h] = tq[h];
         }
         VS_STAMP(3);
+        VS_STAMPC(13);
         // replay the kept tiles against the bound (almost nothing passes)
         consume(min(t_a, tlast), wk[0]);
         consume(min(t_b, tlast), wk[1]);
@@ -666,17 +717,24 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams 
         }
     }
     // ---- steady state: t_cur sits in `slot` (landed or landing), t_nxt in the other slot ----
-    while (t_cur < tile1) {
+    // (written per slot so that the slot is a compile-time constant: LDS offsets become immediates)
+    auto step = [&](const int sl) __attribute__((always_inline)) {
         asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
         float d[NRG][NQH][4];
-        tile_distances(t_cur, slot, d);
+        tile_distances(t_cur, sl, d);
         consume(t_cur, d);
         t_cur = t_nxt;
         t_nxt = next_ticket();
-        issue_tile(min(t_nxt, tlast), slot);
-        slot ^= 1;
+        issue_tile(min(t_nxt, tlast), sl);
+    };
+    if (slot == 1 && t_cur < tile1) step(1);
+    while (t_cur < tile1) {
+        step(0);
+        if (t_cur >= tile1) break;
+        step(1);
     }
     VS_STAMP(5);
+    VS_STAMPC(14);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // retire the discarded tail prefetches: LDS is reused below
     if (MODE == kModeStore) return;
     if (MODE == kModeAssign) {
