@@ -108,6 +108,8 @@ struct vs_index {
     int32_t* d_chunk_list = nullptr;   // [n_chunks] (list, 1024-row chunk) work items over the resident lists
     int32_t* d_chunk_row0 = nullptr;
     int32_t* d_chunk_rows = nullptr;
+    int32_t* d_units = nullptr;        // [n_units_max] per-batch work plan of the list scan (chunk * 32 + unit)
+    int64_t n_units_max = 0;
     int n_chunks = 0;
     int32_t max_list = 0;              // longest resident list
     int32_t* d_lcnt = nullptr;         // [nlist]
@@ -156,7 +158,7 @@ void free_all(vs_index* h) {
                     h->d_out_d, h->d_out_i,
                     h->d_flags, h->d_scores, h->d_probes, h->d_ipart_d, h->d_ipart_i, h->d_cand,
                     h->d_chunk_list, h->d_chunk_row0, h->d_chunk_rows, h->d_lcnt, h->d_lq, h->d_lbase, h->d_qoff,
-                    h->d_candbuf, h->d_gcand_d, h->d_gcand_p};
+                    h->d_candbuf, h->d_gcand_d, h->d_gcand_p, h->d_units};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& ps : h->prof_slot)
@@ -228,7 +230,7 @@ int alloc_scratch(vs_index* h) {
         if ((rc = dev_alloc(&h->d_ipart_i, (size_t)32 * kMaxNprobe * kKcapMax))) return rc;
         if ((rc = dev_alloc(&h->d_cand, 1))) return rc;
         // one zero-filled block per batch: [lcnt nlist][gsel 96][bins 512]
-        if ((rc = dev_alloc(&h->d_lcnt, (size_t)h->nlist + 96 + 512))) return rc;
+        if ((rc = dev_alloc(&h->d_lcnt, (size_t)h->nlist + 96 + 512 + 8))) return rc;  // + plan_done, n_units
         h->d_gsel = h->d_lcnt + h->nlist;
         h->d_bins = reinterpret_cast<unsigned*>(h->d_lcnt + h->nlist + 96);
         if ((rc = dev_alloc(&h->d_lq, (size_t)h->nlist * 32))) return rc;
@@ -427,6 +429,11 @@ int scores_dev(vs_index* h, const float* vecs, const float* norms, int64_t rows,
     return VS_OK;
 }
 
+// tuning knob (VSEARCH_IVF_PLAN=0): list-major scan without the per-batch work plan (one workgroup per chunk)
+int g_ivf_plan = [] {
+    const char* e = getenv("VSEARCH_IVF_PLAN");
+    return e ? atoi(e) : 1;
+}();
 // tuning knob (VSEARCH_IVF_GROUPED=0): fall back to the (query, probe)-major scan
 int g_ivf_grouped = [] {
     const char* e = getenv("VSEARCH_IVF_GROUPED");
@@ -457,7 +464,7 @@ int ivf_batch_dev(vs_index* h, const float* q_dev, int B, int k, int nprobe, flo
             if (rc) return rc;
             h->cand_stride = stride;
         }
-        HIPCHK(hipMemsetAsync(h->d_lcnt, 0, ((size_t)h->nlist + 96 + 512) * sizeof(int32_t), s));
+        HIPCHK(hipMemsetAsync(h->d_lcnt, 0, ((size_t)h->nlist + 96 + 512 + 8) * sizeof(int32_t), s));
         grp.offsets = h->d_offsets;
         grp.lcnt = h->d_lcnt;
         grp.lq = h->d_lq;
@@ -465,6 +472,14 @@ int ivf_batch_dev(vs_index* h, const float* q_dev, int B, int k, int nprobe, flo
         grp.qoff = h->d_qoff;
         grp.cand_stride = h->cand_stride;
         grp.cand_count = h->d_cand;
+        if (h->d_units && g_ivf_plan) {
+            grp.chunk_list = h->d_chunk_list;
+            grp.chunk_rows = h->d_chunk_rows;
+            grp.n_chunks = h->n_chunks;
+            grp.plan_done = h->d_lcnt + h->nlist + 96 + 512;
+            grp.n_units = h->d_lcnt + h->nlist + 96 + 512 + 1;
+            grp.units = h->d_units;
+        }
     }
     if (h->nlist <= 2048) {
         // coarse scores + deterministic top-nprobe (+ grouping tables) in one launch (IVFIndex.cpp:654-666, :697-723)
@@ -490,7 +505,8 @@ int ivf_batch_dev(vs_index* h, const float* q_dev, int B, int k, int nprobe, flo
         lp.cand = h->d_candbuf;
         lp.metric = h->metric;
         prof_begin(h, 1, s);
-        HIPCHK(vs::launch_ivf_list_scan(lp, h->n_chunks, s));
+        if (grp.units) HIPCHK(vs::launch_ivf_unit_scan(lp, grp.units, grp.n_units, B, h->num_cus, s));
+        else HIPCHK(vs::launch_ivf_list_scan(lp, h->n_chunks, s));
         prof_end(h, 1, s);
         vs::IvfSelectParams sp{};
         sp.cand = h->d_candbuf;
@@ -913,6 +929,9 @@ static int ivf_create_impl(const float* vectors, int64_t n_rows, int dim, const 
             if ((rc = dev_alloc(&h->d_chunk_list, cl.size()))) return fail(rc);
             if ((rc = dev_alloc(&h->d_chunk_row0, cl.size()))) return fail(rc);
             if ((rc = dev_alloc(&h->d_chunk_rows, cl.size()))) return fail(rc);
+            h->n_units_max = 0;
+            for (int32_t r : crn) h->n_units_max += (r + 31) >> 5;
+            if ((rc = dev_alloc(&h->d_units, (size_t)std::max<int64_t>(h->n_units_max, 1)))) return fail(rc);
             if ((e = hipMemcpy(h->d_chunk_list, cl.data(), cl.size() * 4, hipMemcpyHostToDevice)) != hipSuccess ||
                 (e = hipMemcpy(h->d_chunk_row0, cr0.data(), cl.size() * 4, hipMemcpyHostToDevice)) != hipSuccess ||
                 (e = hipMemcpy(h->d_chunk_rows, crn.data(), cl.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) {

@@ -94,6 +94,14 @@ struct IvfGroup {
     int32_t* qoff;                   // [B][kIvfMaxProbe+1] window offsets per query, probe order; last = total
     long long cand_stride;           // floats per query in the candidate array
     unsigned long long* cand_count;  // += rows scanned (IVFIndex::searchBatch return value)
+    // work plan of the list scan, written by the last query's workgroup: the 32-row units of every chunk whose
+    // list is probed by some query of the batch, as chunk * 32 + unit (units == nullptr = no plan)
+    const int32_t* chunk_list;       // [n_chunks]
+    const int32_t* chunk_rows;       // [n_chunks]
+    int n_chunks;
+    int32_t* plan_done;              // arrival counter (pre-set to 0)
+    int32_t* units;                  // [sum ceil(chunk_rows / 32)]
+    int32_t* n_units;                // [1]
 };
 
 // Coarse L2 scores against the centroids + the nprobe nearest lists per query, one launch (nlist <= 2048).
@@ -115,6 +123,9 @@ struct IvfListScanParams {
     int metric;
 };
 hipError_t launch_ivf_list_scan(const IvfListScanParams& p, int n_chunks, hipStream_t s);
+// planned variant: one wave per 32-row unit of the plan (IvfGroup::units); B = queries in the batch
+hipError_t launch_ivf_unit_scan(const IvfListScanParams& p, const int32_t* units, const int32_t* n_units, int B, int num_cus,
+                                hipStream_t s);
 
 struct IvfSelectParams {
     const float* cand;

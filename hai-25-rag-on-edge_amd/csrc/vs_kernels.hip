@@ -1465,6 +1465,49 @@ __global__ __launch_bounds__(1024) void ivf_coarse_pick_kernel(const float* __re
         grp.lq[c * kMaxBatch + slot] = b;
         grp.lbase[c * kMaxBatch + slot] = (int64_t)b * grp.cand_stride + s_off[pp];
     }
+    if (!grp.units) return;
+    // ---- work plan: the workgroup that finishes last lists the 32-row units of every probed chunk, so that the
+    //      scan launch deals exactly the live work evenly over its waves ----
+    __shared__ int s_last, s_carry;
+    __shared__ int s_wtot[16];
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) {
+        s_last = atomicAdd(grp.plan_done, 1) == (int)gridDim.x - 1 ? 1 : 0;
+        s_carry = 0;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    const int pl = tid & 63, wv = tid >> 6;
+    for (int base = 0; base < grp.n_chunks; base += 1024) {
+        const int chunk = base + tid;
+        int nu = 0;
+        if (chunk < grp.n_chunks) {
+            // the other workgroups' counts arrive through atomics: read them at agent scope
+            const int cnt = __hip_atomic_load(&grp.lcnt[grp.chunk_list[chunk]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cnt > 0) nu = (grp.chunk_rows[chunk] + 31) >> 5;
+        }
+        int incl = nu;  // inclusive wave scan
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o);
+            if (pl >= o) incl += t;
+        }
+        if (pl == 63) s_wtot[wv] = incl;
+        __syncthreads();
+        int woff = 0, tot = 0;
+        for (int w = 0; w < 16; ++w) {
+            const int t = s_wtot[w];
+            if (w < wv) woff += t;
+            tot += t;
+        }
+        const int pos = s_carry + woff + incl - nu;
+        for (int i = 0; i < nu; ++i) grp.units[pos + i] = chunk * 32 + i;
+        __syncthreads();
+        if (tid == 0) s_carry += tot;
+        __syncthreads();
+    }
+    if (tid == 0) *grp.n_units = s_carry;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1707,6 +1750,95 @@ __global__ __launch_bounds__(kIvfScanThreads) void ivf_list_scan_kernel(const Iv
             }
         }
     }
+}
+
+// Planned variant: the batch's queries are staged once per workgroup; after that every wave works alone on
+// 32-row units of the plan (no barriers, no per-list staging): 4 row groups of 8 rows are loaded (8 lanes per
+// row, whole 128-byte lines per wave-instruction) and scored against every query that probes the unit's list.
+constexpr int kIvfUnitThreads = 256;
+__global__ __launch_bounds__(kIvfUnitThreads) void ivf_unit_scan_kernel(const IvfListScanParams p, const int32_t* __restrict__ units,
+                                                                      const int32_t* __restrict__ n_units_ptr, int B) {
+    __shared__ __attribute__((aligned(16))) float q_s[kMaxBatch * kDim];
+    __shared__ float qn_s[kMaxBatch];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rr = lane >> 3, s8 = lane & 7;
+    const int n_units = *n_units_ptr;
+    if ((int)blockIdx.x * 4 >= n_units) return;  // workgroup-uniform
+    for (int i = tid; i < B * 32; i += kIvfUnitThreads)
+        *reinterpret_cast<f32x4*>(q_s + 4 * i) = *reinterpret_cast<const f32x4*>(p.q + 4 * (int64_t)i);
+    __syncthreads();
+    {   // ||q||^2 in the reference's AVX2 order (cpu_baseline.cpp:95-114): 8 lanes per query
+        const int s = tid >> 3, j = tid & 7;
+        float acc = 0.f;
+        if (s < B) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float x = q_s[s * kDim + 8 * i + j];
+                acc = fmaf(x, x, acc);
+            }
+        }
+        const int b8 = lane & ~7;
+        float sum = __shfl(acc, b8);
+#pragma unroll
+        for (int u = 1; u < 8; ++u) sum = sum + __shfl(acc, b8 + u);
+        if (j == 0 && s < B) qn_s[s] = sum;
+    }
+    __syncthreads();
+    const int nw = (int)gridDim.x * 4;
+    for (int u = (int)blockIdx.x * 4 + wave; u < n_units; u += nw) {
+        const int unit = __builtin_amdgcn_readfirstlane(units[u]);
+        const int chunk = unit >> 5;
+        const int c = p.chunk_list[chunk];
+        const int nq = min(p.lcnt[c], kMaxBatch);
+        const int list_start = p.offsets[c];
+        const int r_end = p.chunk_row0[chunk] + p.chunk_rows[chunk];
+        const int r0 = p.chunk_row0[chunk] + 32 * (unit & 31);
+        f32x4 v[4][4];
+        float vn[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int row = r0 + 8 * g + rr;
+            const int rowc = row < r_end ? row : r_end - 1;
+            const float* src = p.vecs + (int64_t)rowc * kDim + 4 * s8;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) v[g][m] = *reinterpret_cast<const f32x4*>(src + 32 * m);
+            vn[g] = p.vnorm[rowc];
+        }
+        for (int s = 0; s < nq; ++s) {
+            const int qi = p.lq[c * kMaxBatch + s];
+            float* dst = p.cand + p.lbase[c * kMaxBatch + s] + (r0 - list_start);
+            f32x4 qf[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) qf[m] = *reinterpret_cast<const f32x4*>(q_s + qi * kDim + 4 * (s8 + 8 * m));
+            const float qn = qn_s[qi];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float acc = 0.f;
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc = fmaf(v[g][m][i], qf[m][i], acc);
+                acc = dpp_add_xor1(acc);
+                acc = dpp_add_xor2(acc);
+                acc = dpp_add_half_mirror(acc);
+                const float d = p.metric ? -acc : fmaf(-2.0f, acc, qn + vn[g]);
+                if (s8 == 0 && r0 + 8 * g + rr < r_end) dst[8 * g + rr] = d;
+            }
+        }
+    }
+}
+
+hipError_t launch_ivf_unit_scan(const IvfListScanParams& p, const int32_t* units, const int32_t* n_units, int B, int num_cus,
+                                hipStream_t s) {
+    static int per_cu = 0;
+    if (!per_cu) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ivf_unit_scan_kernel, kIvfUnitThreads, 0) != hipSuccess || nb < 1) nb = 4;
+        per_cu = nb > 8 ? 8 : nb;
+    }
+    hipLaunchKernelGGL(ivf_unit_scan_kernel, dim3(num_cus * per_cu), dim3(kIvfUnitThreads), 0, s, p, units, n_units, B);
+    return hipGetLastError();
 }
 
 hipError_t launch_ivf_list_scan(const IvfListScanParams& p, int n_chunks, hipStream_t s) {
