@@ -311,17 +311,6 @@ int g_xchg_first_it = [] {
 }();
 
 int* g_dbg = nullptr;
-// tuning knobs: VSEARCH_STAGGER_US (spread of the workgroup start phases), VSEARCH_STAGGER_PH (number of phases)
-int g_stagger_us = [] {
-    const char* e = getenv("VSEARCH_STAGGER_US");
-    return e ? atoi(e) : 0;
-}();
-int g_stagger_ph = [] {
-    const char* e = getenv("VSEARCH_STAGGER_PH");
-    return e ? atoi(e) : 4;
-}();
-
-
 int pick_kcap(int need) { return need <= 8 ? 8 : (need <= 16 ? 16 : 0); }
 
 // nb <= kMaxMulti batches of B queries in ONE persistent launch on stream s: scan + exchange + top-k +
@@ -354,10 +343,6 @@ int bf_launch(vs_index* h, vs_index::Lane& L, const float* q_dev, int nb, int B,
         // 0x7f800000 = +inf
         HIPCHK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(L.slots), 0x7f800000, (size_t)nb * 32 * vs::kSlotStride, s));
         p.slots_cur = L.slots;
-    }
-    if (exchange && nb >= 4 && g_stagger_us > 0) {
-        p.stagger_ticks = g_stagger_us * 100;
-        p.stagger_phases = g_stagger_ph;
     }
     p.row_begin = 0;
     p.row_end = h->n_rows;

@@ -27,8 +27,6 @@ struct ScanParams {
     float* slots_cur;        // [n_batches][32][kSlotStride] per-workgroup minima (pre-set to +inf) or nullptr = no exchange
     int k1;                  // the exchange bounds the k1-th best distance; also entries kept per partial list
     int* dbg;                // optional debug counters [grid][16]
-    int stagger_ticks;       // multi-batch top-k scan: start phases of the workgroups are spread over this many 10 ns ticks
-    int stagger_phases;      // number of distinct start phases (0/1 = none)
     int64_t row_begin;       // multiple of 16
     int64_t row_end;         // exclusive
     int tiles_per_wg;

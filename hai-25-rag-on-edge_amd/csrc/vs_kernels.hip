@@ -241,17 +241,8 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams 
     const int64_t last_row = p.row_end - 1;
     const int tlast = max(tiles_total - 1, 0);
 
-    // One persistent launch serves n_batches query batches back to back.  Workgroups are never
-    // synchronised with each other, so they drift apart and one workgroup's latency-bound batch
-    // start-up (query staging, first tiles, exchange) overlaps the others' streaming: HBM stays busy.
-    if (MODE == kModeTopK && p.stagger_phases > 1) {
-        // Every workgroup has the same work per batch, so they would otherwise stay in lock-step and all be in
-        // their low-bandwidth phase (query staging, warm-up tiles, exchange, merge) at the same moments.
-        const int phase = (blockIdx.x >> 3) % p.stagger_phases;  // blockIdx & 7 = XCD: every XCD gets every phase
-        const long long wait = (long long)p.stagger_ticks * phase / p.stagger_phases;
-        const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
-        while ((long long)__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
-    }
+    // One persistent launch serves n_batches query batches back to back (no launch gaps, no grid fill/drain per
+    // batch).  The workgroups only meet in the threshold exchange, which waits for half of them.
 #pragma clang loop unroll(disable)
     for (int batch = 0; batch < p.n_batches; ++batch) {
     // Lane-derived values are re-derived per batch from an opaque copy: otherwise hipcc hoists dozens
@@ -675,6 +666,34 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams 
             asm volatile("s_waitcnt vmcnt(9)" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3)::"memory");  // minima (and C) are here
         }
         VS_STAMP(10);
+        // A workgroup that runs ahead of the others would find most slots still unpublished (+inf), i.e. a loose or
+        // infinite bound, and then insert a large part of what it scans.  It re-reads its rows of minima until at
+        // least half of the workgroups have published; every workgroup of the (resident, persistent) grid
+        // publishes without waiting for anybody, so this cannot deadlock, and the spin is bounded anyway.
+        {
+            const int need = (int)gridDim.x / 2;
+            for (int spin = 0;; ++spin) {
+                int cf = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) cf += (v0[i] < VS_INF) + (v1[i] < VS_INF) + (v2[i] < VS_INF) + (v3[i] < VS_INF);
+                cf += dpp_mov_i<0xB1>(cf);
+                cf += dpp_mov_i<0x4E>(cf);
+                cf += dpp_mov_i<0x141>(cf);
+                cf += dpp_mov_i<0x140>(cf);  // row sum: workgroups that have published this row's query
+                if (__all(cf >= need) || spin >= 2048) break;
+                __builtin_amdgcn_s_sleep(24);
+                const float* s0 = slots + (4 * wave + g) * kSlotStride + 16 * r;
+                asm volatile(
+                    "global_load_dwordx4 %0, %4, off sc1\n\t"
+                    "global_load_dwordx4 %1, %4, off offset:16 sc1\n\t"
+                    "global_load_dwordx4 %2, %4, off offset:32 sc1\n\t"
+                    "global_load_dwordx4 %3, %4, off offset:48 sc1\n\t"
+                    "s_waitcnt vmcnt(0)"
+                    : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3)
+                    : "v"(s0)
+                    : "memory");
+            }
+        }
         {
             // Each lane folds its 16 workgroups into one minimum; the k1-th smallest of the row's
             // 16 lane minima is still backed by k1 distinct rows (one per lane group), and with
