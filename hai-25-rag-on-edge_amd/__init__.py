@@ -120,6 +120,7 @@ def lib():
         "vs_ivf_save": (i32, [vp, C.c_char_p]),
         "vs_ivf_search": (i32, [vp, vp, i64, i32, i32, vp, vp, C.POINTER(i64), C.POINTER(Timing)]),
         "vs_ivf_search_dev": (i32, [vp, vp, i32, i32, i32, vp, vp, vp]),
+        "vs_ivf_search_dev_multi": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, vp]),
         "vs_ivf_list_owners": (i32, [vp, i32, i32, vp]),
         "vs_topk_merge_dev": (i32, [vp, vp, i32, i32, i32, i64, i32, vp, vp, vp, vp]),
         "vs_prof_enable": (i32, [vp, i32]),
@@ -343,6 +344,11 @@ class IVFIndex(_Index):
 
     def search_dev(self, q_ptr: int, B: int, k: int, nprobe: int, ids_ptr: int, dists_ptr: int, stream: int):
         _check(lib().vs_ivf_search_dev(self._h, q_ptr, B, k, nprobe, ids_ptr, dists_ptr, stream))
+
+    def search_dev_multi(self, q_ptr: int, n_batches: int, B: int, k: int, nprobe: int, ids_ptr: int, dists_ptr: int,
+                         stream: int):
+        """n_batches independent batches [n_batches][B][128] -> [n_batches][B][k]; asynchronous on `stream`."""
+        _check(lib().vs_ivf_search_dev_multi(self._h, q_ptr, n_batches, B, k, nprobe, ids_ptr, dists_ptr, stream))
 
 
 def topk_merge_dev(dists_ptr: int, ids_ptr: int, G: int, B: int, kin: int, kout: int, out_d_ptr: int,

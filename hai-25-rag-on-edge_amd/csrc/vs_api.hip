@@ -109,6 +109,29 @@ struct vs_index {
     int32_t* d_chunk_row0 = nullptr;
     int32_t* d_chunk_rows = nullptr;
     int32_t* d_units = nullptr;        // [n_units_max] per-batch work plan of the list scan (chunk * 32 + unit)
+    // second set of the per-batch IVF scratch: vs_ivf_search_dev_multi alternates two streams so that one batch's
+    // small latency-bound kernels (coarse + pick, bound, select) run beside the other batch's list scan
+    struct IvfScratch {
+        float* d_scores = nullptr;
+        int64_t scores_cap = 0;
+        int32_t* d_probes = nullptr;
+        float* d_ipart_d = nullptr;
+        int32_t* d_ipart_i = nullptr;
+        int32_t* d_lcnt = nullptr;
+        int32_t* d_gsel = nullptr;
+        unsigned* d_bins = nullptr;
+        int32_t* d_lq = nullptr;
+        long long* d_lbase = nullptr;
+        int32_t* d_qoff = nullptr;
+        float* d_candbuf = nullptr;
+        long long cand_stride = 0;
+        float* d_gcand_d = nullptr;
+        int32_t* d_gcand_p = nullptr;
+        int32_t* d_units = nullptr;
+    } ivf_alt;
+    bool ivf_alt_ready = false;
+    hipStream_t ivf_stream[2] = {nullptr, nullptr};
+    hipEvent_t ivf_fork = nullptr, ivf_join[2] = {nullptr, nullptr};
     int64_t n_units_max = 0;
     int n_chunks = 0;
     int32_t max_list = 0;              // longest resident list
@@ -161,6 +184,17 @@ void free_all(vs_index* h) {
                     h->d_candbuf, h->d_gcand_d, h->d_gcand_p, h->d_units};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    {
+        auto& s = h->ivf_alt;
+        void* alt[] = {s.d_scores, s.d_probes, s.d_ipart_d, s.d_ipart_i, s.d_lcnt, s.d_lq, s.d_lbase, s.d_qoff, s.d_candbuf, s.d_gcand_d, s.d_gcand_p, s.d_units};
+        for (void* p : alt)
+            if (p) (void)hipFree(p);
+        for (int i = 0; i < 2; ++i) {
+            if (h->ivf_stream[i]) (void)hipStreamDestroy(h->ivf_stream[i]);
+            if (h->ivf_join[i]) (void)hipEventDestroy(h->ivf_join[i]);
+        }
+        if (h->ivf_fork) (void)hipEventDestroy(h->ivf_fork);
+    }
     for (auto& ps : h->prof_slot)
         for (auto e : ps.ev) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -189,6 +223,64 @@ void scan_geometry(int64_t rows, int num_cus, int& grid, int& tiles_per_wg) {
     tiles_per_wg = (int)((tiles + g - 1) / g);
     grid = (int)((tiles + tiles_per_wg - 1) / tiles_per_wg);
     grid = std::max(grid, 1);
+}
+
+// per-batch scratch of the IVF search (one set per stream that runs batches)
+int alloc_ivf_scratch(vs_index* h) {
+    int rc;
+    h->scores_cap = (int64_t)32 * ((h->nlist + 15) & ~15);
+    if ((rc = dev_alloc(&h->d_scores, (size_t)h->scores_cap))) return rc;
+    if ((rc = dev_alloc(&h->d_probes, 32 * kMaxNprobe))) return rc;
+    if ((rc = dev_alloc(&h->d_ipart_d, (size_t)32 * kMaxNprobe * kKcapMax))) return rc;
+    if ((rc = dev_alloc(&h->d_ipart_i, (size_t)32 * kMaxNprobe * kKcapMax))) return rc;
+    // one zero-filled block per batch: [lcnt nlist][gsel 96][bins 512][plan_done, n_units]
+    if ((rc = dev_alloc(&h->d_lcnt, (size_t)h->nlist + 96 + 512 + 8))) return rc;
+    h->d_gsel = h->d_lcnt + h->nlist;
+    h->d_bins = reinterpret_cast<unsigned*>(h->d_lcnt + h->nlist + 96);
+    if ((rc = dev_alloc(&h->d_lq, (size_t)h->nlist * 32))) return rc;
+    if ((rc = dev_alloc(&h->d_lbase, (size_t)h->nlist * 32))) return rc;
+    if ((rc = dev_alloc(&h->d_qoff, (size_t)32 * (vs::kIvfMaxProbe + 1)))) return rc;
+    if ((rc = dev_alloc(&h->d_gcand_d, (size_t)32 * 4096))) return rc;
+    if ((rc = dev_alloc(&h->d_gcand_p, (size_t)32 * 4096))) return rc;
+    return VS_OK;
+}
+
+// exchange the index's per-batch IVF scratch with the alternate set (host pointers only: launches already
+// enqueued keep the addresses they were given)
+void swap_ivf_scratch(vs_index* h) {
+    auto& s = h->ivf_alt;
+    std::swap(h->d_scores, s.d_scores);
+    std::swap(h->scores_cap, s.scores_cap);
+    std::swap(h->d_probes, s.d_probes);
+    std::swap(h->d_ipart_d, s.d_ipart_d);
+    std::swap(h->d_ipart_i, s.d_ipart_i);
+    std::swap(h->d_lcnt, s.d_lcnt);
+    std::swap(h->d_gsel, s.d_gsel);
+    std::swap(h->d_bins, s.d_bins);
+    std::swap(h->d_lq, s.d_lq);
+    std::swap(h->d_lbase, s.d_lbase);
+    std::swap(h->d_qoff, s.d_qoff);
+    std::swap(h->d_candbuf, s.d_candbuf);
+    std::swap(h->cand_stride, s.cand_stride);
+    std::swap(h->d_gcand_d, s.d_gcand_d);
+    std::swap(h->d_gcand_p, s.d_gcand_p);
+    std::swap(h->d_units, s.d_units);
+}
+
+int ensure_ivf_alt(vs_index* h) {
+    if (h->ivf_alt_ready) return VS_OK;
+    swap_ivf_scratch(h);  // the (empty) alternate set becomes current: allocate into it
+    int rc = alloc_ivf_scratch(h);
+    if (!rc && h->n_units_max > 0) rc = dev_alloc(&h->d_units, (size_t)h->n_units_max);
+    swap_ivf_scratch(h);
+    if (rc) return rc;
+    for (int i = 0; i < 2; ++i) {
+        HIPCHK(hipStreamCreateWithFlags(&h->ivf_stream[i], hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&h->ivf_join[i], hipEventDisableTiming));
+    }
+    HIPCHK(hipEventCreateWithFlags(&h->ivf_fork, hipEventDisableTiming));
+    h->ivf_alt_ready = true;
+    return VS_OK;
 }
 
 int alloc_scratch(vs_index* h) {
@@ -223,22 +315,8 @@ int alloc_scratch(vs_index* h) {
     if ((rc = dev_alloc(&h->d_out_i, (size_t)kMaxMulti * 32 * 64))) return rc;
     if ((rc = dev_alloc(&h->d_flags, (size_t)kMaxMulti * 32))) return rc;
     if (h->kind == 1) {
-        h->scores_cap = (int64_t)32 * ((h->nlist + 15) & ~15);
-        if ((rc = dev_alloc(&h->d_scores, (size_t)h->scores_cap))) return rc;
-        if ((rc = dev_alloc(&h->d_probes, 32 * kMaxNprobe))) return rc;
-        if ((rc = dev_alloc(&h->d_ipart_d, (size_t)32 * kMaxNprobe * kKcapMax))) return rc;
-        if ((rc = dev_alloc(&h->d_ipart_i, (size_t)32 * kMaxNprobe * kKcapMax))) return rc;
         if ((rc = dev_alloc(&h->d_cand, 1))) return rc;
-        // one zero-filled block per batch: [lcnt nlist][gsel 96][bins 512]
-        if ((rc = dev_alloc(&h->d_lcnt, (size_t)h->nlist + 96 + 512 + 8))) return rc;  // + plan_done, n_units
-        h->d_gsel = h->d_lcnt + h->nlist;
-        h->d_bins = reinterpret_cast<unsigned*>(h->d_lcnt + h->nlist + 96);
-        if ((rc = dev_alloc(&h->d_lq, (size_t)h->nlist * 32))) return rc;
-        if ((rc = dev_alloc(&h->d_lbase, (size_t)h->nlist * 32))) return rc;
-        if ((rc = dev_alloc(&h->d_qoff, (size_t)32 * (vs::kIvfMaxProbe + 1)))) return rc;
-        if ((rc = dev_alloc(&h->d_gcand_d, (size_t)32 * 4096))) return rc;
-        if ((rc = dev_alloc(&h->d_gcand_p, (size_t)32 * 4096))) return rc;
-
+        if ((rc = alloc_ivf_scratch(h))) return rc;
     }
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     return VS_OK;
@@ -1194,6 +1272,40 @@ int vs_ivf_search_dev(vs_index* h, const float* queries_dev, int B, int k, int n
     int rc = set_device(h);
     if (rc) return rc;
     return ivf_batch_dev(h, queries_dev, B, k, nprobe, dists_dev, ids_dev, static_cast<hipStream_t>(stream), nullptr);
+}
+
+int vs_ivf_search_dev_multi(vs_index* h, const float* queries_dev, int n_batches, int B, int k, int nprobe, int32_t* ids_dev,
+                            float* dists_dev, void* stream) {
+    if (!h || h->kind != 1 || !queries_dev || !ids_dev || !dists_dev || n_batches < 1 || B < 1 || B > vs::kMaxBatch || k < 1 ||
+        nprobe < 1) {
+        set_error("vs_ivf_search_dev_multi: bad arguments");
+        return VS_ERR_INVALID;
+    }
+    nprobe = std::min(nprobe, h->nlist);  // IVFIndex.cpp:647
+    if (nprobe > kMaxNprobe) {
+        set_error("nprobe > 256 not supported");
+        return VS_ERR_UNSUPPORTED;
+    }
+    int rc = set_device(h);
+    if (rc) return rc;
+    hipStream_t user = static_cast<hipStream_t>(stream);
+    if (n_batches == 1) return ivf_batch_dev(h, queries_dev, B, k, nprobe, dists_dev, ids_dev, user, nullptr);
+    if ((rc = ensure_ivf_alt(h))) return rc;
+    // even batches on one stream, odd batches (with the alternate scratch) on another: batches are independent
+    HIPCHK(hipEventRecord(h->ivf_fork, user));
+    for (int i = 0; i < 2; ++i) HIPCHK(hipStreamWaitEvent(h->ivf_stream[i], h->ivf_fork, 0));
+    for (int b = 0; b < n_batches && !rc; ++b) {
+        const int lane = b & 1;
+        if (lane) swap_ivf_scratch(h);
+        rc = ivf_batch_dev(h, queries_dev + (size_t)b * B * vs::kDim, B, k, nprobe, dists_dev + (size_t)b * B * k,
+                           ids_dev + (size_t)b * B * k, h->ivf_stream[lane], nullptr);
+        if (lane) swap_ivf_scratch(h);
+    }
+    for (int i = 0; i < 2; ++i) {
+        HIPCHK(hipEventRecord(h->ivf_join[i], h->ivf_stream[i]));
+        HIPCHK(hipStreamWaitEvent(user, h->ivf_join[i], 0));
+    }
+    return rc;
 }
 
 int vs_ivf_search(vs_index* h, const float* queries_host, int64_t nq, int k, int nprobe, int32_t* ids, float* dists,

@@ -185,6 +185,13 @@ VS_API int vs_ivf_search(vs_index* h, const float* queries_host, int64_t nq, int
 VS_API int vs_ivf_search_dev(vs_index* h, const float* queries_dev, int B, int k, int nprobe,
                              int32_t* ids_dev, float* dists_dev, void* stream);
 
+/* The batch loop of main_ivf.cpp:150-214 with the queries already on the device: n_batches independent
+ * batches [n_batches][B][dim] -> [n_batches][B][k].  Batches alternate between two internal streams (each
+ * with its own scratch), so one batch's latency-bound steps (coarse + probe pick, top-k selection) run
+ * beside the other's list scan; `stream` waits for both. */
+VS_API int vs_ivf_search_dev_multi(vs_index* h, const float* queries_dev, int n_batches, int B, int k, int nprobe,
+                                   int32_t* ids_dev, float* dists_dev, void* stream);
+
 /* ---------------------------------------------------------------- multi-GPU */
 /* Which rank owns which inverted list in a cluster-sharded index (host only, no GPU needed):
  * lists sorted by length, longest first, dealt round-robin -> owner_out[nlist] in [0, world).

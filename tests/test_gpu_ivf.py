@@ -222,3 +222,31 @@ def test_gpu_index_builder(gpu_pkg):
         ids32, _, _ = ivf.searchBatch(q, len(q), 5, 32)
     r8, r32 = oracle.recall(ids8[:, :1], gt[:, :1], 1), oracle.recall(ids32[:, :1], gt[:, :1], 1)
     assert 0.5 < r8 <= r32 and r32 >= 0.91
+
+
+def test_multi_batch_equals_single_batches(gpu_pkg):
+    """vs_ivf_search_dev_multi (two alternating streams, two scratch sets) returns what batch-by-batch calls
+    return, for an odd number of batches and on repeated calls."""
+    import torch
+    dev = torch.device("cuda:0")
+    base, cents, vr, off, r2o = _make_index(gpu_pkg, n=20000, nlist=64, seed=3)
+    nb, k, nprobe = 7, 5, 8
+    q = gpu_pkg.synth_sift(32 * nb, seed=77)
+    qd = torch.from_numpy(q).to(dev)
+    s = torch.cuda.current_stream().cuda_stream
+    with gpu_pkg.IVFIndex(vectors_reordered=vr, centroids=cents, cluster_offsets=off, reorder_to_original=r2o) as ivf:
+        want_i = torch.zeros((nb * 32, k), dtype=torch.int32, device=dev)
+        want_d = torch.zeros((nb * 32, k), dtype=torch.float32, device=dev)
+        for b in range(nb):
+            ivf.search_dev(qd.data_ptr() + b * 32 * 128 * 4, 32, k, nprobe, want_i.data_ptr() + b * 32 * k * 4,
+                           want_d.data_ptr() + b * 32 * k * 4, s)
+        torch.cuda.synchronize()
+        for _ in range(3):
+            got_i = torch.full((nb * 32, k), -7, dtype=torch.int32, device=dev)
+            got_d = torch.zeros((nb * 32, k), dtype=torch.float32, device=dev)
+            ivf.search_dev_multi(qd.data_ptr(), nb, 32, k, nprobe, got_i.data_ptr(), got_d.data_ptr(), s)
+            torch.cuda.synchronize()
+            assert torch.equal(got_d, want_d) and torch.equal(got_i, want_i)
+        # and against the host API (which the oracle tests pin)
+        ids, dists, _ = ivf.searchBatch(q, len(q), k, nprobe)
+        assert np.array_equal(ids, want_i.cpu().numpy()) and np.array_equal(dists, want_d.cpu().numpy())
