@@ -128,10 +128,10 @@ struct vs_index {
         float* d_gcand_d = nullptr;
         int32_t* d_gcand_p = nullptr;
         int32_t* d_units = nullptr;
-    } ivf_alt;
-    bool ivf_alt_ready = false;
-    hipStream_t ivf_stream[2] = {nullptr, nullptr};
-    hipEvent_t ivf_fork = nullptr, ivf_join[2] = {nullptr, nullptr};
+    } ivf_alt[7];
+    int ivf_lanes = 0;  // streams set up by vs_ivf_search_dev_multi (0 = not yet)
+    hipStream_t ivf_stream[8] = {};
+    hipEvent_t ivf_fork = nullptr, ivf_join[8] = {};
     int64_t n_units_max = 0;
     int n_chunks = 0;
     int32_t max_list = 0;              // longest resident list
@@ -185,11 +185,12 @@ void free_all(vs_index* h) {
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     {
-        auto& s = h->ivf_alt;
-        void* alt[] = {s.d_scores, s.d_probes, s.d_ipart_d, s.d_ipart_i, s.d_lcnt, s.d_lq, s.d_lbase, s.d_qoff, s.d_candbuf, s.d_gcand_d, s.d_gcand_p, s.d_units};
-        for (void* p : alt)
-            if (p) (void)hipFree(p);
-        for (int i = 0; i < 2; ++i) {
+        for (auto& s : h->ivf_alt) {
+            void* alt[] = {s.d_scores, s.d_probes, s.d_ipart_d, s.d_ipart_i, s.d_lcnt, s.d_lq, s.d_lbase, s.d_qoff, s.d_candbuf, s.d_gcand_d, s.d_gcand_p, s.d_units};
+            for (void* p : alt)
+                if (p) (void)hipFree(p);
+        }
+        for (int i = 0; i < 8; ++i) {
             if (h->ivf_stream[i]) (void)hipStreamDestroy(h->ivf_stream[i]);
             if (h->ivf_join[i]) (void)hipEventDestroy(h->ivf_join[i]);
         }
@@ -247,8 +248,8 @@ int alloc_ivf_scratch(vs_index* h) {
 
 // exchange the index's per-batch IVF scratch with the alternate set (host pointers only: launches already
 // enqueued keep the addresses they were given)
-void swap_ivf_scratch(vs_index* h) {
-    auto& s = h->ivf_alt;
+void swap_ivf_scratch(vs_index* h, int alt) {
+    auto& s = h->ivf_alt[alt];
     std::swap(h->d_scores, s.d_scores);
     std::swap(h->scores_cap, s.scores_cap);
     std::swap(h->d_probes, s.d_probes);
@@ -267,19 +268,27 @@ void swap_ivf_scratch(vs_index* h) {
     std::swap(h->d_units, s.d_units);
 }
 
+// tuning knob (VSEARCH_IVF_LANES, 1..8): streams that vs_ivf_search_dev_multi deals the batches to
+int g_ivf_lanes = [] {
+    const char* e = getenv("VSEARCH_IVF_LANES");
+    return e ? std::max(1, std::min(8, atoi(e))) : 4;
+}();
+
 int ensure_ivf_alt(vs_index* h) {
-    if (h->ivf_alt_ready) return VS_OK;
-    swap_ivf_scratch(h);  // the (empty) alternate set becomes current: allocate into it
-    int rc = alloc_ivf_scratch(h);
-    if (!rc && h->n_units_max > 0) rc = dev_alloc(&h->d_units, (size_t)h->n_units_max);
-    swap_ivf_scratch(h);
-    if (rc) return rc;
-    for (int i = 0; i < 2; ++i) {
+    if (h->ivf_lanes) return VS_OK;
+    for (int l = 1; l < g_ivf_lanes; ++l) {
+        swap_ivf_scratch(h, l - 1);  // the (empty) alternate set becomes current: allocate into it
+        int rc = alloc_ivf_scratch(h);
+        if (!rc && h->n_units_max > 0) rc = dev_alloc(&h->d_units, (size_t)h->n_units_max);
+        swap_ivf_scratch(h, l - 1);
+        if (rc) return rc;
+    }
+    for (int i = 0; i < g_ivf_lanes; ++i) {
         HIPCHK(hipStreamCreateWithFlags(&h->ivf_stream[i], hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&h->ivf_join[i], hipEventDisableTiming));
     }
     HIPCHK(hipEventCreateWithFlags(&h->ivf_fork, hipEventDisableTiming));
-    h->ivf_alt_ready = true;
+    h->ivf_lanes = g_ivf_lanes;
     return VS_OK;
 }
 
@@ -1289,19 +1298,25 @@ int vs_ivf_search_dev_multi(vs_index* h, const float* queries_dev, int n_batches
     int rc = set_device(h);
     if (rc) return rc;
     hipStream_t user = static_cast<hipStream_t>(stream);
-    if (n_batches == 1) return ivf_batch_dev(h, queries_dev, B, k, nprobe, dists_dev, ids_dev, user, nullptr);
+    if (n_batches == 1 || g_ivf_lanes == 1) {
+        for (int b = 0; b < n_batches && !rc; ++b)
+            rc = ivf_batch_dev(h, queries_dev + (size_t)b * B * vs::kDim, B, k, nprobe, dists_dev + (size_t)b * B * k,
+                               ids_dev + (size_t)b * B * k, user, nullptr);
+        return rc;
+    }
     if ((rc = ensure_ivf_alt(h))) return rc;
-    // even batches on one stream, odd batches (with the alternate scratch) on another: batches are independent
+    // the batches are independent: deal them round-robin to the streams (stream l > 0 uses scratch set l - 1)
+    const int lanes = h->ivf_lanes;
     HIPCHK(hipEventRecord(h->ivf_fork, user));
-    for (int i = 0; i < 2; ++i) HIPCHK(hipStreamWaitEvent(h->ivf_stream[i], h->ivf_fork, 0));
+    for (int i = 0; i < lanes; ++i) HIPCHK(hipStreamWaitEvent(h->ivf_stream[i], h->ivf_fork, 0));
     for (int b = 0; b < n_batches && !rc; ++b) {
-        const int lane = b & 1;
-        if (lane) swap_ivf_scratch(h);
+        const int lane = b % lanes;
+        if (lane) swap_ivf_scratch(h, lane - 1);
         rc = ivf_batch_dev(h, queries_dev + (size_t)b * B * vs::kDim, B, k, nprobe, dists_dev + (size_t)b * B * k,
                            ids_dev + (size_t)b * B * k, h->ivf_stream[lane], nullptr);
-        if (lane) swap_ivf_scratch(h);
+        if (lane) swap_ivf_scratch(h, lane - 1);
     }
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < lanes; ++i) {
         HIPCHK(hipEventRecord(h->ivf_join[i], h->ivf_stream[i]));
         HIPCHK(hipStreamWaitEvent(user, h->ivf_join[i], 0));
     }
