@@ -217,9 +217,12 @@ int check_device(int device) {
 }
 
 // scan geometry for n rows: persistent-style grid of at most one workgroup per CU
-void scan_geometry(int64_t rows, int num_cus, int& grid, int& tiles_per_wg) {
+// min_tp > 0: a smaller shard uses fewer workgroups so that each still has min_tp (16-row) tiles, the amount from
+// which the threshold exchange pays -- as long as that keeps at least half of the CUs busy
+void scan_geometry(int64_t rows, int num_cus, int& grid, int& tiles_per_wg, int min_tp = 0) {
     const int64_t tiles = (rows + vs::kTileRows - 1) / vs::kTileRows;
     int64_t g = std::min<int64_t>(num_cus, (tiles + vs::kScanWaves - 1) / vs::kScanWaves);
+    if (min_tp > 0 && tiles / g < min_tp && tiles / min_tp >= num_cus / 2) g = tiles / min_tp;
     g = std::max<int64_t>(std::min<int64_t>(g, vs::kSlotStride), 1);
     tiles_per_wg = (int)((tiles + g - 1) / g);
     grid = (int)((tiles + tiles_per_wg - 1) / tiles_per_wg);
@@ -421,10 +424,10 @@ int bf_launch(vs_index* h, vs_index::Lane& L, const float* q_dev, int nb, int B,
     p.nq_valid = B;
     p.k1 = k1;
     p.dbg = g_dbg;
-    int grid, tp;
-    scan_geometry(h->n_rows, h->num_cus, grid, tp);
     // the exchange pays once every wave has a few tiles left after its warm-up tiles (int8 tiles hold 64 rows)
     const bool u8_path = h->d_vecs_u8 && h->precision != 1 && !force_f32;
+    int grid, tp;
+    scan_geometry(h->n_rows, h->num_cus, grid, tp, (u8_path ? 16 : 6) * vs::kScanWaves);
     const bool exchange = grid >= 16 && tp >= (u8_path ? 16 : 6) * vs::kScanWaves && g_xchg_first_it >= 0;
     if (exchange) {
         // 0x7f800000 = +inf
