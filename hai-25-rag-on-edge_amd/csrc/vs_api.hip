@@ -91,6 +91,9 @@ struct vs_index {
         int* done = nullptr;        // [kMaxMulti] arrival counters, reset per launch
         float* part_d = nullptr;    // [kMaxMulti][32][kSlotStride][16]
         int32_t* part_i = nullptr;
+        float* seed_qnorm = nullptr; // [kMaxMulti][32]   scratch of launch_seed
+        float* seed_wmin = nullptr;  // [kMaxMulti][kSeedWaves][32]
+        float* tau0 = nullptr;       // [kMaxMulti][32]   bounds of the current multi-batch launch
     };
     Lane lane[kMaxLanes];
     int n_lanes = 1;
@@ -173,6 +176,9 @@ void free_all(vs_index* h) {
         if (L.done) (void)hipFree(L.done);
         if (L.part_d) (void)hipFree(L.part_d);
         if (L.part_i) (void)hipFree(L.part_i);
+        if (L.seed_qnorm) (void)hipFree(L.seed_qnorm);
+        if (L.seed_wmin) (void)hipFree(L.seed_wmin);
+        if (L.tau0) (void)hipFree(L.tau0);
         if (L.done_ev) (void)hipEventDestroy(L.done_ev);
         if (L.s) (void)hipStreamDestroy(L.s);
     }
@@ -313,6 +319,9 @@ int alloc_scratch(vs_index* h) {
         for (int i = 0; i < h->n_lanes; ++i) {
             vs_index::Lane& L = h->lane[i];
             if ((rc = dev_alloc(&L.slots, nslot))) return rc;
+            if ((rc = dev_alloc(&L.seed_qnorm, (size_t)kMaxMulti * 32))) return rc;
+            if ((rc = dev_alloc(&L.seed_wmin, (size_t)kMaxMulti * vs::kSeedWaves * 32))) return rc;
+            if ((rc = dev_alloc(&L.tau0, (size_t)kMaxMulti * 32))) return rc;
             if ((rc = dev_alloc(&L.done, kMaxMulti))) return rc;
             if (h->kind == 0) {
                 if ((rc = dev_alloc(&L.part_d, part))) return rc;
@@ -401,6 +410,19 @@ int g_xchg_first_it = [] {
 }();
 
 int* g_dbg = nullptr;
+// tuning knob (VSEARCH_SEED_MIN): multi-batch launches of at least this many batches take their bounds from
+// launch_seed instead of the in-kernel exchange (0 = never)
+int g_seed_min_batches = [] {
+    const char* e = getenv("VSEARCH_SEED_MIN");
+    const int v = e ? atoi(e) : 4;
+    return v > 0 ? v : 1 << 30;
+}();
+
+int g_seed_i8 = [] {
+    const char* e = getenv("VSEARCH_SEED_I8");
+    return e ? atoi(e) : 1;
+}();
+
 int pick_kcap(int need) { return need <= 8 ? 8 : (need <= 16 ? 16 : 0); }
 
 // nb <= kMaxMulti batches of B queries in ONE persistent launch on stream s: scan + exchange + top-k +
@@ -429,7 +451,30 @@ int bf_launch(vs_index* h, vs_index::Lane& L, const float* q_dev, int nb, int B,
     int grid, tp;
     scan_geometry(h->n_rows, h->num_cus, grid, tp, (u8_path ? 16 : 6) * vs::kScanWaves);
     const bool exchange = grid >= 16 && tp >= (u8_path ? 16 : 6) * vs::kScanWaves && g_xchg_first_it >= 0;
-    if (exchange) {
+    // a multi-batch launch gets its bounds up front from a sample of the rows (three small launches for all
+    // batches): every batch then streams from its first tile on; a short call keeps the in-kernel exchange
+    const bool seeded = exchange && nb >= g_seed_min_batches;
+    if (seeded) {
+        vs::SeedParams sp{};
+        sp.base = h->d_vecs;
+        sp.bnorm = h->d_norm;
+        if (h->d_vecs_u8 && h->metric == VS_METRIC_L2 && g_seed_i8) {  // exact int8 copy of the rows: 16x cheaper seed
+            sp.base_u8 = h->d_vecs_u8;
+            sp.rterm = h->d_rterm;
+        }
+        sp.n_rows = h->n_rows;
+        sp.q = q_dev;
+        sp.n_batches = nb;
+        sp.q_batch_stride = (int64_t)B * vs::kDim;
+        sp.nq_valid = B;
+        sp.metric = h->metric;
+        sp.k1 = k1;
+        sp.qnorm = L.seed_qnorm;
+        sp.wmin = L.seed_wmin;
+        sp.tau0 = L.tau0;
+        HIPCHK(vs::launch_seed(sp, s));
+        p.tau0 = L.tau0;
+    } else if (exchange) {
         // 0x7f800000 = +inf
         HIPCHK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(L.slots), 0x7f800000, (size_t)nb * 32 * vs::kSlotStride, s));
         p.slots_cur = L.slots;

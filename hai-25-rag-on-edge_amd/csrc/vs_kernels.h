@@ -25,6 +25,7 @@ struct ScanParams {
     int n_batches;           // query batches served by this one persistent launch (1 for kModeStore)
     int64_t q_batch_stride;  // floats between consecutive batches in q
     float* slots_cur;        // [n_batches][32][kSlotStride] per-workgroup minima (pre-set to +inf) or nullptr = no exchange
+    const float* tau0;       // [n_batches][32] bounds computed beforehand by launch_seed (then no exchange, no warm-up), or nullptr
     int k1;                  // the exchange bounds the k1-th best distance; also entries kept per partial list
     int* dbg;                // optional debug counters [grid][16]
     int64_t row_begin;       // multiple of 16
@@ -47,6 +48,29 @@ struct ScanParams {
 
 // Brute-force / coarse scan.  kcap in {8, 16}; nqh = 1 (<=16 queries) or 2.
 hipError_t launch_scan(const ScanParams& p, int grid, int kcap, int nqh, int mode, hipStream_t s);
+
+// Bounds for a multi-batch scan, computed up front on a sample of the rows: kSeedWaves 16-row tiles spread evenly
+// over the shard, scored against every batch; tau0[batch][q] = next_up of the k1-th smallest of 64 group minima
+// (groups of 32 tiles) -- an upper bound of the k1-th best distance, because k1 distinct rows are at least that
+// close.  Three small launches per call.
+constexpr int kSeedWaves = 2048;  // sample tiles
+struct SeedParams {
+    const float* base;       // [n_rows (+pad)][128]
+    const float* bnorm;
+    const int8_t* base_u8;   // optional exact int8 copy (x - 128) + row terms: the seed then runs on v_mfma_i32_16x16x64_i8
+    const int32_t* rterm;    //   (16x fewer MFMA cycles); a batch with a non-integer query gets tau0 = +inf
+    int64_t n_rows;
+    const float* q;          // [n_batches][nq_valid][128]
+    int n_batches;
+    int64_t q_batch_stride;
+    int nq_valid;
+    int metric;
+    int k1;
+    float* qnorm;            // scratch [n_batches][32]
+    float* wmin;             // scratch [n_batches][64 groups][32]
+    float* tau0;             // out [n_batches][32]
+};
+hipError_t launch_seed(const SeedParams& p, hipStream_t s);
 
 // Cross-workgroup merge of sorted partial lists -> [nq][kout] + tie flags (+ seed thresholds).
 struct MergeParams {

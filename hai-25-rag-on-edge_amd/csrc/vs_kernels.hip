@@ -591,6 +591,13 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams 
 
     const bool exchange = MODE == kModeTopK && slots != nullptr;
     int t_cur = t_a, t_nxt = t_b, slot = 0;
+    if (MODE == kModeTopK && p.tau0) {  // bounds computed up front (launch_seed): stream from the first tile on
+#pragma unroll
+        for (int h = 0; h < NQH; ++h) {
+            tq[h] = p.tau0[batch * kMaxBatch + h * 16 + r];
+            tau[h] = tq[h];
+        }
+    }
     if (exchange) {
         // ---- warm-up: NKEEP tiles per wave whose distances are only kept (no top-k work yet) ----
         float wk[NKEEP][NRG][NQH][4];
@@ -839,6 +846,194 @@ static hipError_t launch_scan_t(const ScanParams& p, int grid, hipStream_t s) {
         attr_set = true;
     }
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(kScanThreads), kScanLds, s, p);
+    return hipGetLastError();
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Seed bounds (see SeedParams).  seed_qnorm_kernel: ||q||^2 in the reference's order; seed_kernel: one wave per
+// sample tile, A fragments and row norms in registers for the whole launch, the queries of every batch straight
+// from global memory (L2) as the B operand; seed_tau_kernel: 32 group minima per query -> k1-th smallest.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void seed_qnorm_kernel(const SeedParams p) {
+    const int batch = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int row = tid >> 3, j = tid & 7;
+    const float* qb = p.q + (int64_t)batch * p.q_batch_stride;
+    float acc = 0.f;
+    if (row < p.nq_valid) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float x = qb[row * kDim + 8 * i + j];
+            acc = fmaf(x, x, acc);
+        }
+    }
+    const int b8 = lane & ~7;
+    float sum = __shfl(acc, b8);
+#pragma unroll
+    for (int u = 1; u < 8; ++u) sum = sum + __shfl(acc, b8 + u);
+    if (j == 0) p.qnorm[batch * kMaxBatch + row] = sum;
+}
+
+// One wave = (batch, chunk of kSeedTilesPerWave sample tiles): the batch's queries stay in registers as the B
+// operand, the tiles stream through (they are shared by all batches: L2 / Infinity Cache hits).
+constexpr int kSeedChunks = 64;                                // group minima per query
+constexpr int kSeedTilesPerWave = kSeedWaves / kSeedChunks;    // 32 tiles = 512 rows per group
+__device__ __forceinline__ int64_t seed_tile(int64_t tiles_total, int s) {  // sample tile s -> tile of the shard
+    return tiles_total >= kSeedWaves ? (int64_t)s * (tiles_total / kSeedWaves) : s;
+}
+
+__global__ __launch_bounds__(256) void seed_kernel(const SeedParams p) {
+    const int lane = threadIdx.x & 63;
+    const int wid = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    const int batch = wid / kSeedChunks, chunk = wid % kSeedChunks;
+    if (batch >= p.n_batches) return;
+    const int r = lane & 15, g = lane >> 4;
+    const int64_t tiles_total = (p.n_rows + kTileRows - 1) / kTileRows;
+    const float* qb = p.q + (int64_t)batch * p.q_batch_stride;
+    f32x4 qf[2][8];
+    float qn[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int qrow = h * 16 + r;
+        const bool qv = qrow < p.nq_valid;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            qf[h][c] = *reinterpret_cast<const f32x4*>(qb + (qv ? qrow : 0) * kDim + 16 * c + 4 * g);
+            if (!qv) qf[h][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        qn[h] = p.qnorm[batch * kMaxBatch + qrow];
+    }
+    float m[2] = {VS_INF, VS_INF};
+    for (int t = 0; t < kSeedTilesPerWave; ++t) {
+        const int64_t tile = seed_tile(tiles_total, chunk * kSeedTilesPerWave + t);
+        if (tile >= tiles_total) break;  // wave-uniform
+        const int64_t row0 = tile * kTileRows;
+        f32x4 a[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) a[c] = *reinterpret_cast<const f32x4*>(p.base + (row0 + r) * kDim + 16 * c + 4 * g);
+        const f32x4 bn = *reinterpret_cast<const f32x4*>(p.bnorm + row0 + 4 * g);  // padded by 64
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][i], qf[h][c][i], acc, 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float d = p.metric ? -acc[j] : fmaf(-2.0f, acc[j], qn[h] + bn[j]);  // the scan's own expression
+                if (row0 + 4 * g + j < p.n_rows) m[h] = fminf(m[h], d);
+            }
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        m[h] = fminf(m[h], __shfl_xor(m[h], 16));
+        m[h] = fminf(m[h], __shfl_xor(m[h], 32));
+    }
+    float* dst = p.wmin + ((int64_t)batch * kSeedChunks + chunk) * kMaxBatch;  // 128 contiguous bytes per wave
+    if (g == 0) {
+        dst[r] = m[0];
+        dst[16 + r] = m[1];
+    }
+}
+
+// int8 variant (rows and queries integers in [0, 255]): the same distances as exact integers, see scan_kernel PREC = 1
+__global__ __launch_bounds__(256) void seed_kernel_i8(const SeedParams p) {
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63;
+    const int wid = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    const int batch = wid / kSeedChunks, chunk = wid % kSeedChunks;
+    if (batch >= p.n_batches) return;
+    const int r = lane & 15, g = lane >> 4;
+    const int64_t tiles_total = (p.n_rows + kTileRows - 1) / kTileRows;
+    const float* qb = p.q + (int64_t)batch * p.q_batch_stride;
+    i32x4 qi[2][2];
+    int qterm[2];
+    bool q_ok = true;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int qrow = h * 16 + r;
+        const bool qv = qrow < p.nq_valid;
+        int part = 0;
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(qb + (qv ? qrow : 0) * kDim + half * 64 + 16 * g + 4 * w);
+                unsigned word = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float x = qv ? v[e] : 128.f;
+                    const int xi = (int)x;
+                    q_ok = q_ok && ((float)xi == x) && xi >= 0 && xi <= 255;
+                    const int sb = xi - 128;
+                    part += sb;
+                    word |= ((unsigned)(sb & 0xff)) << (8 * e);
+                }
+                qi[h][half][w] = (int)word;
+            }
+        part += __shfl_xor(part, 16);
+        part += __shfl_xor(part, 32);
+        qterm[h] = (int)p.qnorm[batch * kMaxBatch + qrow] - 256 * part - 4194304;
+    }
+    float m[2] = {VS_INF, VS_INF};
+    for (int t = 0; t < kSeedTilesPerWave; ++t) {
+        const int64_t tile = seed_tile(tiles_total, chunk * kSeedTilesPerWave + t);
+        if (tile >= tiles_total) break;
+        const int64_t row0 = tile * kTileRows;
+        // A fragments: bytes k = 16 g .. 16 g + 15 and 64 + 16 g .. of row row0 + r
+        const i32x4 a0 = *reinterpret_cast<const i32x4*>(p.base_u8 + (row0 + r) * kDim + 16 * g);
+        const i32x4 a1 = *reinterpret_cast<const i32x4*>(p.base_u8 + (row0 + r) * kDim + 64 + 16 * g);
+        const i32x4 rt = *reinterpret_cast<const i32x4*>(p.rterm + row0 + 4 * g);  // padded by 64
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            i32x4 acc = {0, 0, 0, 0};
+            acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, qi[h][0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, qi[h][1], acc, 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (row0 + 4 * g + j < p.n_rows) m[h] = fminf(m[h], (float)(qterm[h] + rt[j] - 2 * acc[j]));
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        m[h] = fminf(m[h], __shfl_xor(m[h], 16));
+        m[h] = fminf(m[h], __shfl_xor(m[h], 32));
+        if (!__all(q_ok)) m[h] = -VS_INF;  // not an int8 batch: no bound from this kernel (-inf survives the minima below)
+    }
+    float* dst = p.wmin + ((int64_t)batch * kSeedChunks + chunk) * kMaxBatch;
+    if (g == 0) {
+        dst[r] = m[0];
+        dst[16 + r] = m[1];
+    }
+}
+
+__global__ __launch_bounds__(1024) void seed_tau_kernel(const SeedParams p) {
+    // one wave per query (two queries per wave): lane l holds group minimum l; k1 rounds of wave minimum
+    const int batch = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* src = p.wmin + (int64_t)batch * kSeedChunks * kMaxBatch;
+#pragma unroll
+    for (int qq = 0; qq < 2; ++qq) {
+        const int q = 2 * wave + qq;
+        float v = src[lane * kMaxBatch + q];
+        float kth = VS_INF;
+        for (int round = 0; round < p.k1; ++round) {
+            kth = wave_min_f32(v);
+            const unsigned long long msk = __ballot(v == kth);
+            if (msk != 0ull && lane == __builtin_ctzll(msk)) v = VS_INF;  // drop exactly one instance
+        }
+        // (-inf = the int8 seed met a non-integer query: no bound for this batch)
+        if (lane == 0) p.tau0[batch * kMaxBatch + q] = (kth < VS_INF && kth > -VS_INF) ? next_up(kth) : VS_INF;
+    }
+}
+
+hipError_t launch_seed(const SeedParams& p, hipStream_t s) {
+    hipLaunchKernelGGL(seed_qnorm_kernel, dim3(p.n_batches), dim3(256), 0, s, p);
+    const int wgs = (p.n_batches * kSeedChunks + 3) / 4;  // one wave per (batch, chunk)
+    if (p.base_u8) hipLaunchKernelGGL(seed_kernel_i8, dim3(wgs), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(seed_kernel, dim3(wgs), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(seed_tau_kernel, dim3(p.n_batches), dim3(1024), 0, s, p);
     return hipGetLastError();
 }
 
