@@ -243,6 +243,7 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams 
 
     // One persistent launch serves n_batches query batches back to back (no launch gaps, no grid fill/drain per
     // batch).  The workgroups only meet in the threshold exchange, which waits for half of them.
+    bool q_staged = false;  // the next batch's queries are already in (or on their way to) the LDS stage
 #pragma clang loop unroll(disable)
     for (int batch = 0; batch < p.n_batches; ++batch) {
     // Lane-derived values are re-derived per batch from an opaque copy: otherwise hipcc hoists dozens
@@ -312,16 +313,21 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams 
     float* slots = p.slots_cur ? p.slots_cur + (int64_t)batch * 32 * kSlotStride : nullptr;
     // queries -> LDS by DMA as well (2 pieces per wave): chunk c of row q lands at chunk c ^ (q & 15);
     // rows >= nq_valid read row 0 and are zeroed when used (main.cpp:206-211 zero padding)
+    auto issue_queries = [&](const float* qsrc) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int j = 2 * wave + u;
-        const int row = 2 * j + (lane >> 5);
-        const int c4 = lane & 31;
-        const float* src = qb + (row < p.nq_valid ? row : 0) * kDim + 4 * (c4 ^ (row & 15));
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(q_s) + j * 1024),
-                                         16, 0, 0);
-    }
+        for (int u = 0; u < 2; ++u) {
+            const int j = 2 * wave + u;
+            const int row = 2 * j + (lane >> 5);
+            const int c4 = lane & 31;
+            const float* src = qsrc + (row < p.nq_valid ? row : 0) * kDim + 4 * (c4 ^ (row & 15));
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(q_s) + j * 1024),
+                                             16, 0, 0);
+        }
+    };
+    // (from the second batch on the queries were staged during the previous batch, see below)
+    if (!q_staged) issue_queries(qb);
+    q_staged = false;
     int t_a = tile0 + wave * tile_step, t_b = tile0 + (wave + kScanWaves) * tile_step;
     issue_tile(min(t_a, tlast), 0);
     issue_tile(min(t_b, tlast), 1);
@@ -420,6 +426,12 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams 
         }
     }
     VS_STAMP(1);
+    // The query stage is free from here on: stage the NEXT batch's queries now (two more DMA pieces per wave, older
+    // than every tile that will be waited for, so the counted waits below only ever wait a little longer).
+    if (MODE != kModeStore && batch + 1 < p.n_batches) {
+        issue_queries(qb + p.q_batch_stride);
+        q_staged = true;
+    }
 
     float ld[NQH][KCAP];
     int li[NQH][KCAP];
