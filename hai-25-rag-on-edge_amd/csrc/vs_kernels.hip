@@ -11,6 +11,7 @@
 //
 // Wavefront = 64 lanes everywhere; nothing here is written for 32-wide warps.
 #include "vs_kernels.h"
+#include <type_traits>
 
 namespace vs {
 
@@ -186,7 +187,9 @@ constexpr int kDepth = 2;
 constexpr int kRingBytes = kScanWaves * kDepth * kSlotBytes;  // 135168
 constexpr int kQStageBytes = 32 * kDim * 4;                  // 16384
 constexpr int kScratchBytes = 2048;
-constexpr int kScanLds = kRingBytes + kQStageBytes + kScratchBytes;  // 153600 <= 160 KiB
+constexpr int kMergeSmall = 32;     // entries per query of the small workgroup-merge buffer
+constexpr int kMergeSmallBytes = kMaxBatch * kMergeSmall * 8;  // 8192
+constexpr int kScanLds = kRingBytes + kQStageBytes + kScratchBytes + kMergeSmallBytes;  // 161792 <= 160 KiB (163840)
 
 #ifdef VS_STAMPS
 #define VS_STAMP(i)                                                                                    \
@@ -244,6 +247,7 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams 
     // One persistent launch serves n_batches query batches back to back (no launch gaps, no grid fill/drain per
     // batch).  The workgroups only meet in the threshold exchange, which waits for half of them.
     bool q_staged = false;  // the next batch's queries are already in (or on their way to) the LDS stage
+    bool tiles_staged = false;  // ... and so are this wave's first two tiles (slot 0 and slot 1)
 #pragma clang loop unroll(disable)
     for (int batch = 0; batch < p.n_batches; ++batch) {
     // Lane-derived values are re-derived per batch from an opaque copy: otherwise hipcc hoists dozens
@@ -328,9 +332,18 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams 
     // (from the second batch on the queries were staged during the previous batch, see below)
     if (!q_staged) issue_queries(qb);
     q_staged = false;
+    // A wave's first two tiles are the same in every batch; from the second batch on they were fetched by the tail of
+    // the previous batch's loop (instead of two prefetches that would be thrown away) and are already in the ring.
     int t_a = tile0 + wave * tile_step, t_b = tile0 + (wave + kScanWaves) * tile_step;
-    issue_tile(min(t_a, tlast), 0);
-    issue_tile(min(t_b, tlast), 1);
+    if (!tiles_staged) {
+        issue_tile(min(t_a, tlast), 0);
+        issue_tile(min(t_b, tlast), 1);
+    }
+    tiles_staged = MODE != kModeStore;
+    // a ticket past the end of the batch: what goes into the slot is the tile the NEXT batch starts with in it
+    auto issue_or_stage = [&](int t, int sl) __attribute__((always_inline)) {
+        issue_tile(t < tile1 ? t : min(sl == 0 ? t_a : t_b, tlast), sl);
+    };
     if (tid == 0) lds_ticket[0] = 2 * kScanWaves;
     if (tid < 32) lds_cnt[tid] = 0;
     asm volatile("s_waitcnt vmcnt(18)" ::: "memory");  // the two query pieces have landed (two tiles follow)
@@ -629,7 +642,7 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams 
         VS_STAMP(12);
         kill(t_a >= tile1, wk[0]);
         const int t_c = next_ticket();
-        issue_tile(min(t_c, tlast), 0);  // queue: B C
+        issue_or_stage(t_c, 0);  // queue: B C
         // publish this workgroup's per-query minimum (distinct workgroups hold distinct rows)
 #pragma unroll
         for (int h = 0; h < NQH; ++h) {
@@ -670,7 +683,7 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams 
                 : "memory");
         }
         const int t_d = next_ticket();
-        issue_tile(min(t_d, tlast), 1);  // queue: C loads(4) D
+        issue_or_stage(t_d, 1);  // queue: C loads(4) D
         int t_e = t_d;
         if (NKEEP == 3) {
             asm volatile("s_waitcnt vmcnt(13)" ::: "memory");  // C landed
@@ -679,7 +692,7 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams 
             kill(t_c >= tile1, wk[NKEEP - 1]);
             VS_STAMP(8);
             t_e = next_ticket();
-            issue_tile(min(t_e, tlast), 0);  // queue: loads(4) D E
+            issue_or_stage(t_e, 0);  // queue: loads(4) D E
             asm volatile("s_waitcnt vmcnt(18)" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3)::"memory");  // the minima are here
         } else {
             asm volatile("s_waitcnt vmcnt(9)" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3)::"memory");  // minima (and C) are here
@@ -763,7 +776,7 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams 
         consume(t_cur, d);
         t_cur = t_nxt;
         t_nxt = next_ticket();
-        issue_tile(min(t_nxt, tlast), sl);
+        issue_or_stage(t_nxt, sl);
     };
     if (slot == 1 && t_cur < tile1) step(1);
     while (t_cur < tile1) {
@@ -783,64 +796,87 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams 
     VS_STAMP(4);
 
     // ---- workgroup merge: compact the entries that can still matter (d < tau0), rank them ----
+    // With a bound in force a query keeps a handful of entries per workgroup: they fit a small buffer behind the
+    // ring (kMergeSmall per query), which leaves the ring -- and the next batch's two staged tiles per wave --
+    // alone.  Only an unbounded scan (small shards: lists full of unfiltered entries) needs the big buffers; they
+    // overlay the ring, so the staged tiles are then fetched again.
     constexpr int NQ = NQH * 16;
     constexpr int CAP = 32 * KCAP;  // 32 lane lists per query: cannot overflow
-    float* cand_d = reinterpret_cast<float*>(smem);
-    int* cand_i = reinterpret_cast<int*>(smem + (size_t)NQ * CAP * sizeof(float));
+    float* small_d = reinterpret_cast<float*>(smem + kRingBytes + kQStageBytes + kScratchBytes);
+    int* small_i = reinterpret_cast<int*>(small_d + kMaxBatch * kMergeSmall);
+    auto compact = [&](float* cand_d, int* cand_i, const int cap) {
 #pragma unroll
-    for (int h = 0; h < NQH; ++h) {
-        const int qidx = h * 16 + r;
+        for (int h = 0; h < NQH; ++h) {
+            const int qidx = h * 16 + r;
 #pragma unroll
-        for (int j = 0; j < KCAP; ++j)
-            if (li[h][j] >= 0 && ld[h][j] < tq[h]) {
-                const int pos = atomicAdd(&lds_cnt[qidx], 1);
-                cand_d[qidx * CAP + pos] = ld[h][j];
-                cand_i[qidx * CAP + pos] = li[h][j];
-            }
-    }
-    __syncthreads();
-    constexpr int EPL = CAP / 64;
-    for (int qq = wave; qq < NQ; qq += kScanWaves) {
-        const int M = lds_cnt[qq];
-        float cd[EPL];
-        int ci[EPL];
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) {
-            const int idx = e * 64 + lane;
-            cd[e] = idx < M ? cand_d[qq * CAP + idx] : VS_INF;
-            ci[e] = idx < M ? cand_i[qq * CAP + idx] : 0x7fffffff;
-        }
-        // partial lists are query-major: [batch][query][workgroup][KCAP] (one merge launch ranks all batches)
-        float* od = p.part_d + (((int64_t)batch * kMaxBatch + qq) * kSlotStride + blockIdx.x) * KCAP;
-        int32_t* oi = p.part_i + (((int64_t)batch * kMaxBatch + qq) * kSlotStride + blockIdx.x) * KCAP;
-        const int rounds = min(min(p.k1, KCAP), M);
-        for (int round = 0; round < rounds; ++round) {
-            float md = cd[0];
-            int mi = ci[0];
-#pragma unroll
-            for (int e = 1; e < EPL; ++e)
-                if (lex_lt(cd[e], ci[e], md, mi)) {
-                    md = cd[e];
-                    mi = ci[e];
-                }
-            float bd;
-            int bi;
-            wave_lexmin(md, mi, bd, bi);
-            if (lane == 0) {
-                od[round] = bd;
-                oi[round] = bi;
-            }
-#pragma unroll
-            for (int e = 0; e < EPL; ++e)
-                if (ci[e] == bi && cd[e] == bd) {
-                    cd[e] = VS_INF;
-                    ci[e] = 0x7fffffff;
+            for (int j = 0; j < KCAP; ++j)
+                if (li[h][j] >= 0 && ld[h][j] < tq[h]) {
+                    const int pos = atomicAdd(&lds_cnt[qidx], 1);
+                    if (pos < cap) {
+                        cand_d[qidx * cap + pos] = ld[h][j];
+                        cand_i[qidx * cap + pos] = li[h][j];
+                    }
                 }
         }
-        if (lane < KCAP && lane >= rounds) {
-            od[lane] = VS_INF;
-            oi[lane] = -1;
+    };
+    auto rank = [&](const float* cand_d, const int* cand_i, const int cap, auto epl_tag) {
+        constexpr int EPL = decltype(epl_tag)::value;
+        for (int qq = wave; qq < NQ; qq += kScanWaves) {
+            const int M = lds_cnt[qq];
+            float cd[EPL];
+            int ci[EPL];
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                const int idx = e * 64 + lane;
+                cd[e] = idx < M ? cand_d[qq * cap + idx] : VS_INF;
+                ci[e] = idx < M ? cand_i[qq * cap + idx] : 0x7fffffff;
+            }
+            // partial lists are query-major: [batch][query][workgroup][KCAP] (one merge launch ranks all batches)
+            float* od = p.part_d + (((int64_t)batch * kMaxBatch + qq) * kSlotStride + blockIdx.x) * KCAP;
+            int32_t* oi = p.part_i + (((int64_t)batch * kMaxBatch + qq) * kSlotStride + blockIdx.x) * KCAP;
+            const int rounds = min(min(p.k1, KCAP), M);
+            for (int round = 0; round < rounds; ++round) {
+                float md = cd[0];
+                int mi = ci[0];
+#pragma unroll
+                for (int e = 1; e < EPL; ++e)
+                    if (lex_lt(cd[e], ci[e], md, mi)) {
+                        md = cd[e];
+                        mi = ci[e];
+                    }
+                float bd;
+                int bi;
+                wave_lexmin(md, mi, bd, bi);
+                if (lane == 0) {
+                    od[round] = bd;
+                    oi[round] = bi;
+                }
+#pragma unroll
+                for (int e = 0; e < EPL; ++e)
+                    if (ci[e] == bi && cd[e] == bd) {
+                        cd[e] = VS_INF;
+                        ci[e] = 0x7fffffff;
+                    }
+            }
+            if (lane < KCAP && lane >= rounds) {
+                od[lane] = VS_INF;
+                oi[lane] = -1;
+            }
         }
+    };
+    compact(small_d, small_i, kMergeSmall);
+    const bool too_many = __syncthreads_or(lds_cnt[tid & 31] > kMergeSmall);
+    if (!too_many) {
+        rank(small_d, small_i, kMergeSmall, std::integral_constant<int, 1>{});
+    } else {
+        if (tid < 32) lds_cnt[tid] = 0;
+        __syncthreads();
+        float* big_d = reinterpret_cast<float*>(smem);
+        int* big_i = reinterpret_cast<int*>(smem + (size_t)NQ * CAP * sizeof(float));
+        compact(big_d, big_i, CAP);
+        __syncthreads();
+        rank(big_d, big_i, CAP, std::integral_constant<int, CAP / 64>{});
+        tiles_staged = false;  // the ring was overwritten
     }
     __syncthreads();  // LDS (ring, counters, ticket, query stage) is reused by the next batch
     }  // batch loop
