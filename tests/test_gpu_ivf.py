@@ -250,3 +250,32 @@ def test_multi_batch_equals_single_batches(gpu_pkg):
         # and against the host API (which the oracle tests pin)
         ids, dists, _ = ivf.searchBatch(q, len(q), k, nprobe)
         assert np.array_equal(ids, want_i.cpu().numpy()) and np.array_equal(dists, want_d.cpu().numpy())
+
+
+def test_sweep_driver_end_to_end(gpu_pkg, tmp_path):
+    """the nprobe sweep driver builds an index (GPU k-means, reference directory format), runs the CLI
+    per nprobe and writes the CSV; recall grows with nprobe and reaches 100 % at nprobe = nlist."""
+    import csv
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = gpu_pkg.synth_sift(6000, seed=11)
+    q = gpu_pkg.synth_sift(64, seed=12)
+    with gpu_pkg.BruteForceIndex(base) as bf:
+        gt, _ = bf.search(q, 5)
+    gpu_pkg.write_fvecs(str(tmp_path / "b.fvecs"), base)
+    gpu_pkg.write_fvecs(str(tmp_path / "q.fvecs"), q)
+    gpu_pkg.write_ivecs(str(tmp_path / "gt.ivecs"), gt)
+    out = tmp_path / "res"
+    subprocess.run([sys.executable, os.path.join(root, "scripts", "sweep_ivf.py"), "--dataset", "synth", "--base",
+                    str(tmp_path / "b.fvecs"), "--queries", str(tmp_path / "q.fvecs"), "--groundtruth", str(tmp_path / "gt.ivecs"),
+                    "--index-dir", str(tmp_path / "idx"), "--nlist", "64", "--max-iter", "10", "--nprobes", "1", "8", "64",
+                    "--top-k", "5", "--batch", "32", "--out", str(out)], check=True, cwd=str(tmp_path))
+    files = [f for f in os.listdir(out) if f.endswith(".csv")]
+    assert len(files) == 1
+    rows = list(csv.DictReader(open(out / files[0])))
+    assert [r["nprobe"] for r in rows] == ["1", "8", "64"]
+    rec = [float(r["recall"]) for r in rows]
+    assert rec[0] <= rec[1] <= rec[2] and rec[2] == 100.0
+    assert all(float(r["qps"]) > 0 and float(r["avg_candidates"]) > 0 for r in rows)
+    assert os.path.exists(tmp_path / "idx" / "ivf_config.json")

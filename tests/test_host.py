@@ -168,3 +168,24 @@ def test_argument_validation(pkg):
     vr, off, r2o = pkg.ivf_layout_from_assignment(v, np.array([2, 0, 1, 0, 2, 2]), 3)
     assert off.tolist() == [0, 2, 3, 6] and r2o.tolist() == [1, 3, 2, 0, 4, 5]
     assert np.array_equal(vr, v[r2o])
+
+
+def test_sweep_metrics_parser_reads_the_cli_layout():
+    """scripts/sweep_ivf.py parses the metrics.txt layout that cli_ivf.cpp writes into the CSV
+    columns of the reference's sweep (qidk_ivf/scripts/run_all_ivf.sh:62)."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("sweep_ivf", os.path.join(root, "scripts", "sweep_ivf.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    text = ("=== IVF Search Performance Metrics ===\n\nQuery Statistics:\n  Number of queries: 100\n"
+            "  Avg candidates searched: 1234.500000\n  Candidate reduction: 8.100000x\n\n"
+            "Accuracy:\n  Recall@5: 97.250000%\n\n"
+            "Latency:\n  Avg per query (amortized): 0.012000 ms\n  Batch P50: 0.350000 ms\n  Batch P95: 0.400000 ms\n"
+            "  Batch P99: 0.500000 ms\n\nThroughput:\n  Total time: 0.001 s\n  QPS: 83333.300000\n")
+    m = mod.parse_metrics(text)
+    assert m == {"recall": "97.250000", "qps": "83333.300000", "avg_latency_ms": "0.012000", "p50_latency_ms": "0.350000",
+                 "p95_latency_ms": "0.400000", "p99_latency_ms": "0.500000", "avg_candidates": "1234.500000",
+                 "candidate_reduction": "8.100000"}
+    assert mod.COLUMNS[:3] == ["dataset", "nprobe", "top_k"] and len(mod.COLUMNS) == 11
