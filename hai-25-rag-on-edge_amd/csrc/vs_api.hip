@@ -1114,12 +1114,10 @@ int vs_ivf_build(const float* base_host, int64_t n_rows, int dim, int nlist, int
     BUILD_CHK(hipMemcpy(d_x, base_host, (size_t)n_rows * dim * sizeof(float), hipMemcpyHostToDevice));
     BUILD_CHK(hipMemset(d_norm, 0, ((size_t)n_rows + 64) * sizeof(float)));
     BUILD_CHK(vs::launch_row_sqnorm(d_x, n_rows, dim, d_norm, nullptr));
-    // initial centroids: nlist distinct rows drawn with splitmix64 (the reference's KMeans uses k-means++ with
-    // random_state=42, create_ivf_model_reordered.py:97-103; its RNG stream cannot be reproduced, so the
-    // initialisation is documented as different)
+    // initial centroids: k-means++ (D^2 sampling), sklearn's default for the reference's KMeans(random_state=42, n_init=1),
+    // create_ivf_model_reordered.py:97-103.  sklearn's RNG stream and its greedy multi-trial variant are not
+    // reproduced (VSEARCH_KMEANS_INIT=random: nlist distinct random rows instead).
     {
-        std::vector<float> init((size_t)nlist_pad * dim, 0.f);
-        std::vector<int64_t> picked;
         uint64_t st = seed * 0x9E3779B97F4A7C15ull + 0x1234567ull;
         auto next = [&]() {
             uint64_t z = (st += 0x9E3779B97F4A7C15ull);
@@ -1127,14 +1125,35 @@ int vs_ivf_build(const float* base_host, int64_t n_rows, int dim, int nlist, int
             z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
             return z ^ (z >> 31);
         };
-        std::vector<bool> used((size_t)n_rows, false);
-        for (int c = 0; c < nlist; ++c) {
-            int64_t r;
-            do r = (int64_t)(next() % (uint64_t)n_rows); while (used[(size_t)r]);
-            used[(size_t)r] = true;
-            std::memcpy(&init[(size_t)c * dim], base_host + r * dim, (size_t)dim * sizeof(float));
+        const char* init_env = getenv("VSEARCH_KMEANS_INIT");
+        const bool random_init = init_env && std::string(init_env) == "random";
+        BUILD_CHK(hipMemset(d_cents, 0, (size_t)nlist_pad * dim * sizeof(float)));
+        if (random_init) {
+            std::vector<float> init((size_t)nlist_pad * dim, 0.f);
+            std::vector<bool> used((size_t)n_rows, false);
+            for (int c = 0; c < nlist; ++c) {
+                int64_t r;
+                do r = (int64_t)(next() % (uint64_t)n_rows); while (used[(size_t)r]);
+                used[(size_t)r] = true;
+                std::memcpy(&init[(size_t)c * dim], base_host + r * dim, (size_t)dim * sizeof(float));
+            }
+            BUILD_CHK(hipMemcpy(d_cents, init.data(), init.size() * sizeof(float), hipMemcpyHostToDevice));
+        } else {
+            const int n_blocks = (int)((n_rows + vs::kKppBlockRows - 1) / vs::kKppBlockRows);
+            double* d_bsum = nullptr;
+            BUILD_CHK(hipMalloc(&d_bsum, (size_t)n_blocks * sizeof(double)));
+            const int64_t first = (int64_t)(next() % (uint64_t)n_rows);
+            hipError_t e = hipMemcpy(d_cents, d_x + first * dim, (size_t)dim * sizeof(float), hipMemcpyDeviceToDevice);
+            // d_best_d doubles as the running min squared distance (+inf to start with)
+            if (e == hipSuccess) e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_best_d), 0x7f800000, (size_t)n_rows, nullptr);
+            for (int c = 1; c < nlist && e == hipSuccess; ++c) {
+                const double u = (double)(next() >> 11) * (1.0 / 9007199254740992.0);  // [0, 1)
+                e = vs::launch_kpp_step(d_x, d_norm, n_rows, d_cents, c, d_best_d, d_bsum, n_blocks, u, nullptr);
+            }
+            if (e == hipSuccess) e = hipDeviceSynchronize();
+            (void)hipFree(d_bsum);
+            BUILD_CHK(e);
         }
-        BUILD_CHK(hipMemcpy(d_cents, init.data(), init.size() * sizeof(float), hipMemcpyHostToDevice));
     }
     // sklearn's stopping rule: sum of squared centre shifts <= tol * mean per-feature variance
     double tol_abs = 0.0;

@@ -97,6 +97,13 @@ hipError_t launch_merge_layout(const MergeParams& p, int64_t stride_g, int64_t s
 hipError_t launch_kmeans_update(const float* x, const int32_t* assign, int64_t rows, int nlist, float* cents,
                                 unsigned long long* acc, int32_t* counts, double* shift, hipStream_t s);
 
+// k-means++ seeding (Arthur & Vassilvitskii D^2 sampling; sklearn's KMeans default init, create_ivf_model_reordered.py:
+// 97-103).  Step c: d2[i] = min(d2[i], ||x_i - cents[c-1]||^2) with per-block sums, then the row where the running sum
+// of d2 passes u * total becomes cents[c].  Two launches per centre, no host round trip.
+hipError_t launch_kpp_step(const float* x, const float* xnorm, int64_t rows, float* cents, int c, float* d2, double* block_sums,
+                           int n_blocks, double u, hipStream_t s);
+constexpr int kKppBlockRows = 1024;
+
 // ||v||^2 per row in the reference's AVX2 summation order (cpu_baseline.cpp:95-114).
 hipError_t launch_row_sqnorm(const float* v, int64_t rows, int dim, float* out, hipStream_t s);
 

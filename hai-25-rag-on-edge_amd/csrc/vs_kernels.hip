@@ -2091,6 +2091,121 @@ __global__ __launch_bounds__(kIvfUnitThreads) void ivf_unit_scan_kernel(const Iv
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// k-means++ seeding.  kpp_update_kernel: one workgroup per kKppBlockRows rows, 8 lanes per row (as in the IVF
+// scans); kpp_pick_kernel: one workgroup finds the block, then the row, where the running sum passes u * total.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void kpp_update_kernel(const float* __restrict__ x, const float* __restrict__ xnorm, int64_t rows,
+                                                         const float* __restrict__ centre, float* __restrict__ d2,
+                                                         double* __restrict__ block_sums) {
+    __shared__ double wsum[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rr = lane >> 3, s8 = lane & 7;
+    f32x4 cf[4];
+    float cn = 0.f;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        cf[m] = *reinterpret_cast<const f32x4*>(centre + 4 * (s8 + 8 * m));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) cn = fmaf(cf[m][i], cf[m][i], cn);
+    }
+    cn = dpp_add_xor1(cn);
+    cn = dpp_add_xor2(cn);
+    cn = dpp_add_half_mirror(cn);
+    const int64_t row_begin = (int64_t)blockIdx.x * kKppBlockRows;
+    double acc = 0.0;
+    for (int r0 = wave * 8; r0 < kKppBlockRows; r0 += 32) {
+        const int64_t row = row_begin + r0 + rr;
+        const bool ok = row < rows;
+        const float* src = x + (ok ? row : 0) * kDim + 4 * s8;
+        float dot = 0.f;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(src + 32 * m);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dot = fmaf(v[i], cf[m][i], dot);
+        }
+        dot = dpp_add_xor1(dot);
+        dot = dpp_add_xor2(dot);
+        dot = dpp_add_half_mirror(dot);
+        if (ok && s8 == 0) {
+            const float d = fmaxf(fmaf(-2.0f, dot, xnorm[row] + cn), 0.f);
+            const float nd = fminf(d2[row], d);
+            d2[row] = nd;
+            acc += (double)nd;
+        }
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) acc += __shfl_xor(acc, m);
+    if (lane == 0) wsum[wave] = acc;
+    __syncthreads();
+    if (tid == 0) block_sums[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+__global__ __launch_bounds__(1024) void kpp_pick_kernel(const float* __restrict__ x, int64_t rows, const float* __restrict__ d2,
+                                                        const double* __restrict__ block_sums, int n_blocks, double u,
+                                                        float* __restrict__ out_centre) {
+    __shared__ double s_part[1024];
+    __shared__ double s_target, s_before;
+    __shared__ int s_block;
+    __shared__ long long s_row;
+    const int tid = threadIdx.x;
+    // total and the block where the running sum passes the target (serial over <= a few thousand sums: cheap)
+    if (tid == 0) {
+        double total = 0.0;
+        for (int b = 0; b < n_blocks; ++b) total += block_sums[b];
+        const double target = u * total;
+        double run = 0.0;
+        int blk = n_blocks - 1;
+        for (int b = 0; b < n_blocks; ++b) {
+            if (run + block_sums[b] > target) {
+                blk = b;
+                break;
+            }
+            run += block_sums[b];
+        }
+        s_block = blk;
+        s_before = run;
+        s_target = target;
+        s_row = -1;
+    }
+    __syncthreads();
+    const int64_t row = (int64_t)s_block * kKppBlockRows + tid;  // kKppBlockRows == blockDim.x
+    s_part[tid] = row < rows ? (double)d2[row] : 0.0;
+    __syncthreads();
+    if (tid == 0) {
+        double run = s_before;
+        long long pick = -1;
+        const int64_t last = min<int64_t>(rows, ((int64_t)s_block + 1) * kKppBlockRows) - 1;
+        for (int t = 0; t < 1024; ++t) {
+            run += s_part[t];
+            if (run > s_target && s_part[t] > 0.0) {
+                pick = (long long)s_block * kKppBlockRows + t;
+                break;
+            }
+        }
+        if (pick < 0) {  // rounding at the very end of the range (or an all-zero block): last row with d2 > 0, else the last row
+            pick = last;
+            for (int t = 1023; t >= 0; --t)
+                if (s_part[t] > 0.0) {
+                    pick = (long long)s_block * kKppBlockRows + t;
+                    break;
+                }
+        }
+        s_row = pick;
+    }
+    __syncthreads();
+    if (tid < kDim) out_centre[tid] = x[s_row * kDim + tid];
+}
+
+hipError_t launch_kpp_step(const float* x, const float* xnorm, int64_t rows, float* cents, int c, float* d2, double* block_sums,
+                           int n_blocks, double u, hipStream_t s) {
+    hipLaunchKernelGGL(kpp_update_kernel, dim3(n_blocks), dim3(256), 0, s, x, xnorm, rows, cents + (size_t)(c - 1) * kDim, d2, block_sums);
+    hipLaunchKernelGGL(kpp_pick_kernel, dim3(1), dim3(1024), 0, s, x, rows, d2, block_sums, n_blocks, u, cents + (size_t)c * kDim);
+    return hipGetLastError();
+}
+
 hipError_t launch_ivf_unit_scan(const IvfListScanParams& p, const int32_t* units, const int32_t* n_units, int B, int num_cus,
                                 hipStream_t s) {
     static int per_cu = 0;
