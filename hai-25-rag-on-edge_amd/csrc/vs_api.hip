@@ -448,12 +448,15 @@ int bf_launch(vs_index* h, vs_index::Lane& L, const float* q_dev, int nb, int B,
     p.dbg = g_dbg;
     // the exchange pays once every wave has a few tiles left after its warm-up tiles (int8 tiles hold 64 rows)
     const bool u8_path = h->d_vecs_u8 && h->precision != 1 && !force_f32;
-    int grid, tp;
-    scan_geometry(h->n_rows, h->num_cus, grid, tp, (u8_path ? 16 : 6) * vs::kScanWaves);
-    const bool exchange = grid >= 16 && tp >= (u8_path ? 16 : 6) * vs::kScanWaves && g_xchg_first_it >= 0;
     // a multi-batch launch gets its bounds up front from a sample of the rows (three small launches for all
-    // batches): every batch then streams from its first tile on; a short call keeps the in-kernel exchange
-    const bool seeded = exchange && nb >= g_seed_min_batches;
+    // batches): every batch then streams from its first tile on, whatever the shard size (as long as the 2048
+    // sample tiles are a minority of it); a short call keeps the in-kernel exchange, which needs a few tiles per
+    // wave after its warm-up tiles (int8 tiles hold 64 rows)
+    const int64_t tiles_total = (h->n_rows + vs::kTileRows - 1) / vs::kTileRows;
+    const bool seeded = nb >= g_seed_min_batches && tiles_total >= 2 * vs::kSeedWaves && g_xchg_first_it >= 0;
+    int grid, tp;
+    scan_geometry(h->n_rows, h->num_cus, grid, tp, seeded ? 0 : (u8_path ? 16 : 6) * vs::kScanWaves);
+    const bool exchange = !seeded && grid >= 16 && tp >= (u8_path ? 16 : 6) * vs::kScanWaves && g_xchg_first_it >= 0;
     if (seeded) {
         vs::SeedParams sp{};
         sp.base = h->d_vecs;
