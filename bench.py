@@ -149,20 +149,22 @@ def main():
     flags = torch.zeros((S * BATCH,), dtype=torch.int32, device=dev)
     n_qbatches = n_queries // BATCH
 
-    def bf_step(i):
-        # steps are issued in groups of S batches: one multi-batch call (the harness loop of main.cpp:201-251)
+    def bf_step(i, n):
+        # steps are issued in groups of S batches: one multi-batch call (the harness loop of main.cpp:201-251);
+        # the last group of a run of n steps may be shorter, so that exactly n steps are processed
         s = i % S
-        if s != S - 1:
+        if s != S - 1 and i != n - 1:
             return
-        g0 = (i // S) * S  # first batch of the group; the query set is cycled
+        gs = s + 1  # batches in this group
+        g0 = i - s  # first batch of the group; the query set is cycled
         qb = g0 % n_qbatches
-        if qb + S > n_qbatches:
+        if qb + gs > n_qbatches:
             qb = 0
         qp = q_dev.data_ptr() + qb * BATCH * DIM * 4
         if world == 1:
-            bf.search_dev_multi(qp, S, BATCH, K, out_i.data_ptr(), out_d.data_ptr(), flags.data_ptr(), sptr)
+            bf.search_dev_multi(qp, gs, BATCH, K, out_i.data_ptr(), out_d.data_ptr(), flags.data_ptr(), sptr)
         else:
-            bf.search_dev_multi(qp, S, BATCH, K, loc_i_ptr, loc_d_ptr, 0, sptr)
+            bf.search_dev_multi(qp, gs, BATCH, K, loc_i_ptr, loc_d_ptr, 0, sptr)
             all_gather(gath, loc)
             pkg.topk_merge_dev(gath.data_ptr(), gath.data_ptr() + lay.ids_offset * 4, world, S * BATCH, K1, K1,
                                out_d.data_ptr(), out_i.data_ptr(), flags.data_ptr(), sptr, stride_g=lay.stride_g)
@@ -184,11 +186,11 @@ def main():
 
     def timed(step_fn, nsteps, nwarm):
         for i in range(nwarm):
-            step_fn(i)
+            step_fn(i, nwarm)
         barrier()
         t = time.perf_counter()
         for i in range(nsteps):
-            step_fn(i)
+            step_fn(i, nsteps)
         barrier()
         el = time.perf_counter() - t
         if dist is not None:
@@ -197,9 +199,8 @@ def main():
             el = float(tt.item())
         return el
 
-    # round the step counts to whole groups so that every timed step is complete
-    steps = max(S, (steps // S) * S)
-    warmup = max(S, (warmup // S) * S)
+    steps = max(1, steps)
+    warmup = max(1, warmup)
 
     # correctness spot check on the first batch before timing (rank 0, against the oracle at small scale
     # happens in tests; here: self-consistency of the sharded path vs. properties)
@@ -209,8 +210,9 @@ def main():
     bf.prof_enable(False)
     qps = steps * BATCH / elapsed
     ms_per_step = elapsed / steps * 1e3
-    # the prof window covers warmup + timed launches; all are identical launches
-    kern_avg_s = (kern_ms / max(kern_n, 1)) * 1e-3
+    # the prof window covers the warmup + timed launches = warmup + steps batches (the last launch of a run may
+    # hold fewer than S batches): scale to a launch of S batches
+    kern_avg_s = (kern_ms * 1e-3) / (warmup + steps) * S if kern_n else 0.0
     rows_local = r1 - r0
     algo_bytes = (4 * rows_local * DIM + 4 * rows_local + 4 * BATCH * DIM + 8 * BATCH * K) * S  # SURVEY.md 8(d) x S batches per launch
     achieved = algo_bytes / kern_avg_s / 1e9 if kern_avg_s > 0 else 0.0
@@ -246,7 +248,7 @@ def main():
             torch.cuda.synchronize()
             assert np.array_equal(out_d.cpu().numpy(), fp32_d) and np.array_equal(out_i.cpu().numpy(), fp32_i), \
                 "int8 path differs from the fp32 path"
-            k8_s = (k8_ms / max(k8_n, 1)) * 1e-3
+            k8_s = (k8_ms * 1e-3) / (warmup + steps) * S if k8_n else 0.0
             b8 = (rows_local * DIM + 4 * rows_local + 4 * BATCH * DIM + 8 * BATCH * K) * S  # u8 rows + i32 row terms
             int8_info = {"metric": "QPS, same workload, rows stored as u8 + int8 MFMA (bit-identical results)",
                          "value": round(steps * BATCH / el8, 1), "ms_per_step": round(el8 / steps * 1e3, 5),
@@ -289,19 +291,20 @@ def main():
         iout_d = torch.zeros((S * BATCH, K), dtype=torch.float32, device=dev)
         iout_i = torch.zeros((S * BATCH, K), dtype=torch.int32, device=dev)
 
-        def ivf_step(i):
-            # like bf_step: groups of S independent batches per call (two alternating streams inside the library)
+        def ivf_step(i, n):
+            # like bf_step: groups of (up to) S independent batches per call (four streams inside the library)
             s = i % S
-            if s != S - 1:
+            if s != S - 1 and i != n - 1:
                 return
-            qb = ((i // S) * S) % n_qbatches
-            if qb + S > n_qbatches:
+            gs = s + 1
+            qb = (i - s) % n_qbatches
+            if qb + gs > n_qbatches:
                 qb = 0
             qp = q_dev.data_ptr() + qb * BATCH * DIM * 4
             if world == 1:
-                ivf.search_dev_multi(qp, S, BATCH, K, NPROBE, iout_i.data_ptr(), iout_d.data_ptr(), sptr)
+                ivf.search_dev_multi(qp, gs, BATCH, K, NPROBE, iout_i.data_ptr(), iout_d.data_ptr(), sptr)
             else:
-                ivf.search_dev_multi(qp, S, BATCH, K, NPROBE, iloc.data_ptr() + ilay.id_offset(0) * 4,
+                ivf.search_dev_multi(qp, gs, BATCH, K, NPROBE, iloc.data_ptr() + ilay.id_offset(0) * 4,
                                      iloc.data_ptr() + ilay.dist_offset(0) * 4, sptr)
                 all_gather(igath, iloc)
                 pkg.topk_merge_dev(igath.data_ptr(), igath.data_ptr() + ilay.ids_offset * 4, world, S * BATCH, K, K,
