@@ -250,3 +250,44 @@ def test_topk_merge_equals_unsharded(gpu_pkg):
         gpu_pkg.topk_merge_dev(gd.data_ptr(), gi.data_ptr(), G, 32, K1, K1, od.data_ptr(), oi.data_ptr(), fl.data_ptr(), s)
         torch.cuda.synchronize()
         assert torch.equal(od, d_all) and torch.equal(oi, i_all)
+
+
+def test_seeded_multi_batch_exact(gpu_pkg):
+    """Launches of >= 4 batches on a shard of >= 65536 rows take their bounds from the seed launches (int8 seed on
+    integer data) and stream from the first tile on.  7 full batches + a ragged one against the oracle, both
+    precisions, plus exact hits, far-apart duplicates and a batch with a non-integer query (no bound from the int8
+    seed for that batch; the int8 scan skips it and the host reruns it in fp32)."""
+    base = gpu_pkg.synth_sift(150000, seed=21)
+    q = gpu_pkg.synth_sift(7 * 32 + 9, seed=22)
+    q[3] = base[123456]
+    base[140000] = base[17]
+    q[40] = base[17]
+    _check_exact(gpu_pkg, base, q, 5)
+    _check_exact(gpu_pkg, base, q[:160], 10)
+    q2 = q.copy()
+    q2[70, 5] += 0.5  # batch 2 is no longer byte valued
+    oi, od = oracle.search_bf(base, q2, 5)
+    with gpu_pkg.BruteForceIndex(base) as idx:
+        for precision in (1, 0):
+            idx.set_precision(precision)
+            ids, d = idx.search(q2, 5)
+            assert np.array_equal(ids, oi), f"precision {precision}"
+            assert np.allclose(d, od, rtol=0, atol=1e-2)
+
+
+def test_seeded_multi_batch_non_integer_base(gpu_pkg):
+    """The fp32 seed kernel (no int8 copy): same tolerance statement as test_non_integer_data_within_tolerance,
+    on a multi-batch call."""
+    rng = np.random.default_rng(15)
+    base = rng.normal(0, 1, size=(70000, 128)).astype(np.float32)
+    q = rng.normal(0, 1, size=(5 * 32, 128)).astype(np.float32)
+    with gpu_pkg.BruteForceIndex(base) as idx:
+        ids, d = idx.search(q, 5)
+    oi, od = oracle.search_bf(base, q, 5)
+    scale = float((q ** 2).sum(1).max() + (base ** 2).sum(1).max())
+    tol = 2e-6 * scale
+    assert np.allclose(d, od, rtol=0, atol=tol)
+    # ids agree wherever the oracle's own gap to the neighbouring distances exceeds the re-association error
+    same = (ids == oi)
+    gap = np.minimum(np.abs(np.diff(od, axis=1, prepend=-np.inf)), np.abs(np.diff(od, axis=1, append=np.inf)))
+    assert same[gap > 4 * tol].all() and same.mean() > 0.99
