@@ -140,6 +140,8 @@ hipError_t launch_ivf_coarse_pick(const float* q, int B, const float* cents, con
 struct IvfListScanParams {
     const float* vecs;        // [n_rows][128] cluster-reordered
     const float* vnorm;       // [n_rows]
+    const int8_t* vecs_u8;    // optional exact int8 copy (x - 128) of the rows + row terms (unit scan: int8 MFMA, 4x fewer
+    const int32_t* rterm;     //   bytes) -- used for a batch whose queries are integers in [0, 255] too, else the fp32 rows
     const int32_t* offsets;   // [nlist+1]
     const int32_t* chunk_list;  // [n_chunks] list of each (list, 1024-row chunk) work item
     const int32_t* chunk_row0;  // [n_chunks] first row (absolute, local array)

@@ -2048,6 +2048,75 @@ __global__ __launch_bounds__(kIvfUnitThreads) void ivf_unit_scan_kernel(const Iv
     }
     __syncthreads();
     const int nw = (int)gridDim.x * 4;
+    // ---- int8 path: rows stored as (x - 128) bytes, the batch's queries converted once per workgroup; a unit is two
+    //      16-row MFMA tiles against 16-query column blocks of its list's query set; distances are the same integers
+    //      the fp32 path computes (scan_kernel PREC = 1).  A batch with a non-integer query uses the fp32 rows below.
+    if (p.vecs_u8 && p.metric == 0) {
+        typedef int i32x4 __attribute__((ext_vector_type(4)));
+        __shared__ __attribute__((aligned(16))) int q8_s[kMaxBatch * 32];  // [query][128 bytes]
+        __shared__ int qsum_s[kMaxBatch];
+        if (tid < kMaxBatch) qsum_s[tid] = 0;
+        __syncthreads();
+        bool q_ok = true;
+        for (int i = tid; i < B * 32; i += kIvfUnitThreads) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(q_s + 4 * i);
+            unsigned word = 0;
+            int part = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int xi = (int)v[e];
+                q_ok = q_ok && ((float)xi == v[e]) && xi >= 0 && xi <= 255;
+                part += xi - 128;
+                word |= ((unsigned)((xi - 128) & 0xff)) << (8 * e);
+            }
+            q8_s[i] = (int)word;
+            atomicAdd(&qsum_s[i >> 5], part);
+        }
+        if (__syncthreads_and(q_ok ? 1 : 0)) {
+            const int r = lane & 15, g = lane >> 4;
+            for (int u = (int)blockIdx.x * 4 + wave; u < n_units; u += nw) {
+                const int unit = __builtin_amdgcn_readfirstlane(units[u]);
+                const int chunk = unit >> 5;
+                const int c = p.chunk_list[chunk];
+                const int nq = min(p.lcnt[c], kMaxBatch);
+                const int list_start = p.offsets[c];
+                const int r_end = p.chunk_row0[chunk] + p.chunk_rows[chunk];
+                const int r0 = p.chunk_row0[chunk] + 32 * (unit & 31);
+                // A operands of the two tiles: bytes 16 g .. and 64 + 16 g .. of row r0 + 16 t + r (rows past the chunk
+                // read the chunk's last row and are never written)
+                i32x4 a0[2], a1[2], rt[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int row = min(r0 + 16 * t + r, r_end - 1);
+                    a0[t] = *reinterpret_cast<const i32x4*>(p.vecs_u8 + (int64_t)row * kDim + 16 * g);
+                    a1[t] = *reinterpret_cast<const i32x4*>(p.vecs_u8 + (int64_t)row * kDim + 64 + 16 * g);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) rt[t][j] = p.rterm[min(r0 + 16 * t + 4 * g + j, r_end - 1)];
+                }
+                for (int cb = 0; cb < nq; cb += 16) {
+                    const int sq = cb + r;  // this lane's query slot in the list's query set
+                    const bool live = sq < nq;
+                    const int qi = live ? p.lq[c * kMaxBatch + sq] : 0;
+                    const long long cbase = live ? p.lbase[c * kMaxBatch + sq] : 0;
+                    const i32x4 b0 = *reinterpret_cast<const i32x4*>(q8_s + qi * 32 + 4 * g);
+                    const i32x4 b1 = *reinterpret_cast<const i32x4*>(q8_s + qi * 32 + 16 + 4 * g);
+                    const int qterm = (int)qn_s[qi] - 256 * qsum_s[qi] - 4194304;
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        i32x4 acc = {0, 0, 0, 0};
+                        acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0[t], b0, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1[t], b1, acc, 0, 0, 0);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int row = r0 + 16 * t + 4 * g + j;
+                            if (live && row < r_end) p.cand[cbase + (row - list_start)] = (float)(qterm + rt[t][j] - 2 * acc[j]);
+                        }
+                    }
+                }
+            }
+            return;
+        }
+    }
     for (int u = (int)blockIdx.x * 4 + wave; u < n_units; u += nw) {
         const int unit = __builtin_amdgcn_readfirstlane(units[u]);
         const int chunk = unit >> 5;

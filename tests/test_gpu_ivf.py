@@ -279,3 +279,28 @@ def test_sweep_driver_end_to_end(gpu_pkg, tmp_path):
     assert rec[0] <= rec[1] <= rec[2] and rec[2] == 100.0
     assert all(float(r["qps"]) > 0 and float(r["avg_candidates"]) > 0 for r in rows)
     assert os.path.exists(tmp_path / "idx" / "ivf_config.json")
+
+
+def test_int8_rows_and_fp32_fallback_agree(gpu_pkg):
+    """The list scan reads the exact int8 copy of byte-valued rows when the batch's queries are byte valued too, and
+    the fp32 rows otherwise (decided per batch inside the kernel).  (i) integer batch: distances equal the exact
+    integer distances; (ii) the same queries with one made non-integer (whole batch on the fp32 rows): every other
+    query keeps its result bit for bit; (iii) a non-byte-valued base has no int8 copy and still matches."""
+    base, cents, vr, off, r2o = _make_index(gpu_pkg, n=20000, nlist=64, seed=3)
+    q = gpu_pkg.synth_sift(32, seed=91)
+    k, nprobe = 5, 16
+    with gpu_pkg.IVFIndex(vectors_reordered=vr, centroids=cents, cluster_offsets=off, reorder_to_original=r2o) as ivf:
+        ids, d, _ = ivf.searchBatch(q, 32, k, nprobe)
+        ex = oracle.exact_int_dists(q, base)
+        assert np.array_equal(np.take_along_axis(ex, ids.astype(np.int64), 1).astype(np.float32), d)
+        q2 = q.copy()
+        q2[5, 7] += 0.5
+        ids2, d2, _ = ivf.searchBatch(q2, 32, k, nprobe)
+        keep = np.arange(32) != 5
+        assert np.array_equal(ids2[keep], ids[keep]) and np.array_equal(d2[keep], d[keep])
+        oi, od, _ = oracle.ivf_search(vr, off, r2o, cents, q2, k, nprobe)
+        assert np.array_equal(ids2[5], oi[5]) and np.allclose(d2[5], od[5], rtol=0, atol=1e-2)
+    # scaled base: integers up to 436, no int8 copy
+    with gpu_pkg.IVFIndex(vectors_reordered=vr * 2.0, centroids=cents * 2.0, cluster_offsets=off, reorder_to_original=r2o) as ivf2:
+        ids3, d3, _ = ivf2.searchBatch(q * 2.0, 32, k, nprobe)
+        assert np.array_equal(ids3, ids) and np.array_equal(d3, d * 4.0)
