@@ -133,6 +133,13 @@ struct vs_index {
         int32_t* d_units = nullptr;
     } ivf_alt[7];
     int ivf_lanes = 0;  // streams set up by vs_ivf_search_dev_multi (0 = not yet)
+    // multi-batch launches (blockIdx.y = batch): kMaxMulti copies of the per-batch scratch, one slab per batch plus a
+    // small block per batch that is zeroed with one memset per group
+    char* mb_slab = nullptr;
+    int32_t* mb_zslab = nullptr;
+    long long mb_slab_stride = 0, mb_zslab_stride = 0, mb_cand_stride = 0;
+    long long mb_off_lq = 0, mb_off_lbase = 0, mb_off_qoff = 0, mb_off_probes = 0, mb_off_gd = 0, mb_off_gp = 0, mb_off_units = 0,
+              mb_off_cand = 0;
     hipStream_t ivf_stream[8] = {};
     hipEvent_t ivf_fork = nullptr, ivf_join[8] = {};
     int64_t n_units_max = 0;
@@ -201,6 +208,8 @@ void free_all(vs_index* h) {
             if (h->ivf_join[i]) (void)hipEventDestroy(h->ivf_join[i]);
         }
         if (h->ivf_fork) (void)hipEventDestroy(h->ivf_fork);
+        if (h->mb_slab) (void)hipFree(h->mb_slab);
+        if (h->mb_zslab) (void)hipFree(h->mb_zslab);
     }
     for (auto& ps : h->prof_slot)
         for (auto e : ps.ev) (void)hipEventDestroy(e);
@@ -688,6 +697,113 @@ int ivf_batch_dev(vs_index* h, const float* q_dev, int B, int k, int nprobe, flo
     m.out_i = out_i;
     m.id_map = h->d_r2o;
     HIPCHK(vs::launch_merge_layout(m, kcap, (int64_t)nprobe * kcap, s));
+    return VS_OK;
+}
+
+// tuning knob (VSEARCH_IVF_MULTI=0): vs_ivf_search_dev_multi deals batches to streams instead of launching every
+// kernel once for a whole group of batches
+int g_ivf_multi = [] {
+    const char* e = getenv("VSEARCH_IVF_MULTI");
+    return e ? atoi(e) : 1;
+}();
+
+int ensure_ivf_mb(vs_index* h, int nprobe, hipStream_t s) {
+    const long long need = std::min<long long>(h->n_rows, (long long)nprobe * h->max_list);
+    const long long cstride = (need + 63) & ~63ll;
+    if (h->mb_slab && h->mb_cand_stride >= cstride) return VS_OK;
+    HIPCHK(hipStreamSynchronize(s));
+    if (h->mb_slab) (void)hipFree(h->mb_slab);
+    if (h->mb_zslab) (void)hipFree(h->mb_zslab);
+    h->mb_slab = nullptr;
+    h->mb_zslab = nullptr;
+    auto al = [](long long x) { return (x + 255) & ~255ll; };
+    long long off = 0;
+    h->mb_off_lq = off;      off = al(off + (long long)h->nlist * 32 * 4);
+    h->mb_off_lbase = off;   off = al(off + (long long)h->nlist * 32 * 8);
+    h->mb_off_qoff = off;    off = al(off + 32ll * (vs::kIvfMaxProbe + 1) * 4);
+    h->mb_off_probes = off;  off = al(off + 32ll * kMaxNprobe * 4);
+    h->mb_off_gd = off;      off = al(off + 32ll * 4096 * 4);
+    h->mb_off_gp = off;      off = al(off + 32ll * 4096 * 4);
+    h->mb_off_units = off;   off = al(off + std::max<long long>(h->n_units_max, 1) * 4);
+    h->mb_off_cand = off;    off = al(off + 32ll * cstride * 4);
+    h->mb_slab_stride = off;
+    h->mb_zslab_stride = (((long long)h->nlist + 96 + 512 + 8) + 63) & ~63ll;  // ints
+    h->mb_cand_stride = cstride;
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&h->mb_slab), (size_t)h->mb_slab_stride * kMaxMulti));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&h->mb_zslab), (size_t)h->mb_zslab_stride * kMaxMulti * sizeof(int32_t)));
+    return VS_OK;
+}
+
+// nb <= kMaxMulti independent batches, every kernel launched once for all of them (blockIdx.y = batch)
+int ivf_group_dev(vs_index* h, const float* q_dev, int nb, int B, int k, int nprobe, float* out_d, int32_t* out_i, hipStream_t s) {
+    int rc = ensure_ivf_mb(h, nprobe, s);
+    if (rc) return rc;
+    HIPCHK(hipMemsetAsync(h->mb_zslab, 0, (size_t)h->mb_zslab_stride * nb * sizeof(int32_t), s));
+    vs::IvfMulti mb{};
+    mb.slab = h->mb_slab_stride;
+    mb.zslab = h->mb_zslab_stride * (long long)sizeof(int32_t);
+    mb.q = (long long)B * vs::kDim * sizeof(float);
+    mb.out_d = (long long)B * k * sizeof(float);
+    mb.out_i = (long long)B * k * sizeof(int32_t);
+    int32_t* z = h->mb_zslab;
+    char* sl = h->mb_slab;
+    int32_t* probes = reinterpret_cast<int32_t*>(sl + h->mb_off_probes);
+    vs::IvfGroup grp{};
+    grp.offsets = h->d_offsets;
+    grp.lcnt = z;
+    grp.lq = reinterpret_cast<int32_t*>(sl + h->mb_off_lq);
+    grp.lbase = reinterpret_cast<long long*>(sl + h->mb_off_lbase);
+    grp.qoff = reinterpret_cast<int32_t*>(sl + h->mb_off_qoff);
+    grp.cand_stride = h->mb_cand_stride;
+    grp.cand_count = h->d_cand;
+    grp.chunk_list = h->d_chunk_list;
+    grp.chunk_rows = h->d_chunk_rows;
+    grp.n_chunks = h->n_chunks;
+    grp.plan_done = z + h->nlist + 96 + 512;
+    grp.n_units = z + h->nlist + 96 + 512 + 1;
+    grp.units = reinterpret_cast<int32_t*>(sl + h->mb_off_units);
+    grp.mb = mb;
+    HIPCHK(vs::launch_ivf_coarse_pick(q_dev, B, h->d_centroids, h->d_cnorm, h->nlist, nprobe, h->metric, probes, grp, s, nb));
+    vs::IvfListScanParams lp{};
+    lp.vecs = h->d_vecs;
+    lp.vnorm = h->d_norm;
+    if (h->d_vecs_u8 && g_ivf_i8) {
+        lp.vecs_u8 = h->d_vecs_u8;
+        lp.rterm = h->d_rterm;
+    }
+    lp.offsets = h->d_offsets;
+    lp.chunk_list = h->d_chunk_list;
+    lp.chunk_row0 = h->d_chunk_row0;
+    lp.chunk_rows = h->d_chunk_rows;
+    lp.q = q_dev;
+    lp.lcnt = grp.lcnt;
+    lp.lq = grp.lq;
+    lp.lbase = grp.lbase;
+    lp.cand = reinterpret_cast<float*>(sl + h->mb_off_cand);
+    lp.metric = h->metric;
+    lp.mb = mb;
+    prof_begin(h, 1, s);
+    HIPCHK(vs::launch_ivf_unit_scan(lp, grp.units, grp.n_units, B, h->num_cus, s, nb));
+    prof_end(h, 1, s);
+    vs::IvfSelectParams sp{};
+    sp.cand = lp.cand;
+    sp.cand_stride = h->mb_cand_stride;
+    sp.qoff = grp.qoff;
+    sp.probes = probes;
+    sp.offsets = h->d_offsets;
+    sp.id_map = h->d_r2o;
+    sp.tq = reinterpret_cast<unsigned*>(z + h->nlist + 96);
+    sp.gcand_d = reinterpret_cast<float*>(sl + h->mb_off_gd);
+    sp.gcand_p = reinterpret_cast<int32_t*>(sl + h->mb_off_gp);
+    sp.gcnt = z + h->nlist;
+    sp.gdone = z + h->nlist + 32;
+    sp.govf = z + h->nlist + 64;
+    sp.nprobe = nprobe;
+    sp.k = k;
+    sp.out_d = out_d;
+    sp.out_i = out_i;
+    sp.mb = mb;
+    HIPCHK(vs::launch_ivf_select(sp, B, s, nb));
     return VS_OK;
 }
 
@@ -1383,6 +1499,15 @@ int vs_ivf_search_dev_multi(vs_index* h, const float* queries_dev, int n_batches
         for (int b = 0; b < n_batches && !rc; ++b)
             rc = ivf_batch_dev(h, queries_dev + (size_t)b * B * vs::kDim, B, k, nprobe, dists_dev + (size_t)b * B * k,
                                ids_dev + (size_t)b * B * k, user, nullptr);
+        return rc;
+    }
+    if (g_ivf_multi && g_ivf_grouped && g_ivf_plan && h->nlist <= 2048 && h->n_chunks > 0 && h->d_units && pick_kcap(k)) {
+        // every kernel once per group of up to kMaxMulti batches
+        for (int b0 = 0; b0 < n_batches && !rc; b0 += kMaxMulti) {
+            const int nb = std::min(kMaxMulti, n_batches - b0);
+            rc = ivf_group_dev(h, queries_dev + (size_t)b0 * B * vs::kDim, nb, B, k, nprobe, dists_dev + (size_t)b0 * B * k,
+                               ids_dev + (size_t)b0 * B * k, user);
+        }
         return rc;
     }
     if ((rc = ensure_ivf_alt(h))) return rc;

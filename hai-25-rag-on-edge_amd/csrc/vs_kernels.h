@@ -114,6 +114,14 @@ hipError_t launch_pick_probes(const float* scores, int64_t ld, int B, int nlist,
 
 constexpr int kIvfMaxProbe = 256;
 
+// Multi-batch IVF launches: blockIdx.y = batch.  Every per-batch pointer of the parameter structs below points at
+// batch 0's copy; batch y's copy lies `slab` bytes (scratch written and read per batch), `zslab` bytes (the block
+// that is zeroed per batch: list counters, selection counters, plan counters), `q` bytes (queries) or `out` bytes
+// (results) further on.  All zero = single-batch launch.
+struct IvfMulti {
+    long long slab, zslab, q, out_d, out_i;
+};
+
 // Grouping tables of the list-major IVF scan, filled by the coarse/pick kernel (all optional: lcnt == nullptr = off)
 struct IvfGroup {
     const int32_t* offsets;          // [nlist+1] local list offsets
@@ -131,11 +139,12 @@ struct IvfGroup {
     int32_t* plan_done;              // arrival counter (pre-set to 0)
     int32_t* units;                  // [sum ceil(chunk_rows / 32)]
     int32_t* n_units;                // [1]
+    IvfMulti mb;
 };
 
 // Coarse L2 scores against the centroids + the nprobe nearest lists per query, one launch (nlist <= 2048).
 hipError_t launch_ivf_coarse_pick(const float* q, int B, const float* cents, const float* cnorm, int nlist, int nprobe,
-                                  int metric, int32_t* probes, const IvfGroup& grp, hipStream_t s);
+                                  int metric, int32_t* probes, const IvfGroup& grp, hipStream_t s, int n_batches = 1);
 
 struct IvfListScanParams {
     const float* vecs;        // [n_rows][128] cluster-reordered
@@ -152,11 +161,12 @@ struct IvfListScanParams {
     const long long* lbase;
     float* cand;              // [B][cand_stride] candidate scores, probe order
     int metric;
+    IvfMulti mb;
 };
 hipError_t launch_ivf_list_scan(const IvfListScanParams& p, int n_chunks, hipStream_t s);
 // planned variant: one wave per 32-row unit of the plan (IvfGroup::units); B = queries in the batch
 hipError_t launch_ivf_unit_scan(const IvfListScanParams& p, const int32_t* units, const int32_t* n_units, int B, int num_cus,
-                                hipStream_t s);
+                                hipStream_t s, int n_batches = 1);
 
 struct IvfSelectParams {
     const float* cand;
@@ -174,8 +184,9 @@ struct IvfSelectParams {
     int nprobe, k;
     float* out_d;             // [B][k]
     int32_t* out_i;
+    IvfMulti mb;
 };
-hipError_t launch_ivf_select(const IvfSelectParams& p, int B, hipStream_t s);
+hipError_t launch_ivf_select(const IvfSelectParams& p, int B, hipStream_t s, int n_batches = 1);
 
 struct IvfScanParams {
     const float* vecs;        // [n_rows][128] cluster-reordered (vectors_reordered.npy)

@@ -12,6 +12,7 @@
 // Wavefront = 64 lanes everywhere; nothing here is written for 32-wide warps.
 #include "vs_kernels.h"
 #include <type_traits>
+#include <algorithm>
 
 namespace vs {
 
@@ -1572,10 +1573,28 @@ __device__ __forceinline__ float dpp_add_xor1(float x);
 __device__ __forceinline__ float dpp_add_xor2(float x);
 __device__ __forceinline__ float dpp_add_half_mirror(float x);
 
+// multi-batch launches: advance a per-batch pointer to batch blockIdx.y's copy (see IvfMulti)
+template <class T>
+__device__ __forceinline__ T* mb_adv(T* ptr, long long bytes) {
+    return ptr ? reinterpret_cast<T*>(reinterpret_cast<char*>(const_cast<typename std::remove_const<T>::type*>(ptr)) + bytes) : ptr;
+}
+
 template <int EPT>
 __global__ __launch_bounds__(1024) void ivf_coarse_pick_kernel(const float* __restrict__ q, const float* __restrict__ cents,
                                                                const float* __restrict__ cnorm, int nlist, int nprobe,
-                                                               int metric, int32_t* __restrict__ probes, const IvfGroup grp) {
+                                                               int metric, int32_t* __restrict__ probes, IvfGroup grp) {
+    {   // multi-batch launch: this workgroup's batch
+        const long long y = blockIdx.y;
+        q = mb_adv(q, y * grp.mb.q);
+        probes = mb_adv(probes, y * grp.mb.slab);
+        grp.lcnt = mb_adv(grp.lcnt, y * grp.mb.zslab);
+        grp.plan_done = mb_adv(grp.plan_done, y * grp.mb.zslab);
+        grp.n_units = mb_adv(grp.n_units, y * grp.mb.zslab);
+        grp.lq = mb_adv(grp.lq, y * grp.mb.slab);
+        grp.lbase = mb_adv(grp.lbase, y * grp.mb.slab);
+        grp.qoff = mb_adv(grp.qoff, y * grp.mb.slab);
+        grp.units = mb_adv(grp.units, y * grp.mb.slab);
+    }
     __shared__ float sc[256 * EPT];
     __shared__ int s_probe[256];
     __shared__ int s_off[257];
@@ -1903,10 +1922,10 @@ __global__ __launch_bounds__(256) void ivf_scan_kernel(const IvfScanParams p) {
 }
 
 hipError_t launch_ivf_coarse_pick(const float* q, int B, const float* cents, const float* cnorm, int nlist, int nprobe,
-                                  int metric, int32_t* probes, const IvfGroup& grp, hipStream_t s) {
+                                  int metric, int32_t* probes, const IvfGroup& grp, hipStream_t s, int n_batches) {
     if (nprobe > 256) return hipErrorInvalidValue;
-    if (nlist <= 1024) hipLaunchKernelGGL(ivf_coarse_pick_kernel<4>, dim3(B), dim3(1024), 0, s, q, cents, cnorm, nlist, nprobe, metric, probes, grp);
-    else if (nlist <= 2048) hipLaunchKernelGGL(ivf_coarse_pick_kernel<8>, dim3(B), dim3(1024), 0, s, q, cents, cnorm, nlist, nprobe, metric, probes, grp);
+    if (nlist <= 1024) hipLaunchKernelGGL(ivf_coarse_pick_kernel<4>, dim3(B, n_batches), dim3(1024), 0, s, q, cents, cnorm, nlist, nprobe, metric, probes, grp);
+    else if (nlist <= 2048) hipLaunchKernelGGL(ivf_coarse_pick_kernel<8>, dim3(B, n_batches), dim3(1024), 0, s, q, cents, cnorm, nlist, nprobe, metric, probes, grp);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
@@ -2018,8 +2037,18 @@ __global__ __launch_bounds__(kIvfScanThreads) void ivf_list_scan_kernel(const Iv
 // 32-row units of the plan (no barriers, no per-list staging): 4 row groups of 8 rows are loaded (8 lanes per
 // row, whole 128-byte lines per wave-instruction) and scored against every query that probes the unit's list.
 constexpr int kIvfUnitThreads = 256;
-__global__ __launch_bounds__(kIvfUnitThreads) void ivf_unit_scan_kernel(const IvfListScanParams p, const int32_t* __restrict__ units,
+__global__ __launch_bounds__(kIvfUnitThreads) void ivf_unit_scan_kernel(IvfListScanParams p, const int32_t* __restrict__ units,
                                                                       const int32_t* __restrict__ n_units_ptr, int B) {
+    {   // multi-batch launch: this workgroup's batch
+        const long long y = blockIdx.y;
+        p.q = mb_adv(p.q, y * p.mb.q);
+        p.lcnt = mb_adv(p.lcnt, y * p.mb.zslab);
+        p.lq = mb_adv(p.lq, y * p.mb.slab);
+        p.lbase = mb_adv(p.lbase, y * p.mb.slab);
+        p.cand = mb_adv(p.cand, y * p.mb.slab);
+        units = mb_adv(units, y * p.mb.slab);
+        n_units_ptr = mb_adv(n_units_ptr, y * p.mb.zslab);
+    }
     __shared__ __attribute__((aligned(16))) float q_s[kMaxBatch * kDim];
     __shared__ float qn_s[kMaxBatch];
     const int tid = threadIdx.x;
@@ -2276,14 +2305,16 @@ hipError_t launch_kpp_step(const float* x, const float* xnorm, int64_t rows, flo
 }
 
 hipError_t launch_ivf_unit_scan(const IvfListScanParams& p, const int32_t* units, const int32_t* n_units, int B, int num_cus,
-                                hipStream_t s) {
+                                hipStream_t s, int n_batches) {
     static int per_cu = 0;
     if (!per_cu) {
         int nb = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ivf_unit_scan_kernel, kIvfUnitThreads, 0) != hipSuccess || nb < 1) nb = 4;
         per_cu = nb > 8 ? 8 : nb;
     }
-    hipLaunchKernelGGL(ivf_unit_scan_kernel, dim3(num_cus * per_cu), dim3(kIvfUnitThreads), 0, s, p, units, n_units, B);
+    // one resident grid for a single batch; a multi-batch launch shares about two resident grids among its batches
+    const int wgs = n_batches > 1 ? std::max(16, 2 * num_cus * per_cu / n_batches) : num_cus * per_cu;
+    hipLaunchKernelGGL(ivf_unit_scan_kernel, dim3(wgs, n_batches), dim3(kIvfUnitThreads), 0, s, p, units, n_units, B);
     return hipGetLastError();
 }
 
@@ -2305,7 +2336,21 @@ constexpr int kSelCap = 4096;     // global candidate slots per query
 // Pass 1 of the selection: every workgroup takes 1/8 of a query's candidate scores, computes its 256
 // thread minima and their k-th smallest -- a bound backed by k distinct candidates -- and folds it
 // into the query's bound with an atomic (complemented ordered floats: 0 = no bound yet, atomicMax).
-__global__ __launch_bounds__(256) void ivf_bound_kernel(const IvfSelectParams p) {
+__global__ __launch_bounds__(256) void ivf_bound_kernel(IvfSelectParams p) {
+    {   // multi-batch launch: this workgroup's batch
+        const long long y = blockIdx.y;
+        p.cand = mb_adv(p.cand, y * p.mb.slab);
+        p.qoff = mb_adv(p.qoff, y * p.mb.slab);
+        p.probes = mb_adv(p.probes, y * p.mb.slab);
+        p.gcand_d = mb_adv(p.gcand_d, y * p.mb.slab);
+        p.gcand_p = mb_adv(p.gcand_p, y * p.mb.slab);
+        p.tq = mb_adv(p.tq, y * p.mb.zslab);
+        p.gcnt = mb_adv(p.gcnt, y * p.mb.zslab);
+        p.gdone = mb_adv(p.gdone, y * p.mb.zslab);
+        p.govf = mb_adv(p.govf, y * p.mb.zslab);
+        p.out_d = mb_adv(p.out_d, y * p.mb.out_d);
+        p.out_i = mb_adv(p.out_i, y * p.mb.out_i);
+    }
     __shared__ float mn[256];
     const int q = blockIdx.x / kSelSplit, part = blockIdx.x % kSelSplit;
     const int tid = threadIdx.x;
@@ -2336,7 +2381,21 @@ __global__ __launch_bounds__(256) void ivf_bound_kernel(const IvfSelectParams p)
 }
 
 
-__global__ __launch_bounds__(256) void ivf_select_kernel(const IvfSelectParams p) {
+__global__ __launch_bounds__(256) void ivf_select_kernel(IvfSelectParams p) {
+    {   // multi-batch launch: this workgroup's batch
+        const long long y = blockIdx.y;
+        p.cand = mb_adv(p.cand, y * p.mb.slab);
+        p.qoff = mb_adv(p.qoff, y * p.mb.slab);
+        p.probes = mb_adv(p.probes, y * p.mb.slab);
+        p.gcand_d = mb_adv(p.gcand_d, y * p.mb.slab);
+        p.gcand_p = mb_adv(p.gcand_p, y * p.mb.slab);
+        p.tq = mb_adv(p.tq, y * p.mb.zslab);
+        p.gcnt = mb_adv(p.gcnt, y * p.mb.zslab);
+        p.gdone = mb_adv(p.gdone, y * p.mb.zslab);
+        p.govf = mb_adv(p.govf, y * p.mb.zslab);
+        p.out_d = mb_adv(p.out_d, y * p.mb.out_d);
+        p.out_i = mb_adv(p.out_i, y * p.mb.out_i);
+    }
     __shared__ float s_t;
     __shared__ int s_cnt, s_base, s_last;
     __shared__ float cd[1024];
@@ -2493,10 +2552,10 @@ __global__ __launch_bounds__(256) void ivf_select_kernel(const IvfSelectParams p
     }
 }
 
-hipError_t launch_ivf_select(const IvfSelectParams& p, int B, hipStream_t s) {
+hipError_t launch_ivf_select(const IvfSelectParams& p, int B, hipStream_t s, int n_batches) {
     if (p.k > 16 || p.nprobe > 256) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(ivf_bound_kernel, dim3(B * kSelSplit), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(ivf_select_kernel, dim3(B * kSelSplit), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(ivf_bound_kernel, dim3(B * kSelSplit, n_batches), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(ivf_select_kernel, dim3(B * kSelSplit, n_batches), dim3(256), 0, s, p);
     return hipGetLastError();
 }
 
