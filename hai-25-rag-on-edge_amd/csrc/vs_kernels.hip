@@ -1739,56 +1739,6 @@ __global__ __launch_bounds__(1024) void ivf_coarse_pick_kernel(const float* __re
     }
     __syncthreads();
     for (int pp = tid; pp <= nprobe; pp += 1024) grp.qoff[(int64_t)b * (kIvfMaxProbe + 1) + pp] = s_off[pp];
-    for (int pp = tid; pp < nprobe; pp += 1024) {
-        const int c = s_probe[pp];
-        if (c < 0 || s_off[pp + 1] == s_off[pp]) continue;
-        const int slot = atomicAdd(&grp.lcnt[c], 1);  // < 32: a list is probed at most once per query, B <= 32
-        grp.lq[c * kMaxBatch + slot] = b;
-        grp.lbase[c * kMaxBatch + slot] = (int64_t)b * grp.cand_stride + s_off[pp];
-    }
-    if (!grp.units) return;
-    // ---- work plan: the workgroup that finishes last lists the 32-row units of every probed chunk, so that the
-    //      scan launch deals exactly the live work evenly over its waves ----
-    __shared__ int s_last, s_carry;
-    __shared__ int s_wtot[16];
-    __threadfence();
-    __syncthreads();
-    if (tid == 0) {
-        s_last = atomicAdd(grp.plan_done, 1) == (int)gridDim.x - 1 ? 1 : 0;
-        s_carry = 0;
-    }
-    __syncthreads();
-    if (!s_last) return;
-    const int pl = tid & 63, wv = tid >> 6;
-    for (int base = 0; base < grp.n_chunks; base += 1024) {
-        const int chunk = base + tid;
-        int nu = 0;
-        if (chunk < grp.n_chunks) {
-            // the other workgroups' counts arrive through atomics: read them at agent scope
-            const int cnt = __hip_atomic_load(&grp.lcnt[grp.chunk_list[chunk]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (cnt > 0) nu = (grp.chunk_rows[chunk] + 31) >> 5;
-        }
-        int incl = nu;  // inclusive wave scan
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int t = __shfl_up(incl, o);
-            if (pl >= o) incl += t;
-        }
-        if (pl == 63) s_wtot[wv] = incl;
-        __syncthreads();
-        int woff = 0, tot = 0;
-        for (int w = 0; w < 16; ++w) {
-            const int t = s_wtot[w];
-            if (w < wv) woff += t;
-            tot += t;
-        }
-        const int pos = s_carry + woff + incl - nu;
-        for (int i = 0; i < nu; ++i) grp.units[pos + i] = chunk * 32 + i;
-        __syncthreads();
-        if (tid == 0) s_carry += tot;
-        __syncthreads();
-    }
-    if (tid == 0) *grp.n_units = s_carry;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1921,12 +1871,81 @@ __global__ __launch_bounds__(256) void ivf_scan_kernel(const IvfScanParams p) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Grouping + work plan, one workgroup per batch (after ivf_coarse_pick_kernel): every (query, probe) takes a slot
+// in its list's query set (LDS counters: no global atomics, no fences -- with one workgroup per query doing this
+// through global atomics and a last-arriver, the grouping cost grew with the number of batches in flight), then
+// the plan of the list scan is written: the 32-row units of every chunk whose list is probed by some query.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void ivf_group_plan_kernel(const int32_t* __restrict__ probes, int B, int nlist, int nprobe,
+                                                              IvfGroup grp) {
+    {   // multi-batch launch: this workgroup's batch
+        const long long y = blockIdx.y;
+        probes = mb_adv(probes, y * grp.mb.slab);
+        grp.lcnt = mb_adv(grp.lcnt, y * grp.mb.zslab);
+        grp.n_units = mb_adv(grp.n_units, y * grp.mb.zslab);
+        grp.lq = mb_adv(grp.lq, y * grp.mb.slab);
+        grp.lbase = mb_adv(grp.lbase, y * grp.mb.slab);
+        grp.qoff = mb_adv(grp.qoff, y * grp.mb.slab);
+        grp.units = mb_adv(grp.units, y * grp.mb.slab);
+    }
+    __shared__ int cnt_s[2048];
+    __shared__ int s_carry;
+    __shared__ int s_wtot[16];
+    const int tid = threadIdx.x;
+    for (int c = tid; c < nlist; c += 1024) cnt_s[c] = 0;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int e = tid; e < B * nprobe; e += 1024) {
+        const int b = e / nprobe, pp = e - b * nprobe;
+        const int c = probes[(int64_t)b * nprobe + pp];
+        if (c < 0) continue;
+        const int o0 = grp.qoff[(int64_t)b * (kIvfMaxProbe + 1) + pp], o1 = grp.qoff[(int64_t)b * (kIvfMaxProbe + 1) + pp + 1];
+        if (o1 == o0) continue;  // empty (or not resident) list
+        const int slot = atomicAdd(&cnt_s[c], 1);  // < 32: a list is probed at most once per query, B <= 32
+        grp.lq[c * kMaxBatch + slot] = b;
+        grp.lbase[c * kMaxBatch + slot] = (int64_t)b * grp.cand_stride + o0;
+    }
+    __syncthreads();
+    for (int c = tid; c < nlist; c += 1024) grp.lcnt[c] = cnt_s[c];
+    if (!grp.units) return;
+    const int pl = tid & 63, wv = tid >> 6;
+    for (int base = 0; base < grp.n_chunks; base += 1024) {
+        const int chunk = base + tid;
+        int nu = 0;
+        if (chunk < grp.n_chunks && cnt_s[grp.chunk_list[chunk]] > 0) nu = (grp.chunk_rows[chunk] + 31) >> 5;
+        int incl = nu;  // inclusive wave scan
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o);
+            if (pl >= o) incl += t;
+        }
+        if (pl == 63) s_wtot[wv] = incl;
+        __syncthreads();
+        int woff = 0, tot = 0;
+        for (int w = 0; w < 16; ++w) {
+            const int t = s_wtot[w];
+            if (w < wv) woff += t;
+            tot += t;
+        }
+        const int pos = s_carry + woff + incl - nu;
+        for (int i = 0; i < nu; ++i) grp.units[pos + i] = chunk * 32 + i;
+        __syncthreads();
+        if (tid == 0) s_carry += tot;
+        __syncthreads();
+    }
+    if (tid == 0) *grp.n_units = s_carry;
+}
+
 hipError_t launch_ivf_coarse_pick(const float* q, int B, const float* cents, const float* cnorm, int nlist, int nprobe,
                                   int metric, int32_t* probes, const IvfGroup& grp, hipStream_t s, int n_batches) {
     if (nprobe > 256) return hipErrorInvalidValue;
     if (nlist <= 1024) hipLaunchKernelGGL(ivf_coarse_pick_kernel<4>, dim3(B, n_batches), dim3(1024), 0, s, q, cents, cnorm, nlist, nprobe, metric, probes, grp);
     else if (nlist <= 2048) hipLaunchKernelGGL(ivf_coarse_pick_kernel<8>, dim3(B, n_batches), dim3(1024), 0, s, q, cents, cnorm, nlist, nprobe, metric, probes, grp);
     else return hipErrorInvalidValue;
+    // grouping + work plan: one workgroup per batch
+    if (grp.lcnt) hipLaunchKernelGGL(ivf_group_plan_kernel, dim3(1, n_batches), dim3(1024), 0, s, probes, B, nlist, nprobe, grp);
     return hipGetLastError();
 }
 
