@@ -339,8 +339,8 @@ def main():
                     "avg_candidates": avg_cand,
                     "scan_kernel_us": round(ikern_ms / max(ikern_n, 1) * 1e3, 2),
                     "scan_kernel_us_overlapped": round(okern_ms / max(okern_n, 1) * 1e3, 2),
-                    "note": "value: independent batches dealt to 4 streams (vs_ivf_search_dev_multi); scan_kernel_us and "
-                            "the roofline: the list scan kernel timed alone on one stream"}
+                    "note": "value and roofline: vs_ivf_search_dev_multi, every kernel launched once per group of S batches "
+                            "(scan_kernel_us_overlapped = that launch); scan_kernel_us: the scan of ONE batch alone"}
         if avg_cand:
             # The list-major scan reads every probed list ONCE per batch, so its algorithmic bytes are
             # (4d + 4) * rows of the distinct lists probed by the batch (+ 4 B per (query, row) score written),
@@ -352,15 +352,20 @@ def main():
                 pr = np.argsort(cn[None, :] - 2.0 * qs @ cents_h.astype(np.float64).T, axis=1)[:, :NPROBE]
                 uniq_rows += int(sizes[np.unique(pr)].sum())
             uniq_rows /= nb_s
-            ib = (4 * DIM + 4) * uniq_rows + 4 * avg_cand * BATCH
-            ks = ikern_ms / max(ikern_n, 1) * 1e-3
+            # rows: the exact int8 copy (d + 4 bytes per row) when base and queries are byte valued, else fp32 rows
+            i8_rows = bool(np.all(full == np.floor(full)) and full.min() >= 0 and full.max() <= 255)
+            row_bytes = (DIM + 4) if i8_rows else (4 * DIM + 4)
+            ib = row_bytes * uniq_rows + 4 * avg_cand * BATCH
+            # the timed region launches the scan once per group of S batches (blockIdx.y = batch)
+            ks = okern_ms / max(okern_n, 1) * 1e-3
             itraffic = None
             ipath = os.path.join(ROOT, "profiles", "traffic_ivf_list_scan.json")
-            if os.path.exists(ipath) and n_rows == N_BASE:
-                itraffic = json.load(open(ipath)).get("hbm_bytes_per_launch")
-            ivf_info["roofline"] = {"bound": "hbm", "achieved": round(ib / ks / 1e9, 1), "peak": HBM_PEAK_GBS,
-                                    "unit": "GB/s", "frac": round(ib / ks / 1e9 / HBM_PEAK_GBS, 4), "traffic": itraffic,
-                                    "kernel": "vs::ivf_unit_scan_kernel", "algorithmic_bytes_per_launch": int(ib),
+            if os.path.exists(ipath) and n_rows == N_BASE and i8_rows:
+                itraffic = json.load(open(ipath)).get("hbm_bytes_per_launch_32_batches")
+            ivf_info["roofline"] = {"bound": "hbm", "achieved": round(ib * S / ks / 1e9, 1), "peak": HBM_PEAK_GBS,
+                                    "unit": "GB/s", "frac": round(ib * S / ks / 1e9 / HBM_PEAK_GBS, 4), "traffic": itraffic,
+                                    "kernel": "vs::ivf_unit_scan_kernel", "kernel_us": round(ks * 1e6, 2), "batches_per_launch": S,
+                                    "algorithmic_bytes_per_launch": int(ib * S), "row_bytes": row_bytes,
                                     "distinct_rows_per_batch": int(uniq_rows),
                                     "per_query_pass_bytes": int((4 * DIM + 8) * avg_cand * BATCH)}
         log(f"IVF: {ivf_qps:.0f} QPS, recall@1={rec1}, recall@5={rec5}, avg candidates={avg_cand}")

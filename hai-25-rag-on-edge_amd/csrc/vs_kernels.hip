@@ -2268,22 +2268,38 @@ __global__ __launch_bounds__(1024) void kpp_pick_kernel(const float* __restrict_
     __shared__ int s_block;
     __shared__ long long s_row;
     const int tid = threadIdx.x;
-    // total and the block where the running sum passes the target (serial over <= a few thousand sums: cheap)
+    // total and the block where the running sum passes the target: block sums through LDS, 1024 at a time
     if (tid == 0) {
-        double total = 0.0;
-        for (int b = 0; b < n_blocks; ++b) total += block_sums[b];
-        const double target = u * total;
-        double run = 0.0;
-        int blk = n_blocks - 1;
-        for (int b = 0; b < n_blocks; ++b) {
-            if (run + block_sums[b] > target) {
-                blk = b;
-                break;
+        s_before = 0.0;
+        s_block = -1;
+    }
+    __syncthreads();
+    double total = 0.0;
+    for (int b0 = 0; b0 < n_blocks; b0 += 1024) {
+        s_part[tid] = b0 + tid < n_blocks ? block_sums[b0 + tid] : 0.0;
+        __syncthreads();
+        for (int t = 0; t < 1024 && b0 + t < n_blocks; ++t) total += s_part[t];  // every thread: the same order, the same sum
+        __syncthreads();
+    }
+    const double target = u * total;
+    for (int b0 = 0; b0 < n_blocks; b0 += 1024) {
+        s_part[tid] = b0 + tid < n_blocks ? block_sums[b0 + tid] : 0.0;
+        __syncthreads();
+        if (tid == 0 && s_block < 0) {
+            double run = s_before;
+            for (int t = 0; t < 1024 && b0 + t < n_blocks; ++t) {
+                if (run + s_part[t] > target) {
+                    s_block = b0 + t;
+                    break;
+                }
+                run += s_part[t];
             }
-            run += block_sums[b];
+            s_before = run;
         }
-        s_block = blk;
-        s_before = run;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        if (s_block < 0) s_block = n_blocks - 1;
         s_target = target;
         s_row = -1;
     }
