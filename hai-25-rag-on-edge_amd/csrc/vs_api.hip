@@ -1545,24 +1545,39 @@ int vs_ivf_search(vs_index* h, const float* queries_host, int64_t nq, int k, int
     const double t_start = now_ms();
     vs_timing tm{};
     HIPCHK(hipMemsetAsync(h->d_cand, 0, sizeof(unsigned long long), h->stream));
-    std::vector<float> hd((size_t)32 * k);
-    std::vector<int32_t> hi((size_t)32 * k);
     const float inf = std::numeric_limits<float>::infinity();
-    for (int64_t q0 = 0; q0 < nq; q0 += h->batch) {
-        const int B = (int)std::min<int64_t>(h->batch, nq - q0);
+    // Queries go up in chunks of kMaxMulti batches: every kernel is launched once per chunk (the harness loop of
+    // main_ivf.cpp:150-214 collapsed into a call); a ragged tail batch gets its own launches.
+    const bool multi = g_ivf_multi && g_ivf_grouped && g_ivf_plan && h->nlist <= 2048 && h->n_chunks > 0 && h->d_units && pick_kcap(k) &&
+                       k <= 64;  // d_out_* hold kMaxMulti * 32 * 64 words
+    const int64_t chunk = (int64_t)(multi ? kMaxMulti : 1) * h->batch;
+    std::vector<float> hd((size_t)chunk * k);
+    std::vector<int32_t> hi((size_t)chunk * k);
+    for (int64_t q0 = 0; q0 < nq; q0 += chunk) {
+        const int64_t n = std::min<int64_t>(chunk, nq - q0);
+        const int full = (int)(n / h->batch), rem = (int)(n % h->batch);
         double t0 = now_ms();
-        HIPCHK(hipMemcpyAsync(h->d_q, queries_host + q0 * vs::kDim, (size_t)B * vs::kDim * sizeof(float),
+        HIPCHK(hipMemcpyAsync(h->d_q, queries_host + q0 * vs::kDim, (size_t)n * vs::kDim * sizeof(float),
                               hipMemcpyHostToDevice, h->stream));
         double t1 = now_ms();
-        rc = ivf_batch_dev(h, h->d_q, B, k, nprobe, h->d_out_d, h->d_out_i, h->stream, nullptr);
+        if (full > 1) {
+            rc = ivf_group_dev(h, h->d_q, full, h->batch, k, nprobe, h->d_out_d, h->d_out_i, h->stream);
+        } else if (full == 1) {
+            rc = ivf_batch_dev(h, h->d_q, h->batch, k, nprobe, h->d_out_d, h->d_out_i, h->stream, nullptr);
+        }
         if (rc) return rc;
-        HIPCHK(hipMemcpyAsync(hd.data(), h->d_out_d, (size_t)B * k * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipMemcpyAsync(hi.data(), h->d_out_i, (size_t)B * k * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+        if (rem) {
+            const size_t o = (size_t)full * h->batch;
+            rc = ivf_batch_dev(h, h->d_q + o * vs::kDim, rem, k, nprobe, h->d_out_d + o * k, h->d_out_i + o * k, h->stream, nullptr);
+            if (rc) return rc;
+        }
+        HIPCHK(hipMemcpyAsync(hd.data(), h->d_out_d, (size_t)n * k * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(hi.data(), h->d_out_i, (size_t)n * k * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
         double t2 = now_ms();
         tm.h2d_ms += t1 - t0;
         tm.fine_search_ms += t2 - t1;
-        for (int b = 0; b < B; ++b)
+        for (int64_t b = 0; b < n; ++b)
             for (int t = 0; t < k; ++t) {
                 const int32_t id = hi[(size_t)b * k + t];
                 ids[(q0 + b) * k + t] = id;
