@@ -304,3 +304,32 @@ def test_int8_rows_and_fp32_fallback_agree(gpu_pkg):
     with gpu_pkg.IVFIndex(vectors_reordered=vr * 2.0, centroids=cents * 2.0, cluster_offsets=off, reorder_to_original=r2o) as ivf2:
         ids3, d3, _ = ivf2.searchBatch(q * 2.0, 32, k, nprobe)
         assert np.array_equal(ids3, ids) and np.array_equal(d3, d * 4.0)
+
+
+@pytest.mark.parametrize("nlist", [1024, 1500, 2500])
+def test_large_nlist_paths(gpu_pkg, nlist):
+    """nlist <= 1024 and <= 2048 take the two instantiations of the fused coarse kernel, nlist > 2048 the fallback
+    (MFMA score matrix + probe pick + query-major scan).  All must agree with the oracle's restatement (same probes
+    up to last-bit coarse ties) and return exact integer distances; multi-batch == batch by batch."""
+    import torch
+    base = gpu_pkg.synth_sift(60000, seed=31)
+    vr, off, r2o, cents, _ = gpu_pkg.ivf_build(base, nlist, max_iter=3, seed=7)
+    assert len(off) == nlist + 1
+    q = gpu_pkg.synth_sift(3 * 32, seed=32)
+    k, nprobe = 5, 24
+    oi, od, _ = oracle.ivf_search(vr, off, r2o, cents, q, k, nprobe)
+    with gpu_pkg.IVFIndex(vectors_reordered=vr, centroids=cents, cluster_offsets=off, reorder_to_original=r2o) as ivf:
+        ids, d, _ = ivf.searchBatch(q, len(q), k, nprobe)
+        same = np.array([np.array_equal(d[i], od[i]) for i in range(len(q))])
+        assert same.mean() >= 0.95
+        ex = oracle.exact_int_dists(q, base)
+        valid = ids >= 0
+        assert np.array_equal(np.take_along_axis(ex, np.where(valid, ids, 0).astype(np.int64), 1).astype(np.float32)[valid], d[valid])
+        dev = torch.device("cuda:0")
+        qd = torch.from_numpy(q).to(dev)
+        s = torch.cuda.current_stream().cuda_stream
+        gi = torch.zeros((96, k), dtype=torch.int32, device=dev)
+        gd = torch.zeros((96, k), dtype=torch.float32, device=dev)
+        ivf.search_dev_multi(qd.data_ptr(), 3, 32, k, nprobe, gi.data_ptr(), gd.data_ptr(), s)
+        torch.cuda.synchronize()
+        assert np.array_equal(gd.cpu().numpy(), d) and np.array_equal(gi.cpu().numpy(), ids)
