@@ -112,7 +112,7 @@ struct vs_index {
     int32_t* d_chunk_row0 = nullptr;
     int32_t* d_chunk_rows = nullptr;
     int32_t* d_units = nullptr;        // [n_units_max] per-batch work plan of the list scan (chunk * 32 + unit)
-    // second set of the per-batch IVF scratch: vs_ivf_search_dev_multi alternates two streams so that one batch's
+    // further sets of the per-batch IVF scratch (VSEARCH_IVF_MULTI=0: batches are dealt to streams so that one batch's
     // small latency-bound kernels (coarse + pick, bound, select) run beside the other batch's list scan
     struct IvfScratch {
         float* d_scores = nullptr;
@@ -434,8 +434,8 @@ int g_seed_i8 = [] {
 
 int pick_kcap(int need) { return need <= 8 ? 8 : (need <= 16 ? 16 : 0); }
 
-// nb <= kMaxMulti batches of B queries in ONE persistent launch on stream s: scan + exchange + top-k +
-// last-arriver merge, outputs [nb][B][k1].  Consecutive calls on one lane must be stream-ordered.
+// nb <= kMaxMulti batches of B queries in ONE persistent launch on stream s (preceded by the seed launches or the
+// slot reset, followed by one merge launch), outputs [nb][B][k1].  Consecutive calls on one lane must be stream-ordered.
 int bf_launch(vs_index* h, vs_index::Lane& L, const float* q_dev, int nb, int B, int k1, float* out_d, int32_t* out_i,
               int32_t* flags, hipStream_t s, bool force_f32 = false) {
     const int kcap = pick_kcap(k1);
