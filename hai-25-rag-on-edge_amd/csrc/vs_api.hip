@@ -112,7 +112,7 @@ struct vs_index {
     int32_t* d_chunk_row0 = nullptr;
     int32_t* d_chunk_rows = nullptr;
     int32_t* d_units = nullptr;        // [n_units_max] per-batch work plan of the list scan (chunk * 32 + unit)
-    // further sets of the per-batch IVF scratch (VSEARCH_IVF_MULTI=0: batches are dealt to streams so that one batch's
+    // further sets of the per-batch IVF scratch, VSEARCH_IVF_MULTI=0: batches are dealt to streams so that one batch's
     // small latency-bound kernels (coarse + pick, bound, select) run beside the other batch's list scan
     struct IvfScratch {
         float* d_scores = nullptr;
@@ -297,7 +297,7 @@ int ensure_ivf_alt(vs_index* h) {
     for (int l = 1; l < g_ivf_lanes; ++l) {
         swap_ivf_scratch(h, l - 1);  // the (empty) alternate set becomes current: allocate into it
         int rc = alloc_ivf_scratch(h);
-        if (!rc && h->n_units_max > 0) rc = dev_alloc(&h->d_units, (size_t)h->n_units_max);
+        if (!rc && h->n_units_max > 0) rc = dev_alloc(&h->d_units, (size_t)h->n_units_max * 4);
         swap_ivf_scratch(h, l - 1);
         if (rc) return rc;
     }
@@ -611,6 +611,7 @@ int ivf_batch_dev(vs_index* h, const float* q_dev, int B, int k, int nprobe, flo
         grp.cand_count = h->d_cand;
         if (h->d_units && g_ivf_plan) {
             grp.chunk_list = h->d_chunk_list;
+            grp.chunk_row0 = h->d_chunk_row0;
             grp.chunk_rows = h->d_chunk_rows;
             grp.n_chunks = h->n_chunks;
             grp.plan_done = h->d_lcnt + h->nlist + 96 + 512;
@@ -724,7 +725,7 @@ int ensure_ivf_mb(vs_index* h, int nprobe, hipStream_t s) {
     h->mb_off_probes = off;  off = al(off + 32ll * kMaxNprobe * 4);
     h->mb_off_gd = off;      off = al(off + 32ll * 4096 * 4);
     h->mb_off_gp = off;      off = al(off + 32ll * 4096 * 4);
-    h->mb_off_units = off;   off = al(off + std::max<long long>(h->n_units_max, 1) * 4);
+    h->mb_off_units = off;   off = al(off + std::max<long long>(h->n_units_max, 1) * 16);
     h->mb_off_cand = off;    off = al(off + 32ll * cstride * 4);
     h->mb_slab_stride = off;
     h->mb_zslab_stride = (((long long)h->nlist + 96 + 512 + 8) + 63) & ~63ll;  // ints
@@ -757,6 +758,7 @@ int ivf_group_dev(vs_index* h, const float* q_dev, int nb, int B, int k, int npr
     grp.cand_stride = h->mb_cand_stride;
     grp.cand_count = h->d_cand;
     grp.chunk_list = h->d_chunk_list;
+    grp.chunk_row0 = h->d_chunk_row0;
     grp.chunk_rows = h->d_chunk_rows;
     grp.n_chunks = h->n_chunks;
     grp.plan_done = z + h->nlist + 96 + 512;
@@ -1181,7 +1183,7 @@ static int ivf_create_impl(const float* vectors, int64_t n_rows, int dim, const 
             if ((rc = dev_alloc(&h->d_chunk_rows, cl.size()))) return fail(rc);
             h->n_units_max = 0;
             for (int32_t r : crn) h->n_units_max += (r + 31) >> 5;
-            if ((rc = dev_alloc(&h->d_units, (size_t)std::max<int64_t>(h->n_units_max, 1)))) return fail(rc);
+            if ((rc = dev_alloc(&h->d_units, (size_t)std::max<int64_t>(h->n_units_max, 1) * 4))) return fail(rc);
             if ((e = hipMemcpy(h->d_chunk_list, cl.data(), cl.size() * 4, hipMemcpyHostToDevice)) != hipSuccess ||
                 (e = hipMemcpy(h->d_chunk_row0, cr0.data(), cl.size() * 4, hipMemcpyHostToDevice)) != hipSuccess ||
                 (e = hipMemcpy(h->d_chunk_rows, crn.data(), cl.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) {

@@ -134,10 +134,11 @@ struct IvfGroup {
     // work plan of the list scan, written by the last query's workgroup: the 32-row units of every chunk whose
     // list is probed by some query of the batch, as chunk * 32 + unit (units == nullptr = no plan)
     const int32_t* chunk_list;       // [n_chunks]
+    const int32_t* chunk_row0;       // [n_chunks]
     const int32_t* chunk_rows;       // [n_chunks]
     int n_chunks;
     int32_t* plan_done;              // arrival counter (pre-set to 0)
-    int32_t* units;                  // [sum ceil(chunk_rows / 32)]
+    int32_t* units;                  // [sum ceil(chunk_rows / 32)][4]: first row, chunk end row, list | queries << 16, list start
     int32_t* n_units;                // [1]
     IvfMulti mb;
 };

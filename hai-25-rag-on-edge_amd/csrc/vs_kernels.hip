@@ -1934,7 +1934,16 @@ __global__ __launch_bounds__(1024) void ivf_group_plan_kernel(const int32_t* __r
             tot += t;
         }
         const int pos = s_carry + woff + incl - nu;
-        for (int i = 0; i < nu; ++i) grp.units[pos + i] = chunk * 32 + i;
+        if (nu > 0) {
+            // unit record: first row, end row of the chunk, list | queries << 16, first row of the list -- everything
+            // the scan needs, so that a wave's next unit costs ONE (prefetched) load instead of five dependent ones
+            const int c = grp.chunk_list[chunk];
+            const int r0 = grp.chunk_row0[chunk];
+            const int r_end = r0 + grp.chunk_rows[chunk];
+            const int ls = grp.offsets[c];
+            const int nq = min(cnt_s[c], kMaxBatch);
+            for (int i = 0; i < nu; ++i) reinterpret_cast<int4*>(grp.units)[pos + i] = make_int4(r0 + 32 * i, r_end, c | (nq << 16), ls);
+        }
         __syncthreads();
         if (tid == 0) s_carry += tot;
         __syncthreads();
@@ -2126,14 +2135,16 @@ __global__ __launch_bounds__(kIvfUnitThreads) void ivf_unit_scan_kernel(IvfListS
         }
         if (__syncthreads_and(q_ok ? 1 : 0)) {
             const int r = lane & 15, g = lane >> 4;
-            for (int u = (int)blockIdx.x * 4 + wave; u < n_units; u += nw) {
-                const int unit = __builtin_amdgcn_readfirstlane(units[u]);
-                const int chunk = unit >> 5;
-                const int c = p.chunk_list[chunk];
-                const int nq = min(p.lcnt[c], kMaxBatch);
-                const int list_start = p.offsets[c];
-                const int r_end = p.chunk_row0[chunk] + p.chunk_rows[chunk];
-                const int r0 = p.chunk_row0[chunk] + 32 * (unit & 31);
+            const int4* recs = reinterpret_cast<const int4*>(units);
+            int u = (int)blockIdx.x * 4 + wave;
+            int4 rec = u < n_units ? recs[u] : make_int4(0, 0, 0, 0);
+            for (; u < n_units; u += nw) {
+                const int r0 = __builtin_amdgcn_readfirstlane(rec.x);
+                const int r_end = __builtin_amdgcn_readfirstlane(rec.y);
+                const int c = __builtin_amdgcn_readfirstlane(rec.z) & 0xffff;
+                const int nq = __builtin_amdgcn_readfirstlane(rec.z) >> 16;
+                const int list_start = __builtin_amdgcn_readfirstlane(rec.w);
+                if (u + nw < n_units) rec = recs[u + nw];  // the next unit's record, in flight during this unit
                 // A operands of the two tiles: bytes 16 g .. and 64 + 16 g .. of row r0 + 16 t + r (rows past the chunk
                 // read the chunk's last row and are never written)
                 i32x4 a0[2], a1[2], rt[2];
@@ -2170,13 +2181,12 @@ __global__ __launch_bounds__(kIvfUnitThreads) void ivf_unit_scan_kernel(IvfListS
         }
     }
     for (int u = (int)blockIdx.x * 4 + wave; u < n_units; u += nw) {
-        const int unit = __builtin_amdgcn_readfirstlane(units[u]);
-        const int chunk = unit >> 5;
-        const int c = p.chunk_list[chunk];
-        const int nq = min(p.lcnt[c], kMaxBatch);
-        const int list_start = p.offsets[c];
-        const int r_end = p.chunk_row0[chunk] + p.chunk_rows[chunk];
-        const int r0 = p.chunk_row0[chunk] + 32 * (unit & 31);
+        const int4 rec = reinterpret_cast<const int4*>(units)[u];
+        const int r0 = __builtin_amdgcn_readfirstlane(rec.x);
+        const int r_end = __builtin_amdgcn_readfirstlane(rec.y);
+        const int c = __builtin_amdgcn_readfirstlane(rec.z) & 0xffff;
+        const int nq = __builtin_amdgcn_readfirstlane(rec.z) >> 16;
+        const int list_start = __builtin_amdgcn_readfirstlane(rec.w);
         f32x4 v[4][4];
         float vn[4];
 #pragma unroll
