@@ -2114,6 +2114,8 @@ __global__ __launch_bounds__(kIvfUnitThreads) void ivf_unit_scan_kernel(IvfListS
     //      the fp32 path computes (scan_kernel PREC = 1).  A batch with a non-integer query uses the fp32 rows below.
     if (p.vecs_u8 && p.metric == 0) {
         typedef int i32x4 __attribute__((ext_vector_type(4)));
+        typedef int i32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+        typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
         __shared__ __attribute__((aligned(16))) int q8_s[kMaxBatch * 32];  // [query][128 bytes]
         __shared__ int qsum_s[kMaxBatch];
         if (tid < kMaxBatch) qsum_s[tid] = 0;
@@ -2153,8 +2155,9 @@ __global__ __launch_bounds__(kIvfUnitThreads) void ivf_unit_scan_kernel(IvfListS
                     const int row = min(r0 + 16 * t + r, r_end - 1);
                     a0[t] = *reinterpret_cast<const i32x4*>(p.vecs_u8 + (int64_t)row * kDim + 16 * g);
                     a1[t] = *reinterpret_cast<const i32x4*>(p.vecs_u8 + (int64_t)row * kDim + 64 + 16 * g);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) rt[t][j] = p.rterm[min(r0 + 16 * t + 4 * g + j, r_end - 1)];
+                    // row terms of rows 4 g .. 4 g + 3 of the tile: one 4-byte-aligned vector load (rows past the chunk
+                    // belong to the next list or to the array's 64 spare entries: readable, never used)
+                    rt[t] = *reinterpret_cast<const i32x4_u*>(p.rterm + r0 + 16 * t + 4 * g);
                 }
                 for (int cb = 0; cb < nq; cb += 16) {
                     const int sq = cb + r;  // this lane's query slot in the list's query set
@@ -2169,10 +2172,17 @@ __global__ __launch_bounds__(kIvfUnitThreads) void ivf_unit_scan_kernel(IvfListS
                         i32x4 acc = {0, 0, 0, 0};
                         acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0[t], b0, acc, 0, 0, 0);
                         acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1[t], b1, acc, 0, 0, 0);
+                        const int row = r0 + 16 * t + 4 * g;
+                        f32x4 dv;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const int row = r0 + 16 * t + 4 * g + j;
-                            if (live && row < r_end) p.cand[cbase + (row - list_start)] = (float)(qterm + rt[t][j] - 2 * acc[j]);
+                        for (int j = 0; j < 4; ++j) dv[j] = (float)(qterm + rt[t][j] - 2 * acc[j]);
+                        float* dst = p.cand + cbase + (row - list_start);
+                        if (live && row + 3 < r_end) {
+                            *reinterpret_cast<f32x4_u*>(dst) = dv;  // 4 consecutive scores of the query's window
+                        } else if (live) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                if (row + j < r_end) dst[j] = dv[j];
                         }
                     }
                 }
