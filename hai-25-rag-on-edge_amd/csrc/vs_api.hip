@@ -35,6 +35,7 @@ namespace {
 constexpr int kMaxEvents = 8192;
 constexpr int kKcapMax = 16;       // largest per-lane list the scan kernels are compiled for
 constexpr int kMaxNprobe = 256;
+constexpr int kSlotWords = 32 * vs::kIvfSlots;  // per-batch slot minima of the IVF list scan (in the zeroed block)
 constexpr int kMaxLanes = 4;
 constexpr int kMaxMulti = 32;  // batches per persistent scan launch
 
@@ -253,7 +254,7 @@ int alloc_ivf_scratch(vs_index* h) {
     if ((rc = dev_alloc(&h->d_ipart_d, (size_t)32 * kMaxNprobe * kKcapMax))) return rc;
     if ((rc = dev_alloc(&h->d_ipart_i, (size_t)32 * kMaxNprobe * kKcapMax))) return rc;
     // one zero-filled block per batch: [lcnt nlist][gsel 96][bins 512][plan_done, n_units]
-    if ((rc = dev_alloc(&h->d_lcnt, (size_t)h->nlist + 96 + 512 + 8))) return rc;
+    if ((rc = dev_alloc(&h->d_lcnt, (size_t)h->nlist + 96 + 512 + 8 + kSlotWords))) return rc;
     h->d_gsel = h->d_lcnt + h->nlist;
     h->d_bins = reinterpret_cast<unsigned*>(h->d_lcnt + h->nlist + 96);
     if ((rc = dev_alloc(&h->d_lq, (size_t)h->nlist * 32))) return rc;
@@ -601,7 +602,7 @@ int ivf_batch_dev(vs_index* h, const float* q_dev, int B, int k, int nprobe, flo
             if (rc) return rc;
             h->cand_stride = stride;
         }
-        HIPCHK(hipMemsetAsync(h->d_lcnt, 0, ((size_t)h->nlist + 96 + 512 + 8) * sizeof(int32_t), s));
+        HIPCHK(hipMemsetAsync(h->d_lcnt, 0, ((size_t)h->nlist + 96 + 512 + 8 + kSlotWords) * sizeof(int32_t), s));
         grp.offsets = h->d_offsets;
         grp.lcnt = h->d_lcnt;
         grp.lq = h->d_lq;
@@ -645,6 +646,7 @@ int ivf_batch_dev(vs_index* h, const float* q_dev, int B, int k, int nprobe, flo
         lp.lq = h->d_lq;
         lp.lbase = h->d_lbase;
         lp.cand = h->d_candbuf;
+        if (grp.units) lp.slotmin = reinterpret_cast<unsigned*>(h->d_lcnt + h->nlist + 96 + 512 + 8);
         lp.metric = h->metric;
         prof_begin(h, 1, s);
         if (grp.units) HIPCHK(vs::launch_ivf_unit_scan(lp, grp.units, grp.n_units, B, h->num_cus, s));
@@ -658,6 +660,7 @@ int ivf_batch_dev(vs_index* h, const float* q_dev, int B, int k, int nprobe, flo
         sp.offsets = h->d_offsets;
         sp.id_map = h->d_r2o;
         sp.tq = h->d_bins;
+        sp.slotmin = lp.slotmin;  // filled by the planned unit scan (else the bound kernel runs)
         sp.gcand_d = h->d_gcand_d;
         sp.gcand_p = h->d_gcand_p;
         sp.gcnt = h->d_gsel;
@@ -728,7 +731,7 @@ int ensure_ivf_mb(vs_index* h, int nprobe, hipStream_t s) {
     h->mb_off_units = off;   off = al(off + std::max<long long>(h->n_units_max, 1) * 16);
     h->mb_off_cand = off;    off = al(off + 32ll * cstride * 4);
     h->mb_slab_stride = off;
-    h->mb_zslab_stride = (((long long)h->nlist + 96 + 512 + 8) + 63) & ~63ll;  // ints
+    h->mb_zslab_stride = (((long long)h->nlist + 96 + 512 + 8 + kSlotWords) + 63) & ~63ll;  // ints
     h->mb_cand_stride = cstride;
     HIPCHK(hipMalloc(reinterpret_cast<void**>(&h->mb_slab), (size_t)h->mb_slab_stride * kMaxMulti));
     HIPCHK(hipMalloc(reinterpret_cast<void**>(&h->mb_zslab), (size_t)h->mb_zslab_stride * kMaxMulti * sizeof(int32_t)));
@@ -782,6 +785,7 @@ int ivf_group_dev(vs_index* h, const float* q_dev, int nb, int B, int k, int npr
     lp.lq = grp.lq;
     lp.lbase = grp.lbase;
     lp.cand = reinterpret_cast<float*>(sl + h->mb_off_cand);
+    lp.slotmin = reinterpret_cast<unsigned*>(z + h->nlist + 96 + 512 + 8);
     lp.metric = h->metric;
     lp.mb = mb;
     prof_begin(h, 1, s);
@@ -795,6 +799,7 @@ int ivf_group_dev(vs_index* h, const float* q_dev, int nb, int B, int k, int npr
     sp.offsets = h->d_offsets;
     sp.id_map = h->d_r2o;
     sp.tq = reinterpret_cast<unsigned*>(z + h->nlist + 96);
+    sp.slotmin = lp.slotmin;
     sp.gcand_d = reinterpret_cast<float*>(sl + h->mb_off_gd);
     sp.gcand_p = reinterpret_cast<int32_t*>(sl + h->mb_off_gp);
     sp.gcnt = z + h->nlist;

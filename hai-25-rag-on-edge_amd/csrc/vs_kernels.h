@@ -161,9 +161,12 @@ struct IvfListScanParams {
     const int32_t* lq;
     const long long* lbase;
     float* cand;              // [B][cand_stride] candidate scores, probe order
+    unsigned* slotmin;        // [B][kIvfSlots] (pre-set to 0): per query, the minimum score of the units that hash to a slot, as
+                              // complemented ordered floats under atomicMax; their k-th smallest bounds the k-th best score
     int metric;
     IvfMulti mb;
 };
+constexpr int kIvfSlots = 64;
 hipError_t launch_ivf_list_scan(const IvfListScanParams& p, int n_chunks, hipStream_t s);
 // planned variant: one wave per 32-row unit of the plan (IvfGroup::units); B = queries in the batch
 hipError_t launch_ivf_unit_scan(const IvfListScanParams& p, const int32_t* units, const int32_t* n_units, int B, int num_cus,
@@ -177,6 +180,7 @@ struct IvfSelectParams {
     const int32_t* offsets;   // [nlist+1]
     const int32_t* id_map;    // reorder_to_original (local)
     unsigned* tq;             // [B] complemented ordered-float bound per query (pre-set to 0)
+    const unsigned* slotmin;  // [B][kIvfSlots] from the unit scan, or nullptr = run ivf_bound_kernel
     float* gcand_d;           // [B][4096] gathered candidates under the bound
     int32_t* gcand_p;
     int32_t* gcnt;            // [B] (pre-set to 0)

@@ -2078,6 +2078,7 @@ __global__ __launch_bounds__(kIvfUnitThreads) void ivf_unit_scan_kernel(IvfListS
         p.lq = mb_adv(p.lq, y * p.mb.slab);
         p.lbase = mb_adv(p.lbase, y * p.mb.slab);
         p.cand = mb_adv(p.cand, y * p.mb.slab);
+        p.slotmin = mb_adv(p.slotmin, y * p.mb.zslab);
         units = mb_adv(units, y * p.mb.slab);
         n_units_ptr = mb_adv(n_units_ptr, y * p.mb.zslab);
     }
@@ -2167,6 +2168,7 @@ __global__ __launch_bounds__(kIvfUnitThreads) void ivf_unit_scan_kernel(IvfListS
                     const i32x4 b0 = *reinterpret_cast<const i32x4*>(q8_s + qi * 32 + 4 * g);
                     const i32x4 b1 = *reinterpret_cast<const i32x4*>(q8_s + qi * 32 + 16 + 4 * g);
                     const int qterm = (int)qn_s[qi] - 256 * qsum_s[qi] - 4194304;
+                    float umin = VS_INF;  // this unit's minimum score for the lane's query
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
                         i32x4 acc = {0, 0, 0, 0};
@@ -2179,11 +2181,20 @@ __global__ __launch_bounds__(kIvfUnitThreads) void ivf_unit_scan_kernel(IvfListS
                         float* dst = p.cand + cbase + (row - list_start);
                         if (live && row + 3 < r_end) {
                             *reinterpret_cast<f32x4_u*>(dst) = dv;  // 4 consecutive scores of the query's window
+                            umin = fminf(umin, fminf(fminf(dv[0], dv[1]), fminf(dv[2], dv[3])));
                         } else if (live) {
 #pragma unroll
                             for (int j = 0; j < 4; ++j)
-                                if (row + j < r_end) dst[j] = dv[j];
+                                if (row + j < r_end) {
+                                    dst[j] = dv[j];
+                                    umin = fminf(umin, dv[j]);
+                                }
                         }
+                    }
+                    if (p.slotmin) {  // fold the 4 lanes of the query column, one atomic per (unit, query)
+                        umin = fminf(umin, __shfl_xor(umin, 16));
+                        umin = fminf(umin, __shfl_xor(umin, 32));
+                        if (live && g == 0 && umin < VS_INF) atomicMax(p.slotmin + qi * kIvfSlots + (u & (kIvfSlots - 1)), ~f32_ordered(umin));
                     }
                 }
             }
@@ -2215,6 +2226,7 @@ __global__ __launch_bounds__(kIvfUnitThreads) void ivf_unit_scan_kernel(IvfListS
 #pragma unroll
             for (int m = 0; m < 4; ++m) qf[m] = *reinterpret_cast<const f32x4*>(q_s + qi * kDim + 4 * (s8 + 8 * m));
             const float qn = qn_s[qi];
+            float umin = VS_INF;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 float acc = 0.f;
@@ -2226,7 +2238,16 @@ __global__ __launch_bounds__(kIvfUnitThreads) void ivf_unit_scan_kernel(IvfListS
                 acc = dpp_add_xor2(acc);
                 acc = dpp_add_half_mirror(acc);
                 const float d = p.metric ? -acc : fmaf(-2.0f, acc, qn + vn[g]);
-                if (s8 == 0 && r0 + 8 * g + rr < r_end) dst[8 * g + rr] = d;
+                if (s8 == 0 && r0 + 8 * g + rr < r_end) {
+                    dst[8 * g + rr] = d;
+                    umin = fminf(umin, d);
+                }
+            }
+            if (p.slotmin) {  // the unit's minimum score for this query: fold the row lanes, one atomic
+                umin = fminf(umin, __shfl_xor(umin, 8));
+                umin = fminf(umin, __shfl_xor(umin, 16));
+                umin = fminf(umin, __shfl_xor(umin, 32));
+                if (lane == 0 && umin < VS_INF) atomicMax(p.slotmin + qi * kIvfSlots + (u & (kIvfSlots - 1)), ~f32_ordered(umin));
             }
         }
     }
@@ -2404,6 +2425,7 @@ __global__ __launch_bounds__(256) void ivf_bound_kernel(IvfSelectParams p) {
         p.gcand_d = mb_adv(p.gcand_d, y * p.mb.slab);
         p.gcand_p = mb_adv(p.gcand_p, y * p.mb.slab);
         p.tq = mb_adv(p.tq, y * p.mb.zslab);
+        p.slotmin = mb_adv(p.slotmin, y * p.mb.zslab);
         p.gcnt = mb_adv(p.gcnt, y * p.mb.zslab);
         p.gdone = mb_adv(p.gdone, y * p.mb.zslab);
         p.govf = mb_adv(p.govf, y * p.mb.zslab);
@@ -2449,6 +2471,7 @@ __global__ __launch_bounds__(256) void ivf_select_kernel(IvfSelectParams p) {
         p.gcand_d = mb_adv(p.gcand_d, y * p.mb.slab);
         p.gcand_p = mb_adv(p.gcand_p, y * p.mb.slab);
         p.tq = mb_adv(p.tq, y * p.mb.zslab);
+        p.slotmin = mb_adv(p.slotmin, y * p.mb.zslab);
         p.gcnt = mb_adv(p.gcnt, y * p.mb.zslab);
         p.gdone = mb_adv(p.gdone, y * p.mb.zslab);
         p.govf = mb_adv(p.govf, y * p.mb.zslab);
@@ -2468,10 +2491,23 @@ __global__ __launch_bounds__(256) void ivf_select_kernel(IvfSelectParams p) {
     const float* sc = p.cand + (int64_t)q * p.cand_stride;
     for (int pp = tid; pp <= p.nprobe; pp += 256) s_off[pp] = p.qoff[(int64_t)q * (kIvfMaxProbe + 1) + pp];
     for (int pp = tid; pp < p.nprobe; pp += 256) s_probe[pp] = p.probes[(int64_t)q * p.nprobe + pp];
+    __shared__ float s_slot[kIvfSlots];
     if (tid == 0) {
         s_cnt = 0;
-        const unsigned u = p.tq[q];  // bound from ivf_bound_kernel (0 = none)
+        const unsigned u = p.slotmin ? 0u : p.tq[q];  // bound from ivf_bound_kernel (0 = none)
         s_t = u ? f32_unordered(~u) : VS_INF;
+    }
+    if (p.slotmin && tid < kIvfSlots) {
+        const unsigned u = p.slotmin[q * kIvfSlots + tid];  // minima of disjoint sets of units (0 = empty slot)
+        s_slot[tid] = u ? f32_unordered(~u) : VS_INF;
+    }
+    __syncthreads();
+    if (p.slotmin && tid < kIvfSlots) {
+        // k-th smallest of the slot minima: k distinct candidates are at least that good
+        const float v = s_slot[tid];
+        int rank = 0;
+        for (int j = 0; j < kIvfSlots; ++j) rank += (s_slot[j] < v || (s_slot[j] == v && j < tid)) ? 1 : 0;
+        if (rank == min(p.k, kIvfSlots) - 1) s_t = v;
     }
     __syncthreads();
     const float T = s_t;
@@ -2613,7 +2649,7 @@ __global__ __launch_bounds__(256) void ivf_select_kernel(IvfSelectParams p) {
 
 hipError_t launch_ivf_select(const IvfSelectParams& p, int B, hipStream_t s, int n_batches) {
     if (p.k > 16 || p.nprobe > 256) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(ivf_bound_kernel, dim3(B * kSelSplit, n_batches), dim3(256), 0, s, p);
+    if (!p.slotmin) hipLaunchKernelGGL(ivf_bound_kernel, dim3(B * kSelSplit, n_batches), dim3(256), 0, s, p);
     hipLaunchKernelGGL(ivf_select_kernel, dim3(B * kSelSplit, n_batches), dim3(256), 0, s, p);
     return hipGetLastError();
 }
