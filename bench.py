@@ -376,14 +376,20 @@ def main():
     if world == 1 and rank == 0 and not args.no_cpu:
         import oracle
         oracle.search_bf(shard, queries[:2], K)  # thread pool + page-in warm-up
-        tq = time.perf_counter()
-        oracle.search_bf(shard, queries[:8], K)
-        per_q = (time.perf_counter() - tq) / 8
-        nq_cpu = int(min(2048, max(16, 15.0 / max(per_q, 1e-4))))  # ~15 s of CPU work
-        tm = {}
-        tq = time.perf_counter()
-        cid, cd = oracle.search_bf(shard, queries[:nq_cpu], K, tm)
-        cel = time.perf_counter() - tq
+        # bounded sample: chunks of 128 queries until ~15 s of CPU work (or 2048 queries) are done
+        tm = {"dist_s": 0.0, "topk_s": 0.0}
+        cids, cds, nq_cpu, cel = [], [], 0, 0.0
+        while nq_cpu < 2048 and cel < 15.0:
+            t1 = {}
+            tq = time.perf_counter()
+            ci_, cd_ = oracle.search_bf(shard, queries[nq_cpu:nq_cpu + 128], K, t1)
+            cel += time.perf_counter() - tq
+            tm["dist_s"] += t1["dist_s"]
+            tm["topk_s"] += t1["topk_s"]
+            cids.append(ci_)
+            cds.append(cd_)
+            nq_cpu += 128
+        cid, cd = np.concatenate(cids), np.concatenate(cds)
         gid, gd = bf.search(queries[:nq_cpu], K)
         assert np.array_equal(gid, cid) and np.array_equal(gd, cd), "GPU result differs from the CPU oracle"
         cpu_info = {"value": round(nq_cpu / cel, 2), "unit": "queries/s", "cores": oracle.num_threads(), "kind": "port",
