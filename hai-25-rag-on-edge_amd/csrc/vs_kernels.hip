@@ -2410,7 +2410,7 @@ hipError_t launch_ivf_list_scan(const IvfListScanParams& p, int n_chunks, hipStr
 // pass 2 collects the few scores under the bound, maps them back to reordered positions and ranks
 // them by counting in (dist, position) order; ids go through reorder_to_original (:774-779).
 // ------------------------------------------------------------------------------------------------
-constexpr int kSelSplit = 8;      // workgroups per query
+constexpr int kSelSplit = 2;      // workgroups per query
 constexpr int kSelCap = 4096;     // global candidate slots per query
 
 // Pass 1 of the selection: every workgroup takes 1/8 of a query's candidate scores, computes its 256
