@@ -139,6 +139,7 @@ struct vs_index {
     char* mb_slab = nullptr;
     int32_t* mb_zslab = nullptr;
     long long mb_slab_stride = 0, mb_zslab_stride = 0, mb_cand_stride = 0;
+    int mb_nbk = 0;  // per-query score-block minima (32 scores per block) of the list scan
     long long mb_off_lq = 0, mb_off_lbase = 0, mb_off_qoff = 0, mb_off_probes = 0, mb_off_gd = 0, mb_off_gp = 0, mb_off_units = 0,
               mb_off_cand = 0;
     hipStream_t ivf_stream[8] = {};
@@ -704,6 +705,13 @@ int ivf_batch_dev(vs_index* h, const float* q_dev, int B, int k, int nprobe, flo
     return VS_OK;
 }
 
+// tuning knob (VSEARCH_IVF_BUCKETS=0): multi-batch launches bound the selection by 64 slot minima per query instead of
+// per-block minima (the selection then reads every candidate score)
+int g_ivf_buckets = [] {
+    const char* e = getenv("VSEARCH_IVF_BUCKETS");
+    return e ? atoi(e) : 1;
+}();
+
 // tuning knob (VSEARCH_IVF_MULTI=0): vs_ivf_search_dev_multi deals batches to streams instead of launching every
 // kernel once for a whole group of batches
 int g_ivf_multi = [] {
@@ -731,7 +739,8 @@ int ensure_ivf_mb(vs_index* h, int nprobe, hipStream_t s) {
     h->mb_off_units = off;   off = al(off + std::max<long long>(h->n_units_max, 1) * 16);
     h->mb_off_cand = off;    off = al(off + 32ll * cstride * 4);
     h->mb_slab_stride = off;
-    h->mb_zslab_stride = (((long long)h->nlist + 96 + 512 + 8 + kSlotWords) + 63) & ~63ll;  // ints
+    h->mb_nbk = (int)(cstride / 32 + 2);
+    h->mb_zslab_stride = (((long long)h->nlist + 96 + 512 + 8 + kSlotWords + 32ll * h->mb_nbk) + 63) & ~63ll;  // ints
     h->mb_cand_stride = cstride;
     HIPCHK(hipMalloc(reinterpret_cast<void**>(&h->mb_slab), (size_t)h->mb_slab_stride * kMaxMulti));
     HIPCHK(hipMalloc(reinterpret_cast<void**>(&h->mb_zslab), (size_t)h->mb_zslab_stride * kMaxMulti * sizeof(int32_t)));
@@ -786,6 +795,11 @@ int ivf_group_dev(vs_index* h, const float* q_dev, int nb, int B, int k, int npr
     lp.lbase = grp.lbase;
     lp.cand = reinterpret_cast<float*>(sl + h->mb_off_cand);
     lp.slotmin = reinterpret_cast<unsigned*>(z + h->nlist + 96 + 512 + 8);
+    if (g_ivf_buckets) {
+        lp.bkt = reinterpret_cast<unsigned*>(z + h->nlist + 96 + 512 + 8 + kSlotWords);
+        lp.nbk = h->mb_nbk;
+        lp.cand_stride = h->mb_cand_stride;
+    }
     lp.metric = h->metric;
     lp.mb = mb;
     prof_begin(h, 1, s);
@@ -800,6 +814,8 @@ int ivf_group_dev(vs_index* h, const float* q_dev, int nb, int B, int k, int npr
     sp.id_map = h->d_r2o;
     sp.tq = reinterpret_cast<unsigned*>(z + h->nlist + 96);
     sp.slotmin = lp.slotmin;
+    sp.bkt = lp.bkt;
+    sp.nbk = lp.nbk;
     sp.gcand_d = reinterpret_cast<float*>(sl + h->mb_off_gd);
     sp.gcand_p = reinterpret_cast<int32_t*>(sl + h->mb_off_gp);
     sp.gcnt = z + h->nlist;

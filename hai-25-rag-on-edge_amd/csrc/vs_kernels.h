@@ -163,6 +163,10 @@ struct IvfListScanParams {
     float* cand;              // [B][cand_stride] candidate scores, probe order
     unsigned* slotmin;        // [B][kIvfSlots] (pre-set to 0): per query, the minimum score of the units that hash to a slot, as
                               // complemented ordered floats under atomicMax; their k-th smallest bounds the k-th best score
+    unsigned* bkt;            // [B][nbk] (pre-set to 0), or nullptr: finer variant of slotmin -- the minimum score of the units
+    int nbk;                  // whose first candidate falls into [32 b, 32 b + 32) of the query's candidate array; the
+                              // selection then reads only the candidate blocks under the bound instead of every score
+    long long cand_stride;    // floats per query in the candidate array (bucket index = window position / 32)
     int metric;
     IvfMulti mb;
 };
@@ -181,6 +185,8 @@ struct IvfSelectParams {
     const int32_t* id_map;    // reorder_to_original (local)
     unsigned* tq;             // [B] complemented ordered-float bound per query (pre-set to 0)
     const unsigned* slotmin;  // [B][kIvfSlots] from the unit scan, or nullptr = run ivf_bound_kernel
+    const unsigned* bkt;      // [B][nbk] per-block minima from the unit scan (takes precedence), or nullptr
+    int nbk;
     float* gcand_d;           // [B][4096] gathered candidates under the bound
     int32_t* gcand_p;
     int32_t* gcnt;            // [B] (pre-set to 0)

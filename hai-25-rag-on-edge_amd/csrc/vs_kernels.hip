@@ -2079,6 +2079,7 @@ __global__ __launch_bounds__(kIvfUnitThreads) void ivf_unit_scan_kernel(IvfListS
         p.lbase = mb_adv(p.lbase, y * p.mb.slab);
         p.cand = mb_adv(p.cand, y * p.mb.slab);
         p.slotmin = mb_adv(p.slotmin, y * p.mb.zslab);
+        p.bkt = mb_adv(p.bkt, y * p.mb.zslab);
         units = mb_adv(units, y * p.mb.slab);
         n_units_ptr = mb_adv(n_units_ptr, y * p.mb.zslab);
     }
@@ -2191,10 +2192,16 @@ __global__ __launch_bounds__(kIvfUnitThreads) void ivf_unit_scan_kernel(IvfListS
                                 }
                         }
                     }
-                    if (p.slotmin) {  // fold the 4 lanes of the query column, one atomic per (unit, query)
+                    if (p.slotmin || p.bkt) {  // fold the 4 lanes of the query column, one atomic per (unit, query)
                         umin = fminf(umin, __shfl_xor(umin, 16));
                         umin = fminf(umin, __shfl_xor(umin, 32));
-                        if (live && g == 0 && umin < VS_INF) atomicMax(p.slotmin + qi * kIvfSlots + (u & (kIvfSlots - 1)), ~f32_ordered(umin));
+                        if (live && g == 0 && umin < VS_INF) {
+                            if (p.bkt)  // block of the query's candidate array in which this unit's scores start
+                                atomicMax(p.bkt + (long long)qi * p.nbk + (int)((cbase - (long long)qi * p.cand_stride + (r0 - list_start)) >> 5),
+                                          ~f32_ordered(umin));
+                            else
+                                atomicMax(p.slotmin + qi * kIvfSlots + (u & (kIvfSlots - 1)), ~f32_ordered(umin));
+                        }
                     }
                 }
             }
@@ -2243,11 +2250,17 @@ __global__ __launch_bounds__(kIvfUnitThreads) void ivf_unit_scan_kernel(IvfListS
                     umin = fminf(umin, d);
                 }
             }
-            if (p.slotmin) {  // the unit's minimum score for this query: fold the row lanes, one atomic
+            if (p.slotmin || p.bkt) {  // the unit's minimum score for this query: fold the row lanes, one atomic
                 umin = fminf(umin, __shfl_xor(umin, 8));
                 umin = fminf(umin, __shfl_xor(umin, 16));
                 umin = fminf(umin, __shfl_xor(umin, 32));
-                if (lane == 0 && umin < VS_INF) atomicMax(p.slotmin + qi * kIvfSlots + (u & (kIvfSlots - 1)), ~f32_ordered(umin));
+                if (lane == 0 && umin < VS_INF) {
+                    if (p.bkt)
+                        atomicMax(p.bkt + (long long)qi * p.nbk + (int)((p.lbase[c * kMaxBatch + s] - (long long)qi * p.cand_stride + (r0 - list_start)) >> 5),
+                                  ~f32_ordered(umin));
+                    else
+                        atomicMax(p.slotmin + qi * kIvfSlots + (u & (kIvfSlots - 1)), ~f32_ordered(umin));
+                }
             }
         }
     }
@@ -2426,6 +2439,7 @@ __global__ __launch_bounds__(256) void ivf_bound_kernel(IvfSelectParams p) {
         p.gcand_p = mb_adv(p.gcand_p, y * p.mb.slab);
         p.tq = mb_adv(p.tq, y * p.mb.zslab);
         p.slotmin = mb_adv(p.slotmin, y * p.mb.zslab);
+        p.bkt = mb_adv(p.bkt, y * p.mb.zslab);
         p.gcnt = mb_adv(p.gcnt, y * p.mb.zslab);
         p.gdone = mb_adv(p.gdone, y * p.mb.zslab);
         p.govf = mb_adv(p.govf, y * p.mb.zslab);
@@ -2472,6 +2486,7 @@ __global__ __launch_bounds__(256) void ivf_select_kernel(IvfSelectParams p) {
         p.gcand_p = mb_adv(p.gcand_p, y * p.mb.slab);
         p.tq = mb_adv(p.tq, y * p.mb.zslab);
         p.slotmin = mb_adv(p.slotmin, y * p.mb.zslab);
+        p.bkt = mb_adv(p.bkt, y * p.mb.zslab);
         p.gcnt = mb_adv(p.gcnt, y * p.mb.zslab);
         p.gdone = mb_adv(p.gdone, y * p.mb.zslab);
         p.govf = mb_adv(p.govf, y * p.mb.zslab);
@@ -2497,12 +2512,33 @@ __global__ __launch_bounds__(256) void ivf_select_kernel(IvfSelectParams p) {
         const unsigned u = p.slotmin ? 0u : p.tq[q];  // bound from ivf_bound_kernel (0 = none)
         s_t = u ? f32_unordered(~u) : VS_INF;
     }
-    if (p.slotmin && tid < kIvfSlots) {
+    __shared__ float s_mn[256];
+    __shared__ int s_blk[1024];
+    __shared__ int s_nblk;
+    const unsigned* bk = p.bkt ? p.bkt + (long long)q * p.nbk : nullptr;
+    const int nb_used = min(p.nbk, (S + 31) / 32 + 1);
+    if (bk) {
+        // per-block minima of the unit scan: the k-th smallest of the 256 thread minima is backed by k distinct candidates
+        float mine = VS_INF;
+        for (int j = tid; j < nb_used; j += 256) {
+            const unsigned u = bk[j];
+            if (u) mine = fminf(mine, f32_unordered(~u));
+        }
+        s_mn[tid] = mine;
+        if (tid == 0) s_nblk = 0;
+    }
+    if (!bk && p.slotmin && tid < kIvfSlots) {
         const unsigned u = p.slotmin[q * kIvfSlots + tid];  // minima of disjoint sets of units (0 = empty slot)
         s_slot[tid] = u ? f32_unordered(~u) : VS_INF;
     }
     __syncthreads();
-    if (p.slotmin && tid < kIvfSlots) {
+    if (bk) {
+        const float v = s_mn[tid];
+        int rank = 0;
+        for (int j = 0; j < 256; ++j) rank += (s_mn[j] < v || (s_mn[j] == v && j < tid)) ? 1 : 0;
+        if (rank == min(p.k, 256) - 1) s_t = v;
+    }
+    if (!bk && p.slotmin && tid < kIvfSlots) {
         // k-th smallest of the slot minima: k distinct candidates are at least that good
         const float v = s_slot[tid];
         int rank = 0;
@@ -2528,6 +2564,30 @@ __global__ __launch_bounds__(256) void ivf_select_kernel(IvfSelectParams p) {
             }
         }
     };
+    if (bk) {
+        // only the 32-score blocks that can hold a score under the bound are read: block j is needed when a unit that
+        // starts in block j or j - 1 has a minimum <= T (a unit's 32 scores span at most two blocks)
+        if (part == 0) {
+            for (int j = tid; j < nb_used; j += 256) {
+                const unsigned u0 = bk[j], u1 = j > 0 ? bk[j - 1] : 0u;
+                const bool need = (u0 && f32_unordered(~u0) <= T) || (u1 && f32_unordered(~u1) <= T);
+                if (need) {
+                    const int pos = atomicAdd(&s_nblk, 1);
+                    if (pos < 1024) s_blk[pos] = j;
+                }
+            }
+            __syncthreads();
+            const int nblk = s_nblk;
+            if (nblk > 1024) {
+                if (tid == 0) s_cnt = 2048;  // too many blocks under the bound: the exact slow path below
+            } else {
+                for (int e = tid; e < nblk * 32; e += 256) {
+                    const int i = 32 * s_blk[e >> 5] + (e & 31);
+                    if (i < S) consider(i, sc[i]);
+                }
+            }
+        }
+    } else {
     // this workgroup's slice of the candidate array (16-byte loads, four in flight per thread)
     const int S4 = S >> 2;
     const int per = (S4 + kSelSplit - 1) / kSelSplit;
@@ -2551,6 +2611,7 @@ __global__ __launch_bounds__(256) void ivf_select_kernel(IvfSelectParams p) {
     }
     if (part == kSelSplit - 1)
         for (int i = 4 * S4 + tid; i < S; i += 256) consider(i, sc[i]);
+    }
     __syncthreads();
     // append to the query's global candidate list (write-through), then take an arrival ticket
     const int C = s_cnt;
@@ -2649,7 +2710,7 @@ __global__ __launch_bounds__(256) void ivf_select_kernel(IvfSelectParams p) {
 
 hipError_t launch_ivf_select(const IvfSelectParams& p, int B, hipStream_t s, int n_batches) {
     if (p.k > 16 || p.nprobe > 256) return hipErrorInvalidValue;
-    if (!p.slotmin) hipLaunchKernelGGL(ivf_bound_kernel, dim3(B * kSelSplit, n_batches), dim3(256), 0, s, p);
+    if (!p.slotmin && !p.bkt) hipLaunchKernelGGL(ivf_bound_kernel, dim3(B * kSelSplit, n_batches), dim3(256), 0, s, p);
     hipLaunchKernelGGL(ivf_select_kernel, dim3(B * kSelSplit, n_batches), dim3(256), 0, s, p);
     return hipGetLastError();
 }
