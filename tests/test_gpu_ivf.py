@@ -333,3 +333,36 @@ def test_large_nlist_paths(gpu_pkg, nlist):
         ivf.search_dev_multi(qd.data_ptr(), 3, 32, k, nprobe, gi.data_ptr(), gd.data_ptr(), s)
         torch.cuda.synchronize()
         assert np.array_equal(gd.cpu().numpy(), d) and np.array_equal(gi.cpu().numpy(), ids)
+
+
+def test_cluster_shards_multi_batch(gpu_pkg):
+    """Sharded index + multi-batch launches (what bench.py --gpus N runs per rank): lists that are not resident on a
+    shard have length 0 there and must drop out of the work plan; merged shards equal the unsharded result."""
+    import torch
+    dev = torch.device("cuda:0")
+    base, cents, vr, off, r2o = _make_index(gpu_pkg, n=16000, nlist=64, seed=6)
+    nb, k, nprobe, world = 5, 5, 16, 4
+    q = gpu_pkg.synth_sift(32 * nb, seed=67)
+    s = torch.cuda.current_stream().cuda_stream
+    qd = torch.from_numpy(q).to(dev)
+
+    def run(rank, w):
+        with gpu_pkg.IVFIndex(vectors_reordered=vr, centroids=cents, cluster_offsets=off, reorder_to_original=r2o,
+                              rank=rank, world=w) as ivf:
+            ids = torch.zeros((nb * 32, k), dtype=torch.int32, device=dev)
+            d = torch.zeros((nb * 32, k), dtype=torch.float32, device=dev)
+            ivf.search_dev_multi(qd.data_ptr(), nb, 32, k, nprobe, ids.data_ptr(), d.data_ptr(), s)
+            torch.cuda.synchronize()
+            return d, ids
+    d_all, i_all = run(0, 1)
+    parts = [run(r, world) for r in range(world)]
+    gd = torch.stack([p[0] for p in parts]).contiguous()
+    gi = torch.stack([p[1] for p in parts]).contiguous()
+    od = torch.zeros((nb * 32, k), dtype=torch.float32, device=dev)
+    oi = torch.zeros((nb * 32, k), dtype=torch.int32, device=dev)
+    gpu_pkg.topk_merge_dev(gd.data_ptr(), gi.data_ptr(), world, nb * 32, k, k, od.data_ptr(), oi.data_ptr(), 0, s)
+    torch.cuda.synchronize()
+    assert torch.equal(od, d_all)
+    a, b = i_all.cpu().numpy(), oi.cpu().numpy()
+    for i in range(nb * 32):
+        assert sorted(a[i].tolist()) == sorted(b[i].tolist())
