@@ -613,9 +613,14 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams 
             }
         }
     };
+    // The ticket is taken with an opaque ds_add_rtn: hipcc orders a visible LDS atomic behind EVERY pending LDS-DMA
+    // (s_waitcnt vmcnt(0): it cannot tell that the counter and the ring do not overlap), which would drain the
+    // tile queue once per tile and leave a wave with one tile in flight instead of two.
+    const unsigned ticket_addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) int*)lds_ticket;
     auto next_ticket = [&]() -> int {
         int tk = 0;
-        if (lane == 0) tk = atomicAdd(&lds_ticket[0], 1);
+        if (lane == 0)
+            asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(tk) : "v"(ticket_addr), "v"(1) : "memory");
         return tile0 + __builtin_amdgcn_readfirstlane(tk) * tile_step;
     };
 
