@@ -477,13 +477,16 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams 
     }
     const unsigned fa_n = (unsigned)(wave * (kDepth * kSlotBytes) + 8192 + 16 * g);  // norms / row terms of rows 4g..4g+3 (+16 rg)
     // distances of one tile: d[rg][h][j] for query column 16 h + r, base rows 16 rg + 4 g + j
-    auto tile_distances = [&](int tt, int slot, float (&d)[NRG][NQH][4]) __attribute__((always_inline)) {
+    // after_frags(): called once the tile's fragments have been requested from LDS (the caller waits for them and may
+    // then refill the slot while the MFMAs run)
+    auto tile_distances = [&](int tt, int slot, float (&d)[NRG][NQH][4], auto after_frags) __attribute__((always_inline)) {
         const char* src = smem + slot * kSlotBytes;
         if (PREC == 0) {
             f32x4 a[8];
 #pragma unroll
             for (int c = 0; c < 8; ++c) a[c] = *reinterpret_cast<const f32x4*>(src + fa[c]);
             const f32x4 bn = *reinterpret_cast<const f32x4*>(src + fa_n);
+            after_frags();
             f32x4 acc[NQH];
 #pragma unroll
             for (int h = 0; h < NQH; ++h) acc[h] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -513,6 +516,7 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams 
                 a1[rg] = *reinterpret_cast<const i32x4*>(src + fa[2 * rg + 1]);
                 rtv[rg] = *reinterpret_cast<const i32x4*>(src + fa_n + 64 * rg);
             }
+            after_frags();
 #pragma unroll
             for (int rg = 0; rg < NRG; ++rg) {
 #pragma unroll
@@ -648,7 +652,7 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams 
         };
         asm volatile("s_waitcnt vmcnt(9)" ::: "memory");  // A landed (B follows)
         VS_STAMP(11);
-        tile_distances(min(t_a, tlast), 0, wk[0]);
+        tile_distances(min(t_a, tlast), 0, wk[0], [] {});
         VS_STAMP(12);
         kill(t_a >= tile1, wk[0]);
         const int t_c = next_ticket();
@@ -674,7 +678,7 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams 
         }
         VS_STAMP(2);
         asm volatile("s_waitcnt vmcnt(9)" ::: "memory");  // B landed (C, and on wave 1 the store, follow)
-        tile_distances(min(t_b, tlast), 1, wk[1]);
+        tile_distances(min(t_b, tlast), 1, wk[1], [] {});
         kill(t_b >= tile1, wk[1]);
         VS_STAMP(7);
         // DPP row `g` of wave w will reduce query 4w+g: its 16 lanes read that query's 1 KB row of
@@ -698,7 +702,7 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams 
         if (NKEEP == 3) {
             asm volatile("s_waitcnt vmcnt(13)" ::: "memory");  // C landed
             VS_STAMP(9);
-            tile_distances(min(t_c, tlast), 0, wk[NKEEP - 1]);
+            tile_distances(min(t_c, tlast), 0, wk[NKEEP - 1], [] {});
             kill(t_c >= tile1, wk[NKEEP - 1]);
             VS_STAMP(8);
             t_e = next_ticket();
@@ -780,13 +784,17 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams 
     // ---- steady state: t_cur sits in `slot` (landed or landing), t_nxt in the other slot ----
     // (written per slot so that the slot is a compile-time constant: LDS offsets become immediates)
     auto step = [&](const int sl) __attribute__((always_inline)) {
+        const int t_new = next_ticket();
         asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
         float d[NRG][NQH][4];
-        tile_distances(t_cur, sl, d);
+        // the slot is refilled as soon as its fragments sit in registers, before the MFMAs: two tiles in flight
+        tile_distances(t_cur, sl, d, [&] {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            issue_or_stage(t_new, sl);
+        });
         consume(t_cur, d);
         t_cur = t_nxt;
-        t_nxt = next_ticket();
-        issue_or_stage(t_nxt, sl);
+        t_nxt = t_new;
     };
     if (slot == 1 && t_cur < tile1) step(1);
     while (t_cur < tile1) {
