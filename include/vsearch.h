@@ -186,9 +186,9 @@ VS_API int vs_ivf_search_dev(vs_index* h, const float* queries_dev, int B, int k
                              int32_t* ids_dev, float* dists_dev, void* stream);
 
 /* The batch loop of main_ivf.cpp:150-214 with the queries already on the device: n_batches independent
- * batches [n_batches][B][dim] -> [n_batches][B][k].  Batches alternate between two internal streams (each
- * with its own scratch), so one batch's latency-bound steps (coarse + probe pick, top-k selection) run
- * beside the other's list scan; `stream` waits for both. */
+ * batches [n_batches][B][dim] -> [n_batches][B][k].  Every kernel of the pipeline is launched once for a
+ * group of up to 32 batches (blockIdx.y = batch, per-batch scratch slabs), so the latency-bound steps
+ * (coarse + probe pick, grouping, selection) fill the GPU and the host enqueues six operations per group. */
 VS_API int vs_ivf_search_dev_multi(vs_index* h, const float* queries_dev, int n_batches, int B, int k, int nprobe,
                                    int32_t* ids_dev, float* dists_dev, void* stream);
 
