@@ -2,20 +2,24 @@
 """bench.py -- QPS of the distance + top-k hot path on MI355X (BASELINE.json metric).
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  (N > 1 without a launcher: this script starts N child ranks itself, before anything touches the GPU;
+   under `python -m torch.distributed.run --nproc-per-node N ...` it is one of the ranks.)
 
 A *step* is one pass of the hot path over one batch of 32 synthetic queries that are already
 resident in HBM: exact brute force, k = 5, against the synthetic SIFT-1M base (1 000 000 x 128 fp32,
 generator of SURVEY.md 8d, seeds 20251205 / 20251206).  `value` = queries / second of the whole job.
+The timed region of exactly K steps is repeated `--repeats` times (barrier + synchronize on both
+sides, max over ranks each time); `value` / `ms_per_step` are the median region.
 
 N = 1  : config "SIFT-1M brute-force batch=32 on 1xMI355X" (BASELINE.json configs[2]).
 N > 1  : the same base row-sharded over the ranks (strong scaling); every rank scans its shard for
-         the same 32 queries, the per-shard top-(k+1) lists are exchanged with ONE RCCL all-gather per
-         `--coll-every` steps and merged on the device (the only data-path collective the path has).
-Extra (same JSON line, key "ivf"): IVF nlist=1024 nprobe=32 QPS + recall@1 on the same data, list
-shards dealt over the ranks when N > 1 (BASELINE.json configs[3]/[4]).
+         the same queries, the per-shard top-(k+1) lists are exchanged with ONE RCCL all-gather per
+         group of `--coll-every` steps and merged on the device (the only collective the path has).
+Extras on the same JSON line: "ivf" (nlist=1024 nprobe=32, configs[3]/[4]), "ivf_nprobe8", "bf_int8",
+"host_api" (vs_bf_search / vs_ivf_search on host buffers: upload, download and reference tie order
+inside the timed region -- SURVEY 8(d)'s QPS definition), "siftsmall_b1", "sift1m_b1" (configs[1]).
 
-The JSON line also carries `roofline` (dominant kernel vs the HBM roof, timed with HIP events on the
+The line also carries `roofline` (dominant kernel vs the HBM roof, timed with HIP events on the
 stream it runs on) and `cpu_baseline` (the oracle's restatement of cpu_baseline.cpp on this box's
 host cores, bounded sample, rank 0 at N = 1 only).
 """
@@ -24,6 +28,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -33,6 +39,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 N_BASE = 1_000_000
+N_SMALL = 10_000
 DIM = 128
 BATCH = 32
 K = 5
@@ -47,33 +54,31 @@ def log(*a):
         print("[bench]", *a, file=sys.stderr, flush=True)
 
 
-def kmeans_assign(x, cents, chunk=131072):
-    """argmin_c ||x - c||^2 on the GPU with torch (index BUILD only -- not the graded path)."""
-    import torch
-    cn = (cents * cents).sum(1)
-    out = torch.empty(x.shape[0], dtype=torch.int64, device=x.device)
-    for s in range(0, x.shape[0], chunk):
-        xs = x[s:s + chunk]
-        d = cn[None, :] - 2.0 * (xs @ cents.T)
-        out[s:s + chunk] = d.argmin(1)
-    return out
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks as child processes.  The parent
+    has not imported torch or touched HIP at this point and never does."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        rc = p.wait() or rc
+    sys.stdout.write(out0.decode(errors="replace"))
+    sys.stdout.flush()
+    return rc
 
 
-def build_ivf_torch(base_dev, nlist, iters, seed):
-    """Lloyd k-means (create_ivf_model_reordered.py:96-105 uses sklearn KMeans; rebuilt here with
-    torch because the reference builder does not parse and sklearn is not the point of the bench)."""
-    import torch
-    g = torch.Generator(device="cpu").manual_seed(seed)
-    n = base_dev.shape[0]
-    cents = base_dev[torch.randperm(n, generator=g)[:nlist].to(base_dev.device)].clone()
-    for _ in range(iters):
-        a = kmeans_assign(base_dev, cents)
-        sums = torch.zeros_like(cents).index_add_(0, a, base_dev)
-        cnt = torch.bincount(a, minlength=nlist).to(cents.dtype)
-        nz = cnt > 0
-        cents[nz] = sums[nz] / cnt[nz, None]
-    a = kmeans_assign(base_dev, cents)
-    return cents, a
+def median(xs):
+    xs = sorted(xs)
+    return xs[len(xs) // 2]
 
 
 def main():
@@ -81,6 +86,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--repeats", type=int, default=5, help="the timed region of K steps is repeated R times; the median is reported")
     ap.add_argument("--coll-every", type=int, default=32,
                     help="batches per multi-batch call (and per all-gather + merge when N > 1)")
     ap.add_argument("--rows", type=int, default=N_BASE, help="base rows (default SIFT-1M)")
@@ -88,22 +94,27 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not time the scan kernel with HIP events")
     ap.add_argument("--no-int8", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip host_api / B=1 / nprobe=8 legs")
     ap.add_argument("--kmeans-iters", type=int, default=20)
-    ap.add_argument("--torch-kmeans", action="store_true", help="build the index with torch instead of vs_ivf_build")
+    ap.add_argument("--collective", default="auto", choices=["auto", "library", "torch"],
+                    help="N > 1: RCCL all-gather inside libvsearch_hip.so (vs_comm_*) or torch.distributed's")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N > 1 path on ONE GPU (all ranks share cuda:0, gathers staged through host)")
     args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1 and args.gpus > 1:
+        # no launcher: become one (nothing has initialised the GPU in this process)
+        raise SystemExit(self_launch(args.gpus))
+    if world != args.gpus:
+        raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
 
     import torch
     import __graft_entry__ as ge
     pkg = ge.load_package()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched through torch.distributed.run (one rank per GPU)")
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -120,7 +131,8 @@ def main():
         raise SystemExit("no HIP device: the bench never runs a CPU fallback")
 
     n_rows = args.rows
-    steps, warmup, S = args.steps, args.warmup, max(1, args.coll_every)
+    steps, warmup, S = max(1, args.steps), max(1, args.warmup), max(1, min(32, args.coll_every))
+    R = max(1, args.repeats)
     K1 = K + 1
 
     # ---------------------------------------------------------------- data (synthetic, deterministic)
@@ -137,42 +149,36 @@ def main():
     q_dev = torch.from_numpy(queries).to(dev)
     stream = torch.cuda.current_stream()
     sptr = stream.cuda_stream
+    n_qbatches = n_queries // BATCH
 
-    # per-rank result buffer: [2][S][B][K1] words (dists as float bits | ids) -> one all-gather per S steps
-    lay = pkg.GatherLayout(S, BATCH, K1)
-    loc = torch.zeros((lay.words,), dtype=torch.int32, device=dev)
-    loc_d_ptr = loc.data_ptr()
-    loc_i_ptr = loc.data_ptr() + lay.ids_offset * 4
-    gath = torch.zeros((world * lay.words,), dtype=torch.int32, device=dev) if world > 1 else None
+    # ---------------------------------------------------------------- the one collective (N > 1)
+    comm = None
+    coll_kind = None
+    if world > 1:
+        coll_kind = "torch-rccl" if args.backend == "nccl" else "gloo-rehearsal"
+        if args.backend == "nccl" and args.collective in ("auto", "library") and hasattr(pkg, "Comm"):
+            try:
+                uid = [pkg.Comm.unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(uid, src=0)
+                comm = pkg.Comm(uid[0], rank, world, local_rank)
+                coll_kind = "library-rccl"
+            except Exception as e:  # the torch collective below is the same all-gather driven from here
+                if args.collective == "library":
+                    raise
+                log(f"rank {rank}: library RCCL communicator unavailable ({e}); using torch.distributed's all-gather")
+                comm = None
+        ok = torch.tensor([1 if comm is not None else 0], device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0 and comm is not None:
+            comm.close()
+            comm = None
+            coll_kind = "torch-rccl"
+
+    loc = torch.zeros((2 * S * BATCH * K1,), dtype=torch.int32, device=dev)
+    gath = torch.zeros((world * loc.numel(),), dtype=torch.int32, device=dev) if world > 1 else None
     out_d = torch.zeros((S * BATCH, K1), dtype=torch.float32, device=dev)
     out_i = torch.zeros((S * BATCH, K1), dtype=torch.int32, device=dev)
     flags = torch.zeros((S * BATCH,), dtype=torch.int32, device=dev)
-    n_qbatches = n_queries // BATCH
-
-    def bf_step(i, n):
-        # steps are issued in groups of S batches: one multi-batch call (the harness loop of main.cpp:201-251);
-        # the last group of a run of n steps may be shorter, so that exactly n steps are processed
-        s = i % S
-        if s != S - 1 and i != n - 1:
-            return
-        gs = s + 1  # batches in this group
-        g0 = i - s  # first batch of the group; the query set is cycled
-        qb = g0 % n_qbatches
-        if qb + gs > n_qbatches:
-            qb = 0
-        qp = q_dev.data_ptr() + qb * BATCH * DIM * 4
-        if world == 1:
-            bf.search_dev_multi(qp, gs, BATCH, K, out_i.data_ptr(), out_d.data_ptr(), flags.data_ptr(), sptr)
-        else:
-            bf.search_dev_multi(qp, gs, BATCH, K, loc_i_ptr, loc_d_ptr, 0, sptr)
-            all_gather(gath, loc)
-            pkg.topk_merge_dev(gath.data_ptr(), gath.data_ptr() + lay.ids_offset * 4, world, S * BATCH, K1, K1,
-                               out_d.data_ptr(), out_i.data_ptr(), flags.data_ptr(), sptr, stride_g=lay.stride_g)
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
 
     def all_gather(dst, src):
         """ONE collective for the per-shard top-k lists (RCCL over xGMI; gloo only in rehearsals)."""
@@ -184,37 +190,83 @@ def main():
         else:
             dist.all_gather_into_tensor(dst, src)
 
-    def timed(step_fn, nsteps, nwarm):
+    def group_of(i, n):
+        """steps are issued in groups of S batches (one multi-batch call = the harness loop of main.cpp:201-251);
+        the last group of a run of n steps may be shorter, so that exactly n steps are processed"""
+        s = i % S
+        if s != S - 1 and i != n - 1:
+            return None
+        gs = s + 1
+        qb = (i - s) % n_qbatches
+        if qb + gs > n_qbatches:
+            qb = 0
+        return gs, q_dev.data_ptr() + qb * BATCH * DIM * 4
+
+    def sharded_call(search_local, search_sharded, gs, qp, kk, o_i, o_d, fl):
+        """N > 1: local top-kk per shard -> one all-gather of gs * BATCH lists per rank -> device merge."""
+        if comm is not None:
+            search_sharded(comm, qp, gs, BATCH, o_i.data_ptr(), o_d.data_ptr(), fl, sptr)
+            return
+        lay = pkg.GatherLayout(gs, BATCH, kk)
+        lv, gv = loc[:lay.words], gath[:world * lay.words]
+        search_local(qp, gs, lv.data_ptr() + lay.ids_offset * 4, lv.data_ptr())
+        all_gather(gv, lv)
+        pkg.topk_merge_dev(gv.data_ptr(), gv.data_ptr() + lay.ids_offset * 4, world, gs * BATCH, kk, kk,
+                           o_d.data_ptr(), o_i.data_ptr(), fl, sptr, stride_g=lay.stride_g)
+
+    def bf_step(i, n):
+        g = group_of(i, n)
+        if g is None:
+            return
+        gs, qp = g
+        if world == 1:
+            bf.search_dev_multi(qp, gs, BATCH, K, out_i.data_ptr(), out_d.data_ptr(), flags.data_ptr(), sptr)
+        else:
+            sharded_call(lambda q, nb, ip, dp: bf.search_dev_multi(q, nb, BATCH, K, ip, dp, 0, sptr),
+                         lambda c, q, nb, B, ip, dp, fl, st: bf.search_dev_sharded(c, q, nb, B, K, ip, dp, fl, st),
+                         gs, qp, K1, out_i, out_d, flags.data_ptr())
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(step_fn, nsteps, nwarm, repeats=R):
+        """W warm-up steps, then `repeats` regions of exactly `nsteps` steps, each bracketed by barrier + synchronize,
+        max over ranks per region; returns the list of region times."""
         for i in range(nwarm):
             step_fn(i, nwarm)
-        barrier()
-        t = time.perf_counter()
-        for i in range(nsteps):
-            step_fn(i, nsteps)
-        barrier()
-        el = time.perf_counter() - t
-        if dist is not None:
-            tt = torch.tensor([el], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            el = float(tt.item())
-        return el
+        out = []
+        for _ in range(repeats):
+            barrier()
+            t = time.perf_counter()
+            for i in range(nsteps):
+                step_fn(i, nsteps)
+            barrier()
+            el = time.perf_counter() - t
+            if dist is not None:
+                tt = torch.tensor([el], dtype=torch.float64, device=dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                el = float(tt.item())
+            out.append(el)
+        return out
 
-    steps = max(1, steps)
-    warmup = max(1, warmup)
-
-    # correctness spot check on the first batch before timing (rank 0, against the oracle at small scale
-    # happens in tests; here: self-consistency of the sharded path vs. properties)
+    # ---------------------------------------------------------------- brute force fp32 (the headline)
     bf.prof_enable(not args.no_prof)
-    elapsed = timed(bf_step, steps, warmup)
+    regions = timed(bf_step, steps, warmup)
     kern_ms, kern_n = bf.prof_read(0)
     bf.prof_enable(False)
+    elapsed = median(regions)
     qps = steps * BATCH / elapsed
     ms_per_step = elapsed / steps * 1e3
-    # the prof window covers the warmup + timed launches = warmup + steps batches (the last launch of a run may
-    # hold fewer than S batches): scale to a launch of S batches
-    kern_avg_s = (kern_ms * 1e-3) / (warmup + steps) * S if kern_n else 0.0
+    # the prof window covers every launch of the warm-up and of the R regions = warmup + R * steps batches (the last
+    # launch of a run may hold fewer than S batches): time per batch, scaled to a launch of S batches
+    n_batches_prof = warmup + R * steps
+    kern_per_batch_s = (kern_ms * 1e-3) / n_batches_prof if kern_n else 0.0
+    kern_avg_s = kern_per_batch_s * S
     rows_local = r1 - r0
-    algo_bytes = (4 * rows_local * DIM + 4 * rows_local + 4 * BATCH * DIM + 8 * BATCH * K) * S  # SURVEY.md 8(d) x S batches per launch
+    batch_bytes = 4 * rows_local * DIM + 4 * rows_local + 4 * BATCH * DIM + 8 * BATCH * K  # SURVEY.md 8(d)
+    algo_bytes = batch_bytes * S
     achieved = algo_bytes / kern_avg_s / 1e9 if kern_avg_s > 0 else 0.0
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic_bf_scan.json")
@@ -223,7 +275,8 @@ def main():
             traffic = json.load(open(tpath)).get("hbm_bytes_per_batch") * S
         except Exception:
             traffic = None
-    log(f"brute force: {qps:.0f} QPS, {ms_per_step * 1e3:.1f} us/step, scan kernel {kern_avg_s * 1e6:.1f} us "
+    log(f"brute force: {qps:.0f} QPS, {ms_per_step * 1e3:.1f} us/step (median of {R}: "
+        f"{', '.join(f'{e / steps * 1e6:.1f}' for e in regions)}), scan kernel {kern_per_batch_s * 1e6:.1f} us/batch "
         f"({achieved:.0f} GB/s algorithmic)")
 
     # exactness guard on what was just timed: ascending, finite, ids in range
@@ -242,13 +295,14 @@ def main():
         else:
             fp32_d, fp32_i = od.copy(), oi.copy()
             bf.prof_enable(not args.no_prof)
-            el8 = timed(bf_step, steps, warmup)
+            reg8 = timed(bf_step, steps, warmup)
             k8_ms, k8_n = bf.prof_read(0)
             bf.prof_enable(False)
             torch.cuda.synchronize()
             assert np.array_equal(out_d.cpu().numpy(), fp32_d) and np.array_equal(out_i.cpu().numpy(), fp32_i), \
                 "int8 path differs from the fp32 path"
-            k8_s = (k8_ms * 1e-3) / (warmup + steps) * S if k8_n else 0.0
+            el8 = median(reg8)
+            k8_s = (k8_ms * 1e-3) / n_batches_prof * S if k8_n else 0.0
             b8 = (rows_local * DIM + 4 * rows_local + 4 * BATCH * DIM + 8 * BATCH * K) * S  # u8 rows + i32 row terms
             int8_info = {"metric": "QPS, same workload, rows stored as u8 + int8 MFMA (bit-identical results)",
                          "value": round(steps * BATCH / el8, 1), "ms_per_step": round(el8 / steps * 1e3, 5),
@@ -257,118 +311,174 @@ def main():
                                       "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                       "frac": round(b8 / k8_s / 1e9 / HBM_PEAK_GBS, 4) if k8_s > 0 else None,
                                       "traffic": None, "algorithmic_bytes_per_launch": b8,
-                                      "note": "128 MB of rows fit the 256 MB Infinity Cache, so the rate can exceed HBM's"}}
+                                      "note": "the 128 MB of rows fit the 256 MB Infinity Cache: the binding limit is the "
+                                              "per-CU LDS-DMA delivery rate, not HBM; HBM peak is the reference roof"}}
             log(f"int8 path: {int8_info['value']:.0f} QPS, {int8_info['ms_per_step'] * 1e3:.1f} us/step")
             bf.set_precision(1)
 
-    # ---------------------------------------------------------------- IVF extra
+    # ---------------------------------------------------------------- host-buffer API (SURVEY 8(d)'s QPS definition)
+    host_info = None
+    if world == 1 and not args.no_extras:
+        nq_h = n_queries
+        tm = pkg.Timing()
+        bf.search(queries[:nq_h], K)  # pinned staging + tie scratch allocated here, not in the timed calls
+        th = []
+        for _ in range(R):
+            t = time.perf_counter()
+            hid, hdd = bf.search(queries[:nq_h], K, tm)
+            th.append(time.perf_counter() - t)
+        host_info = {"bf": {"metric": "QPS of vs_bf_search on host buffers (query upload, result download and reference tie "
+                                      "order inside the timed call)", "value": round(nq_h / median(th), 1), "queries_per_call": nq_h,
+                            "tie_queries": int(tm.tie_queries), "tie_resolve_ms": round(tm.tie_resolve_ms, 3),
+                            "vs_device_api": round(nq_h / median(th) / qps, 4)}}
+        log(f"host API brute force: {host_info['bf']['value']:.0f} QPS ({nq_h} queries per call, {tm.tie_queries} tie queries, "
+            f"{tm.tie_resolve_ms:.2f} ms resolving them)")
+
+    # ---------------------------------------------------------------- B = 1 legs (BASELINE.json configs[1])
+    b1_info = {}
+    if world == 1 and not args.no_extras:
+        o1_d = torch.zeros((32, K1), dtype=torch.float32, device=dev)
+        o1_i = torch.zeros((32, K1), dtype=torch.int32, device=dev)
+        f1 = torch.zeros((32,), dtype=torch.int32, device=dev)
+
+        def b1_leg(index, rows, tag):
+            # throughput: 32 single-query batches per call (each streams the base once: cpu_baseline's loop, one launch)
+            def step(i, n):
+                if i % 32 != 31 and i != n - 1:
+                    return
+                gs = i % 32 + 1
+                index.search_dev_multi(q_dev.data_ptr() + ((i - gs + 1) % 1024) * DIM * 4, gs, 1, K, o1_i.data_ptr(),
+                                       o1_d.data_ptr(), f1.data_ptr(), sptr)
+            nst = 640
+            reg = timed(step, nst, 64, repeats=3)
+            us_q = median(reg) / nst * 1e6
+            # latency: one query per call, synchronised (launch + scan + merge + sync)
+            lat = []
+            for i in range(60):
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                index.search_dev(q_dev.data_ptr() + i * DIM * 4, 1, K, o1_i.data_ptr(), o1_d.data_ptr(), f1.data_ptr(), sptr)
+                torch.cuda.synchronize()
+                lat.append(time.perf_counter() - t)
+            lat_us = median(lat[10:]) * 1e6
+            bytes_q = 4 * rows * DIM + 4 * rows + 4 * DIM + 8 * K
+            info = {"us_per_query": round(us_q, 2), "qps": round(1e6 / us_q, 1), "latency_us_single_call": round(lat_us, 1),
+                    "rows": rows, "batch": 1, "algorithmic_bytes_per_query": bytes_q,
+                    "hbm_frac": round(bytes_q / (us_q * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+            log(f"{tag}: {us_q:.2f} us/query streamed ({info['qps']:.0f} QPS), {lat_us:.1f} us single-call latency")
+            return info
+
+        b1_info["sift1m_b1"] = b1_leg(bf, rows_local, "SIFT-1M B=1")
+        small = pkg.synth_sift(N_SMALL, seed=SEED_BASE)
+        bfs = pkg.BruteForceIndex(small, device=local_rank)
+        bfs.set_precision(1)
+        b1_info["siftsmall_b1"] = b1_leg(bfs, N_SMALL, "SIFT-small B=1")
+        b1_info["siftsmall_b1"]["note"] = "5 MB base: cache resident, launch-latency bound (SURVEY 8(d)): absolute us are the figure"
+        bfs.close()
+
+    # ---------------------------------------------------------------- IVF extras
     ivf_info = None
+    ivf8_info = None
     if not args.no_ivf:
         t0 = time.time()
         # every rank builds the same index deterministically from the full base (index build is
         # outside the timed region and outside the graded path)
         full = shard if world == 1 else pkg.synth_sift(n_rows, seed=SEED_BASE)
         nlist = pkg.clamp_nlist(n_rows, NLIST)
-        if args.torch_kmeans:
-            full_dev = torch.from_numpy(full).to(dev)
-            cents, assign = build_ivf_torch(full_dev, nlist, args.kmeans_iters, seed=42)
-            vr, off, r2o = pkg.ivf_layout_from_assignment(full, assign.cpu().numpy(), nlist)
-            cents_h = cents.cpu().numpy()
-            del full_dev, assign
-            torch.cuda.empty_cache()
-        else:
-            # native builder: k-means on the library's own MFMA scan kernel, deterministic
-            vr, off, r2o, cents_h, n_it = pkg.ivf_build(full, nlist, max_iter=args.kmeans_iters, seed=42, device=local_rank)
-            log(f"vs_ivf_build: {n_it} Lloyd iterations")
+        # native builder: k-means on the library's own MFMA scan kernel, deterministic
+        vr, off, r2o, cents_h, n_it = pkg.ivf_build(full, nlist, max_iter=args.kmeans_iters, seed=42, device=local_rank)
+        log(f"vs_ivf_build: {n_it} Lloyd iterations")
         ivf = pkg.IVFIndex(vectors_reordered=vr, centroids=cents_h, cluster_offsets=off, reorder_to_original=r2o,
                            device=local_rank, rank=rank, world=world)
         sizes = np.diff(off)
         log(f"IVF index: nlist={nlist}, list sizes min/avg/max = {sizes.min()}/{sizes.mean():.0f}/{sizes.max()}, "
             f"built in {time.time() - t0:.1f}s")
-        ilay = pkg.GatherLayout(S, BATCH, K)
-        iloc = torch.zeros((ilay.words,), dtype=torch.int32, device=dev)
-        igath = torch.zeros((world * ilay.words,), dtype=torch.int32, device=dev) if world > 1 else None
         iout_d = torch.zeros((S * BATCH, K), dtype=torch.float32, device=dev)
         iout_i = torch.zeros((S * BATCH, K), dtype=torch.int32, device=dev)
-
-        def ivf_step(i, n):
-            # like bf_step: groups of (up to) S independent batches per call (four streams inside the library)
-            s = i % S
-            if s != S - 1 and i != n - 1:
-                return
-            gs = s + 1
-            qb = (i - s) % n_qbatches
-            if qb + gs > n_qbatches:
-                qb = 0
-            qp = q_dev.data_ptr() + qb * BATCH * DIM * 4
-            if world == 1:
-                ivf.search_dev_multi(qp, gs, BATCH, K, NPROBE, iout_i.data_ptr(), iout_d.data_ptr(), sptr)
-            else:
-                ivf.search_dev_multi(qp, gs, BATCH, K, NPROBE, iloc.data_ptr() + ilay.id_offset(0) * 4,
-                                     iloc.data_ptr() + ilay.dist_offset(0) * 4, sptr)
-                all_gather(igath, iloc)
-                pkg.topk_merge_dev(igath.data_ptr(), igath.data_ptr() + ilay.ids_offset * 4, world, S * BATCH, K, K,
-                                   iout_d.data_ptr(), iout_i.data_ptr(), 0, sptr, stride_g=ilay.stride_g)
-
-        ivf.prof_enable(True)
-        iel = timed(ivf_step, steps, warmup)
-        okern_ms, okern_n = ivf.prof_read(1)  # scan kernel while other batches' kernels share the GPU
-        ivf.prof_enable(False)
-        # the scan kernel alone (one stream, batch by batch): the figure its roofline is computed from
-        ivf.prof_enable(True)
-        for i in range(64):
-            ivf.search_dev(q_dev.data_ptr() + (i % n_qbatches) * BATCH * DIM * 4, BATCH, K, NPROBE, iout_i.data_ptr(),
-                           iout_d.data_ptr(), sptr)
-        torch.cuda.synchronize()
-        ikern_ms, ikern_n = ivf.prof_read(1)
-        ivf.prof_enable(False)
-        ivf_qps = steps * BATCH / iel
-        # recall@1 / recall@5 against exact ground truth from the brute-force path (N = 1 only: the
-        # sharded variants are covered by tests)
-        rec1 = rec5 = None
-        avg_cand = None
+        i8_rows = bool(np.all(full == np.floor(full)) and full.min() >= 0 and full.max() <= 255)
+        row_bytes = (DIM + 4) if i8_rows else (4 * DIM + 4)
+        cn = (cents_h.astype(np.float64) ** 2).sum(1)
+        gt_ids = None
         if world == 1:
-            nrec = 1024
-            gt_ids, _ = bf.search(queries[:nrec], K)
-            ids, _, total = ivf.searchBatch(queries[:nrec], nrec, K, NPROBE)
-            rec1 = float(np.mean(ids[:, 0] == gt_ids[:, 0]))
-            rec5 = float(np.mean([len(set(ids[i]) & set(gt_ids[i])) / K for i in range(nrec)]))
-            avg_cand = total / nrec
-        ivf_info = {"metric": "ivf_qps", "value": round(ivf_qps, 1), "ms_per_step": round(iel / steps * 1e3, 4),
-                    "nlist": nlist, "nprobe": NPROBE, "batch": BATCH, "recall_at_1": rec1, "recall_at_5": rec5,
-                    "avg_candidates": avg_cand,
-                    "scan_kernel_us": round(ikern_ms / max(ikern_n, 1) * 1e3, 2),
-                    "scan_kernel_us_overlapped": round(okern_ms / max(okern_n, 1) * 1e3, 2),
-                    "note": "value and roofline: vs_ivf_search_dev_multi, every kernel launched once per group of S batches "
-                            "(scan_kernel_us_overlapped = that launch); scan_kernel_us: the scan of ONE batch alone"}
-        if avg_cand:
-            # The list-major scan reads every probed list ONCE per batch, so its algorithmic bytes are
-            # (4d + 4) * rows of the distinct lists probed by the batch (+ 4 B per (query, row) score written),
-            # not SURVEY 8(d)'s per-query (4d + 8) * S_q, which assumes one pass per query.
-            cn = (cents_h.astype(np.float64) ** 2).sum(1)
-            uniq_rows, nb_s = 0, 8
-            for b0 in range(nb_s):
-                qs = queries[b0 * BATCH:(b0 + 1) * BATCH].astype(np.float64)
-                pr = np.argsort(cn[None, :] - 2.0 * qs @ cents_h.astype(np.float64).T, axis=1)[:, :NPROBE]
-                uniq_rows += int(sizes[np.unique(pr)].sum())
-            uniq_rows /= nb_s
-            # rows: the exact int8 copy (d + 4 bytes per row) when base and queries are byte valued, else fp32 rows
-            i8_rows = bool(np.all(full == np.floor(full)) and full.min() >= 0 and full.max() <= 255)
-            row_bytes = (DIM + 4) if i8_rows else (4 * DIM + 4)
-            ib = row_bytes * uniq_rows + 4 * avg_cand * BATCH
-            # the timed region launches the scan once per group of S batches (blockIdx.y = batch)
-            ks = okern_ms / max(okern_n, 1) * 1e-3
-            itraffic = None
-            ipath = os.path.join(ROOT, "profiles", "traffic_ivf_list_scan.json")
-            if os.path.exists(ipath) and n_rows == N_BASE and i8_rows:
-                itraffic = json.load(open(ipath)).get("hbm_bytes_per_launch_32_batches")
-            ivf_info["roofline"] = {"bound": "hbm", "achieved": round(ib * S / ks / 1e9, 1), "peak": HBM_PEAK_GBS,
-                                    "unit": "GB/s", "frac": round(ib * S / ks / 1e9 / HBM_PEAK_GBS, 4), "traffic": itraffic,
-                                    "kernel": "vs::ivf_unit_scan_kernel", "kernel_us": round(ks * 1e6, 2), "batches_per_launch": S,
+            gt_ids, _ = bf.search(queries[:1024], K)
+
+        def ivf_leg(nprobe):
+            def ivf_step(i, n):
+                g = group_of(i, n)
+                if g is None:
+                    return
+                gs, qp = g
+                if world == 1:
+                    ivf.search_dev_multi(qp, gs, BATCH, K, nprobe, iout_i.data_ptr(), iout_d.data_ptr(), sptr)
+                else:
+                    sharded_call(lambda q, nb, ip, dp: ivf.search_dev_multi(q, nb, BATCH, K, nprobe, ip, dp, sptr),
+                                 lambda c, q, nb, B, ip, dp, fl, st: ivf.search_dev_sharded(c, q, nb, B, K, nprobe, ip, dp, st),
+                                 gs, qp, K, iout_i, iout_d, 0)
+
+            ivf.prof_enable(True)
+            ireg = timed(ivf_step, steps, warmup)
+            okern_ms, okern_n = ivf.prof_read(1)
+            ivf.prof_enable(False)
+            iel = median(ireg)
+            info = {"metric": "ivf_qps", "value": round(steps * BATCH / iel, 1), "ms_per_step": round(iel / steps * 1e3, 4),
+                    "nlist": nlist, "nprobe": nprobe, "batch": BATCH}
+            if world == 1:
+                nrec = 1024
+                ids, _, total = ivf.searchBatch(queries[:nrec], nrec, K, nprobe)
+                info["recall_at_1"] = float(np.mean(ids[:, 0] == gt_ids[:, 0]))          # main_ivf.cpp:52-59 with k = 1
+                info["recall_at_5"] = float(np.mean([len(set(ids[i]) & set(gt_ids[i])) / K for i in range(nrec)]))
+                info["avg_candidates"] = total / nrec
+                # The list-major scan reads every probed list ONCE per batch, so its algorithmic bytes are
+                # row_bytes * rows of the distinct lists probed by the batch (+ 4 B per (query, row) score written),
+                # not SURVEY 8(d)'s per-query (4d + 8) * S_q, which assumes one pass per query.
+                uniq_rows, nb_s = 0, 8
+                for b0 in range(nb_s):
+                    qs = queries[b0 * BATCH:(b0 + 1) * BATCH].astype(np.float64)
+                    pr = np.argsort(cn[None, :] - 2.0 * qs @ cents_h.astype(np.float64).T, axis=1)[:, :nprobe]
+                    uniq_rows += int(sizes[np.unique(pr)].sum())
+                uniq_rows /= nb_s
+                ib = row_bytes * uniq_rows + 4 * info["avg_candidates"] * BATCH   # per batch
+                # kernel time per batch: every launch of the prof window (warm-up + R regions), divided by the batches
+                # they held -- launches of different sizes are never averaged as if they were equal
+                ks_batch = (okern_ms * 1e-3) / n_batches_prof if okern_n else 0.0
+                ach = ib / ks_batch / 1e9 if ks_batch > 0 else None
+                itraffic = None
+                ipath = os.path.join(ROOT, "profiles", "traffic_ivf_list_scan.json")
+                if os.path.exists(ipath) and n_rows == N_BASE and i8_rows and nprobe == NPROBE:
+                    itraffic = json.load(open(ipath)).get("hbm_bytes_per_launch_32_batches")
+                    itraffic = int(itraffic * S / 32) if itraffic else None
+                frac = round(ach / HBM_PEAK_GBS, 4) if ach else None
+                info["roofline"] = {"bound": "hbm", "achieved": round(ach, 1) if ach else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                    "frac": frac if (frac is not None and frac <= 1.0) else None, "traffic": itraffic,
+                                    "kernel": "vs::ivf_unit_scan_kernel", "kernel_us_per_batch": round(ks_batch * 1e6, 2),
+                                    "kernel_us": round(ks_batch * S * 1e6, 2), "batches_per_launch": S,
                                     "algorithmic_bytes_per_launch": int(ib * S), "row_bytes": row_bytes,
                                     "distinct_rows_per_batch": int(uniq_rows),
-                                    "per_query_pass_bytes": int((4 * DIM + 8) * avg_cand * BATCH)}
-        log(f"IVF: {ivf_qps:.0f} QPS, recall@1={rec1}, recall@5={rec5}, avg candidates={avg_cand}")
+                                    "per_query_pass_bytes": int((4 * DIM + 8) * info["avg_candidates"] * BATCH),
+                                    "note": "list-major scan on the exact int8 copy: the 132 MB of rows stay in the 256 MB "
+                                            "Infinity Cache across batches, so delivery (L2 / Infinity Cache -> CU) binds, not "
+                                            "HBM; fraction quoted against the HBM peak as the reference roof" if i8_rows else
+                                            "fp32 rows streamed from HBM"}
+            log(f"IVF nprobe={nprobe}: {info['value']:.0f} QPS, recall@1={info.get('recall_at_1')}, "
+                f"recall@5={info.get('recall_at_5')}, avg candidates={info.get('avg_candidates')}")
+            return info
+
+        ivf_info = ivf_leg(NPROBE)
+        if not args.no_extras:
+            ivf8_info = ivf_leg(8)
+        if world == 1 and not args.no_extras:
+            tm = pkg.Timing()
+            ivf.searchBatch(queries, n_queries, K, NPROBE)
+            th = []
+            for _ in range(R):
+                t = time.perf_counter()
+                ivf.searchBatch(queries, n_queries, K, NPROBE, tm)
+                th.append(time.perf_counter() - t)
+            host_info["ivf"] = {"metric": "QPS of vs_ivf_search on host buffers, nprobe=32", "value": round(n_queries / median(th), 1),
+                                "queries_per_call": n_queries, "vs_device_api": round(n_queries / median(th) / ivf_info["value"], 4),
+                                "stage_ms": {"centroid_search": round(tm.centroid_search_ms, 3), "gather": round(tm.gather_ms, 3),
+                                             "fine_search": round(tm.fine_search_ms, 3)}}
+            log(f"host API IVF: {host_info['ivf']['value']:.0f} QPS")
         ivf.close()
 
     # ---------------------------------------------------------------- CPU baseline (rank 0, N = 1)
@@ -414,19 +524,27 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"SIFT-1M-shaped synthetic {n_rows}x{DIM} fp32 base, brute force, batch={BATCH}, k={K}",
                        "parallelism": f"row-shard x{world}" if world > 1 else "single GPU",
-                       "collective_every_steps": S if world > 1 else None},
+                       "collective_every_steps": S if world > 1 else None, "collective": coll_kind},
+            "repeats": R,
+            "ms_per_step_regions": [round(e / steps * 1e3, 5) for e in regions],
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "vs::scan_kernel<2,8,0>", "kernel_us": round(kern_avg_s * 1e6, 2),
+                         "kernel": "vs::scan_kernel<2,8,0,0>", "kernel_us": round(kern_avg_s * 1e6, 2),
+                         "kernel_us_per_batch": round(kern_per_batch_s * 1e6, 2),
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "batches_per_launch": S,
-                         "mfma_tflops": round(2.0 * BATCH * rows_local * DIM * S / max(kern_avg_s, 1e-12) / 1e12, 2)},
+                         "mfma_tflops": round(2.0 * BATCH * rows_local * DIM / max(kern_per_batch_s, 1e-12) / 1e12, 2)},
             "cpu_baseline": cpu_info,
             "ivf": ivf_info,
+            "ivf_nprobe8": ivf8_info,
             "bf_int8": int8_info,
+            "host_api": host_info,
         }
+        line.update(b1_info)
         print(json.dumps(line), flush=True)
     bf.close()
+    if comm is not None:
+        comm.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

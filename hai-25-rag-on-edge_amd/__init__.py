@@ -53,6 +53,11 @@ class Timing(C.Structure):
     ]
 
 
+def hip_runtime_dir() -> str:
+    """Directory of the ROCm HIP runtime the stand-alone CLIs load (tests run them as child processes)."""
+    return os.environ.get("ROCM_PATH", "/opt/rocm") + "/lib"
+
+
 def build(verbose: bool = False, targets=("lib",)) -> str:
     """Compile csrc/ for gfx950 with hipcc (cross-compiles without a GPU)."""
     cmd = ["make", "-C", CSRC, *targets]
@@ -125,6 +130,7 @@ def lib():
         "vs_topk_merge_dev": (i32, [vp, vp, i32, i32, i32, i64, i32, vp, vp, vp, vp]),
         "vs_prof_enable": (i32, [vp, i32]),
         "vs_prof_read": (i32, [vp, i32, C.POINTER(C.c_double), C.POINTER(i64)]),
+        "vs_prof_read_launches": (i32, [vp, i32, vp, i64, C.POINTER(i64)]),
         "vs_index_rows": (i64, [vp]),
         "vs_index_dim": (i32, [vp]),
         "vs_index_nlist": (i32, [vp]),

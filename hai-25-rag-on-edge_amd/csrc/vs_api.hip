@@ -38,6 +38,8 @@ constexpr int kMaxNprobe = 256;
 constexpr int kSlotWords = 32 * vs::kIvfSlots;  // per-batch slot minima of the IVF list scan (in the zeroed block)
 constexpr int kMaxLanes = 4;
 constexpr int kMaxMulti = 32;  // batches per persistent scan launch
+constexpr int kTieDense = 4096;   // rows whose distances the tie resolver takes densely
+constexpr int kTieCap = 8192;     // candidate slots per flagged query (more: full-row fallback)
 
 struct ProfSlot {
     std::vector<hipEvent_t> ev;  // pairs
@@ -159,7 +161,34 @@ struct vs_index {
     long long cand_stride = 0;
     int max_grid = 0;
 
+    // host-buffer API (vs_bf_search / vs_ivf_search): two slots of pinned staging + device I/O buffers, so that chunk
+    // c + 1's query upload and chunk c - 1's result download run beside chunk c's kernels (copy streams + events)
+    struct PipeSlot {
+        float* pin_q = nullptr;    // [kMaxMulti * 32][128]
+        char* pin_out = nullptr;   // dists | ids | flags of one chunk
+        float* d_q = nullptr;
+        float* d_out_d = nullptr;  // [kMaxMulti * 32][64]
+        int32_t* d_out_i = nullptr;
+        int32_t* d_flags = nullptr;
+        hipEvent_t ev_h2d = nullptr, ev_comp = nullptr, ev_d2h = nullptr;
+        int64_t q0 = -1, n = 0;    // the chunk in flight in this slot (q0 < 0: free)
+    } pipe[2];
+    hipStream_t s_h2d = nullptr, s_d2h = nullptr;
+    // tie resolver (flagged queries of vs_bf_search): distances to the first kTieDense rows, bound, filtered candidates
+    float* d_tie_dense = nullptr;  // [32][kTieDense]
+    float* d_tie_tau = nullptr;    // [32]
+    int32_t* d_tie_cnt = nullptr;  // [32]
+    int32_t* d_tie_row = nullptr;  // [32][kTieCap]
+    float* d_tie_d = nullptr;      // [32][kTieCap]
+
+    // SearchTiming split of vs_ivf_search (IVFIndex.h:31-36): HIP events between the stages of every launch group
+    std::vector<hipEvent_t> stage_ev;  // quadruples: start, after coarse + pick, after grouping, after scan + select
+    int stage_used = 0;
+    bool stage_on = false;
+    double stage_ms[3] = {0, 0, 0};
+
     hipStream_t stream = nullptr;
+    hipEvent_t ev_busy = nullptr;  // recorded after every enqueue on a caller stream: the next call waits on it
     bool prof = false;
     ProfSlot prof_slot[2];
 };
@@ -215,6 +244,26 @@ void free_all(vs_index* h) {
     }
     for (auto& ps : h->prof_slot)
         for (auto e : ps.ev) (void)hipEventDestroy(e);
+    for (auto e : h->stage_ev) (void)hipEventDestroy(e);
+    for (int i = 0; i < 2; ++i) {
+        vs_index::PipeSlot& S = h->pipe[i];
+        if (S.pin_q) (void)hipHostFree(S.pin_q);
+        if (S.pin_out) (void)hipHostFree(S.pin_out);
+        if (i > 0) {  // slot 0 aliases d_q / d_out_* / d_flags, freed above
+            void* dp[] = {S.d_q, S.d_out_d, S.d_out_i, S.d_flags};
+            for (void* q : dp)
+                if (q) (void)hipFree(q);
+        }
+        hipEvent_t evs[] = {S.ev_h2d, S.ev_comp, S.ev_d2h};
+        for (hipEvent_t e : evs)
+            if (e) (void)hipEventDestroy(e);
+    }
+    void* tie[] = {h->d_tie_dense, h->d_tie_tau, h->d_tie_cnt, h->d_tie_row, h->d_tie_d};
+    for (void* q : tie)
+        if (q) (void)hipFree(q);
+    if (h->s_h2d) (void)hipStreamDestroy(h->s_h2d);
+    if (h->s_d2h) (void)hipStreamDestroy(h->s_d2h);
+    if (h->ev_busy) (void)hipEventDestroy(h->ev_busy);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -412,6 +461,25 @@ void prof_end(vs_index* h, int which, hipStream_t s) {
     if ((int)ps.ev.size() < ps.used + 2) return;
     (void)hipEventRecord(ps.ev[ps.used + 1], s);
     ps.used += 2;
+}
+
+// stage mark i (0..3) of the current launch group (vs_ivf_search only)
+void stage_mark(vs_index* h, int i, hipStream_t s) {
+    if (!h->stage_on) return;
+    if (i == 0 && h->stage_used + 4 > kMaxEvents) {
+        h->stage_on = false;
+        return;
+    }
+    while ((int)h->stage_ev.size() < h->stage_used + 4) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) {
+            h->stage_on = false;
+            return;
+        }
+        h->stage_ev.push_back(e);
+    }
+    (void)hipEventRecord(h->stage_ev[h->stage_used + i], s);
+    if (i == 3) h->stage_used += 4;
 }
 
 // tuning knob (VSEARCH_XCHG_IT): loop iteration of the first threshold-exchange attempt
@@ -621,15 +689,20 @@ int ivf_batch_dev(vs_index* h, const float* q_dev, int B, int k, int nprobe, flo
             grp.units = h->d_units;
         }
     }
+    stage_mark(h, 0, s);
     if (h->nlist <= 2048) {
-        // coarse scores + deterministic top-nprobe (+ grouping tables) in one launch (IVFIndex.cpp:654-666, :697-723)
+        // coarse scores + deterministic top-nprobe (IVFIndex.cpp:654-666, :697-723), then the grouping tables
         HIPCHK(vs::launch_ivf_coarse_pick(q_dev, B, h->d_centroids, h->d_cnorm, h->nlist, nprobe, h->metric, h->d_probes, grp, s));
+        stage_mark(h, 1, s);
+        HIPCHK(vs::launch_ivf_group_plan(h->d_probes, B, h->nlist, nprobe, grp, s));
     } else {
         // large nlist: Q x C^T + ||c||^2 epilogue on the MFMA scan kernel, then a selection launch
         int rc = scores_dev(h, h->d_centroids, h->d_cnorm, h->nlist, q_dev, B, h->d_scores, ld, s);
         if (rc) return rc;
         HIPCHK(vs::launch_pick_probes(h->d_scores, ld, B, h->nlist, nprobe, h->d_probes, s));
+        stage_mark(h, 1, s);
     }
+    stage_mark(h, 2, s);
     if (grouped) {
         vs::IvfListScanParams lp{};
         lp.vecs = h->d_vecs;
@@ -672,6 +745,7 @@ int ivf_batch_dev(vs_index* h, const float* q_dev, int B, int k, int nprobe, flo
         sp.out_d = out_d;
         sp.out_i = out_i;
         HIPCHK(vs::launch_ivf_select(sp, B, s));
+        stage_mark(h, 3, s);
         return VS_OK;
     }
     vs::IvfScanParams ip{};
@@ -702,6 +776,7 @@ int ivf_batch_dev(vs_index* h, const float* q_dev, int B, int k, int nprobe, flo
     m.out_i = out_i;
     m.id_map = h->d_r2o;
     HIPCHK(vs::launch_merge_layout(m, kcap, (int64_t)nprobe * kcap, s));
+    stage_mark(h, 3, s);
     return VS_OK;
 }
 
@@ -718,6 +793,10 @@ int g_ivf_multi = [] {
     const char* e = getenv("VSEARCH_IVF_MULTI");
     return e ? atoi(e) : 1;
 }();
+
+bool ivf_multi_ok(const vs_index* h, int k) {
+    return g_ivf_multi && g_ivf_grouped && g_ivf_plan && h->nlist <= 2048 && h->n_chunks > 0 && h->d_units && pick_kcap(k);
+}
 
 int ensure_ivf_mb(vs_index* h, int nprobe, hipStream_t s) {
     const long long need = std::min<long long>(h->n_rows, (long long)nprobe * h->max_list);
@@ -777,7 +856,11 @@ int ivf_group_dev(vs_index* h, const float* q_dev, int nb, int B, int k, int npr
     grp.n_units = z + h->nlist + 96 + 512 + 1;
     grp.units = reinterpret_cast<int32_t*>(sl + h->mb_off_units);
     grp.mb = mb;
+    stage_mark(h, 0, s);
     HIPCHK(vs::launch_ivf_coarse_pick(q_dev, B, h->d_centroids, h->d_cnorm, h->nlist, nprobe, h->metric, probes, grp, s, nb));
+    stage_mark(h, 1, s);
+    HIPCHK(vs::launch_ivf_group_plan(probes, B, h->nlist, nprobe, grp, s, nb));
+    stage_mark(h, 2, s);
     vs::IvfListScanParams lp{};
     lp.vecs = h->d_vecs;
     lp.vnorm = h->d_norm;
@@ -827,6 +910,199 @@ int ivf_group_dev(vs_index* h, const float* q_dev, int nb, int B, int k, int npr
     sp.out_i = out_i;
     sp.mb = mb;
     HIPCHK(vs::launch_ivf_select(sp, B, s, nb));
+    stage_mark(h, 3, s);
+    return VS_OK;
+}
+
+
+// no C++ exception leaves the C ABI (vs_status instead)
+template <class F>
+int guarded(F&& f) {
+    try {
+        return f();
+    } catch (const std::bad_alloc&) {
+        set_error("out of host memory");
+        return VS_ERR_NOMEM;
+    } catch (const std::exception& e) {
+        set_error(std::string("internal error: ") + e.what());
+        return VS_ERR_INVALID;
+    }
+}
+
+// Calls on one index may arrive on different caller streams, but its scratch is one set: every enqueue waits for the
+// previous call's work (an event), so that two calls never overlap on the device.
+int order_begin(vs_index* h, hipStream_t s) {
+    if (!h->ev_busy) {
+        HIPCHK(hipEventCreateWithFlags(&h->ev_busy, hipEventDisableTiming));
+        return VS_OK;  // nothing enqueued yet
+    }
+    HIPCHK(hipStreamWaitEvent(s, h->ev_busy, 0));
+    return VS_OK;
+}
+int order_end(vs_index* h, hipStream_t s) {
+    HIPCHK(hipEventRecord(h->ev_busy, s));
+    return VS_OK;
+}
+
+int ensure_pipe(vs_index* h) {
+    if (h->pipe[0].pin_q) return VS_OK;
+    const size_t nqc = (size_t)kMaxMulti * 32;
+    for (int i = 0; i < 2; ++i) {
+        vs_index::PipeSlot& S = h->pipe[i];
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&S.pin_q), nqc * vs::kDim * sizeof(float), hipHostMallocDefault));
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&S.pin_out), nqc * (64 * 2 + 1) * sizeof(float), hipHostMallocDefault));
+        if (i == 0) {
+            S.d_q = h->d_q;
+            S.d_out_d = h->d_out_d;
+            S.d_out_i = h->d_out_i;
+            S.d_flags = h->d_flags;
+        } else {
+            int rc;
+            if ((rc = dev_alloc(&S.d_q, nqc * vs::kDim))) return rc;
+            if ((rc = dev_alloc(&S.d_out_d, nqc * 64))) return rc;
+            if ((rc = dev_alloc(&S.d_out_i, nqc * 64))) return rc;
+            if ((rc = dev_alloc(&S.d_flags, nqc))) return rc;
+        }
+        HIPCHK(hipEventCreateWithFlags(&S.ev_h2d, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&S.ev_comp, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&S.ev_d2h, hipEventDisableTiming));
+    }
+    HIPCHK(hipStreamCreateWithFlags(&h->s_h2d, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&h->s_d2h, hipStreamNonBlocking));
+    return VS_OK;
+}
+
+// Full-row fallback of the tie resolver: the whole distance row of one query (already in h->d_q at row `b`) -> host replay.
+int resolve_dense_full(vs_index* h, const float* q_dev, int B, const std::vector<int>& which, const int64_t* qidx, int k,
+                       int32_t* ids, float* dists) {
+    const int64_t ld = (h->n_rows + 15) & ~int64_t(15);
+    if (h->scores_cap < (int64_t)B * ld) {
+        if (h->d_scores) (void)hipFree(h->d_scores);
+        h->d_scores = nullptr;
+        h->scores_cap = 0;
+        int rc = dev_alloc(&h->d_scores, (size_t)32 * ld);
+        if (rc) return rc;
+        h->scores_cap = (int64_t)32 * ld;
+    }
+    int rc = scores_dev(h, h->d_vecs, h->d_norm, h->n_rows, q_dev, B, h->d_scores, ld, h->stream);
+    if (rc) return rc;
+    std::vector<float> row((size_t)ld);
+    for (int b : which) {
+        HIPCHK(hipMemcpyAsync(row.data(), h->d_scores + (size_t)b * ld, (size_t)h->n_rows * sizeof(float), hipMemcpyDeviceToHost,
+                              h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        vs::select_topk_slots_dense(row.data(), h->n_rows, k, (int32_t)h->id_offset, ids + qidx[b] * k, dists + qidx[b] * k);
+    }
+    return VS_OK;
+}
+
+// Exact select_topk (cpu_baseline.cpp:127-153) for queries whose k+1 best distances contain a tie.  The slot replay
+// only depends on rows that change the k-slot buffer, i.e. rows whose distance is below the buffer maximum when they
+// arrive -- and that maximum never rises.  So: the first kTieDense rows are taken densely (their distance rows), the
+// k-th smallest of them bounds the buffer maximum for every later row, and ONE filtered pass over the rest of the base
+// emits the few rows under that bound (about N * k / kTieDense of them).  The host replays the slots over
+// "dense rows, then candidates in row order".  Exact whenever the distances are (integer-valued SIFT: always).
+int resolve_ties(vs_index* h, const float* queries_host, const std::vector<int64_t>& flagged, int k, int32_t* ids, float* dists) {
+    int rc;
+    const int64_t L0 = std::min<int64_t>(h->n_rows, kTieDense);
+    const int64_t L0p = (L0 + 15) & ~int64_t(15);
+    if (!h->d_tie_dense) {
+        if ((rc = dev_alloc(&h->d_tie_dense, (size_t)32 * kTieDense))) return rc;
+        if ((rc = dev_alloc(&h->d_tie_tau, 32))) return rc;
+        if ((rc = dev_alloc(&h->d_tie_cnt, 32))) return rc;
+        if ((rc = dev_alloc(&h->d_tie_row, (size_t)32 * kTieCap))) return rc;
+        if ((rc = dev_alloc(&h->d_tie_d, (size_t)32 * kTieCap))) return rc;
+    }
+    const int group = 32;
+    std::vector<float> qbuf((size_t)group * vs::kDim), dense((size_t)group * L0p), cd;
+    std::vector<int32_t> cr, order;
+    std::vector<int32_t> srow;
+    std::vector<float> sdist;
+    int32_t cnt[32];
+    for (size_t f0 = 0; f0 < flagged.size(); f0 += group) {
+        const int B = (int)std::min<size_t>(group, flagged.size() - f0);
+        for (int b = 0; b < B; ++b)
+            std::memcpy(&qbuf[(size_t)b * vs::kDim], queries_host + flagged[f0 + b] * vs::kDim, vs::kDim * sizeof(float));
+        HIPCHK(hipMemcpyAsync(h->d_q, qbuf.data(), (size_t)B * vs::kDim * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        if ((rc = scores_dev(h, h->d_vecs, h->d_norm, L0, h->d_q, B, h->d_tie_dense, L0p, h->stream))) return rc;
+        const bool sparse = h->n_rows > L0;
+        if (sparse) {
+            // bound = next_up(k-th smallest of the dense rows): merge kernel over G = L0 one-entry lists
+            HIPCHK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->d_tie_tau), 0xff800000u, 32, h->stream));  // -inf: padding queries emit nothing
+            HIPCHK(hipMemsetAsync(h->d_tie_cnt, 0, 32 * sizeof(int32_t), h->stream));
+            vs::MergeParams m{};
+            m.part_d = h->d_tie_dense;
+            m.G = (int)L0;
+            m.kin = 1;
+            m.nq = B;
+            m.kout = k;
+            m.tau_out = h->d_tie_tau;
+            HIPCHK(vs::launch_merge_layout(m, 1, L0p, h->stream));
+            vs::ScanParams p{};
+            p.base = h->d_vecs;
+            p.bnorm = h->d_norm;
+            p.q = h->d_q;
+            p.n_batches = 1;
+            p.metric = h->metric;
+            p.nq_valid = B;
+            p.k1 = k + 1;
+            p.tau0 = h->d_tie_tau;
+            p.row_begin = L0;  // multiple of 16 (kTieDense)
+            p.row_end = h->n_rows;
+            p.f_cnt = h->d_tie_cnt;
+            p.f_row = h->d_tie_row;
+            p.f_d = h->d_tie_d;
+            p.f_cap = kTieCap;
+            int grid, tp;
+            scan_geometry(h->n_rows - L0, h->num_cus, grid, tp);
+            p.tiles_per_wg = tp;
+            HIPCHK(vs::launch_scan(p, grid, 8, 2, vs::kModeFilter, h->stream));
+            HIPCHK(hipMemcpyAsync(cnt, h->d_tie_cnt, sizeof(cnt), hipMemcpyDeviceToHost, h->stream));
+        }
+        HIPCHK(hipMemcpyAsync(dense.data(), h->d_tie_dense, (size_t)B * L0p * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        int mx = 0;
+        std::vector<int> overflow;
+        if (sparse) {
+            for (int b = 0; b < B; ++b) {
+                if (cnt[b] > kTieCap) overflow.push_back(b);
+                else mx = std::max(mx, cnt[b]);
+            }
+            if (mx > 0) {
+                cr.resize((size_t)B * mx);
+                cd.resize((size_t)B * mx);
+                HIPCHK(hipMemcpy2DAsync(cr.data(), (size_t)mx * 4, h->d_tie_row, (size_t)kTieCap * 4, (size_t)mx * 4, B,
+                                        hipMemcpyDeviceToHost, h->stream));
+                HIPCHK(hipMemcpy2DAsync(cd.data(), (size_t)mx * 4, h->d_tie_d, (size_t)kTieCap * 4, (size_t)mx * 4, B,
+                                        hipMemcpyDeviceToHost, h->stream));
+                HIPCHK(hipStreamSynchronize(h->stream));
+            }
+        }
+        for (int b = 0; b < B; ++b) {
+            const int m = sparse ? cnt[b] : 0;
+            if (m > kTieCap) continue;  // full-row fallback below
+            srow.resize((size_t)L0 + m);
+            sdist.resize((size_t)L0 + m);
+            for (int64_t j = 0; j < L0; ++j) {
+                srow[(size_t)j] = (int32_t)(j + h->id_offset);
+                sdist[(size_t)j] = dense[(size_t)b * L0p + j];
+            }
+            order.resize((size_t)m);
+            std::iota(order.begin(), order.end(), 0);
+            const int32_t* rr = m ? &cr[(size_t)b * mx] : nullptr;
+            const float* dd = m ? &cd[(size_t)b * mx] : nullptr;
+            std::sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return rr[x] < rr[y]; });
+            for (int j = 0; j < m; ++j) {
+                srow[(size_t)L0 + j] = rr[order[(size_t)j]] + (int32_t)h->id_offset;
+                sdist[(size_t)L0 + j] = dd[order[(size_t)j]];
+            }
+            const int64_t qi = flagged[f0 + b];
+            vs::select_topk_slots_sparse(srow.data(), sdist.data(), (int64_t)srow.size(), k, ids + qi * k, dists + qi * k);
+        }
+        if (!overflow.empty()) {  // massive ties / duplicates: more rows under the bound than the candidate buffer holds
+            if ((rc = resolve_dense_full(h, h->d_q, B, overflow, &flagged[f0], k, ids, dists))) return rc;
+        }
+    }
     return VS_OK;
 }
 
@@ -878,6 +1154,23 @@ int vs_prof_read(vs_index* h, int which, double* total_ms, int64_t* launches) {
     }
     if (total_ms) *total_ms = tot;
     if (launches) *launches = ps.used / 2;
+    return VS_OK;
+}
+
+int vs_prof_read_launches(vs_index* h, int which, double* ms_out, int64_t cap, int64_t* launches) {
+    if (!h || which < 0 || which > 1 || (cap > 0 && !ms_out)) return VS_ERR_INVALID;
+    int rc = set_device(h);
+    if (rc) return rc;
+    ProfSlot& ps = h->prof_slot[which];
+    int64_t n = 0;
+    for (int i = 0; i + 1 < ps.used; i += 2, ++n) {
+        if (n >= cap) continue;
+        HIPCHK(hipEventSynchronize(ps.ev[i + 1]));
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, ps.ev[i], ps.ev[i + 1]));
+        ms_out[n] = ms;
+    }
+    if (launches) *launches = n;
     return VS_OK;
 }
 
@@ -943,8 +1236,10 @@ int vs_bf_search_dev(vs_index* h, const float* queries_dev, int B, int k, int32_
     }
     int rc = set_device(h);
     if (rc) return rc;
-    return bf_batch_dev(h, h->lane[0], queries_dev, B, k + 1, dists_dev, ids_dev, flags_dev ? flags_dev : h->d_flags,
-                        static_cast<hipStream_t>(stream));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if ((rc = order_begin(h, st))) return rc;
+    rc = bf_batch_dev(h, h->lane[0], queries_dev, B, k + 1, dists_dev, ids_dev, flags_dev ? flags_dev : h->d_flags, st);
+    return rc ? rc : order_end(h, st);
 }
 
 int vs_bf_search_dev_multi(vs_index* h, const float* queries_dev, int n_batches, int B, int k, int32_t* ids_dev,
@@ -959,7 +1254,10 @@ int vs_bf_search_dev_multi(vs_index* h, const float* queries_dev, int n_batches,
         set_error("k too large for the compiled scan kernels (k <= 15)");
         return VS_ERR_UNSUPPORTED;
     }
-    return bf_multi_dev(h, queries_dev, n_batches, B, k + 1, dists_dev, ids_dev, flags_dev, static_cast<hipStream_t>(stream));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if ((rc = order_begin(h, st))) return rc;
+    rc = bf_multi_dev(h, queries_dev, n_batches, B, k + 1, dists_dev, ids_dev, flags_dev, st);
+    return rc ? rc : order_end(h, st);
 }
 
 int vs_bf_scores_dev(vs_index* h, const float* queries_dev, int B, float* scores_dev_, int64_t ld, void* stream) {
@@ -969,7 +1267,10 @@ int vs_bf_scores_dev(vs_index* h, const float* queries_dev, int B, float* scores
     }
     int rc = set_device(h);
     if (rc) return rc;
-    return scores_dev(h, h->d_vecs, h->d_norm, h->n_rows, queries_dev, B, scores_dev_, ld, static_cast<hipStream_t>(stream));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if ((rc = order_begin(h, st))) return rc;
+    rc = scores_dev(h, h->d_vecs, h->d_norm, h->n_rows, queries_dev, B, scores_dev_, ld, st);
+    return rc ? rc : order_end(h, st);
 }
 
 int vs_bf_search(vs_index* h, const float* queries_host, int64_t nq, int k, int32_t* ids, float* dists,
@@ -978,111 +1279,111 @@ int vs_bf_search(vs_index* h, const float* queries_host, int64_t nq, int k, int3
         set_error("vs_bf_search: bad arguments");
         return VS_ERR_INVALID;
     }
-    int rc = set_device(h);
-    if (rc) return rc;
-    const double t_start = now_ms();
-    vs_timing tm{};
-    const int k1 = k + 1;
-    if (!pick_kcap(k1)) {
-        set_error("k too large for the compiled scan kernels (k <= 15)");
-        return VS_ERR_UNSUPPORTED;
-    }
-    // Queries go up in chunks of kMaxMulti batches: one persistent scan launch + one merge launch per
-    // chunk (the harness loop of main.cpp:201-251 collapsed into a call); a ragged tail batch gets its own.
-    const int64_t chunk = (int64_t)kMaxMulti * h->batch;
-    std::vector<float> hd((size_t)chunk * k1);
-    std::vector<int32_t> hi((size_t)chunk * k1), hf((size_t)chunk);
-    std::vector<int64_t> flagged;
-    const float inf = std::numeric_limits<float>::infinity();
-    for (int64_t q0 = 0; q0 < nq; q0 += chunk) {
-        const int64_t n = std::min<int64_t>(chunk, nq - q0);
-        const int full = (int)(n / h->batch), rem = (int)(n % h->batch);
-        double t0 = now_ms();
-        HIPCHK(hipMemcpyAsync(h->d_q, queries_host + q0 * vs::kDim, (size_t)n * vs::kDim * sizeof(float),
-                              hipMemcpyHostToDevice, h->stream));
-        double t1 = now_ms();
-        if (full) {
-            rc = bf_launch(h, h->lane[0], h->d_q, full, h->batch, k1, h->d_out_d, h->d_out_i, h->d_flags, h->stream);
-            if (rc) return rc;
+    return guarded([&]() -> int {
+        int rc = set_device(h);
+        if (rc) return rc;
+        const double t_start = now_ms();
+        vs_timing tm{};
+        const int k1 = k + 1;
+        if (!pick_kcap(k1)) {
+            set_error("k too large for the compiled scan kernels (k <= 15)");
+            return VS_ERR_UNSUPPORTED;
         }
-        if (rem) {
-            const size_t o = (size_t)full * h->batch;
-            rc = bf_launch(h, h->lane[0], h->d_q + o * vs::kDim, 1, rem, k1, h->d_out_d + o * k1, h->d_out_i + o * k1,
-                           h->d_flags + o, h->stream);
-            if (rc) return rc;
-        }
-        HIPCHK(hipMemcpyAsync(hd.data(), h->d_out_d, (size_t)n * k1 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipMemcpyAsync(hi.data(), h->d_out_i, (size_t)n * k1 * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipMemcpyAsync(hf.data(), h->d_flags, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
-        bool rerun = false;
-        for (int64_t b = 0; b < n; ++b) rerun = rerun || hf[(size_t)b] == 2;
-        if (rerun) {
-            // a query of this chunk is not an integer in [0, 255]: the int8 scan skipped its batch -> fp32 path
-            if (full) {
-                rc = bf_launch(h, h->lane[0], h->d_q, full, h->batch, k1, h->d_out_d, h->d_out_i, h->d_flags, h->stream, true);
-                if (rc) return rc;
-            }
-            if (rem) {
+        if ((rc = ensure_pipe(h)) || (rc = order_begin(h, h->stream))) return rc;
+        // Queries go through in chunks of kMaxMulti batches: one persistent scan launch + one merge launch per chunk
+        // (the harness loop of main.cpp:201-251 collapsed into a call; a ragged tail batch gets its own launch).  Two
+        // chunks are in flight: uploads and downloads run on copy streams beside the other chunk's kernels.
+        const int64_t chunk = (int64_t)kMaxMulti * h->batch;
+        std::vector<int64_t> flagged;
+        const float inf = std::numeric_limits<float>::infinity();
+        auto launch_chunk = [&](vs_index::PipeSlot& S, bool force_f32) -> int {
+            const int full = (int)(S.n / h->batch), rem = (int)(S.n % h->batch);
+            int r2 = VS_OK;
+            if (full) r2 = bf_launch(h, h->lane[0], S.d_q, full, h->batch, k1, S.d_out_d, S.d_out_i, S.d_flags, h->stream, force_f32);
+            if (!r2 && rem) {
                 const size_t o = (size_t)full * h->batch;
-                rc = bf_launch(h, h->lane[0], h->d_q + o * vs::kDim, 1, rem, k1, h->d_out_d + o * k1, h->d_out_i + o * k1,
-                               h->d_flags + o, h->stream, true);
-                if (rc) return rc;
+                r2 = bf_launch(h, h->lane[0], S.d_q + o * vs::kDim, 1, rem, k1, S.d_out_d + o * k1, S.d_out_i + o * k1, S.d_flags + o,
+                               h->stream, force_f32);
             }
-            HIPCHK(hipMemcpyAsync(hd.data(), h->d_out_d, (size_t)n * k1 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-            HIPCHK(hipMemcpyAsync(hi.data(), h->d_out_i, (size_t)n * k1 * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-            HIPCHK(hipMemcpyAsync(hf.data(), h->d_flags, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-            HIPCHK(hipStreamSynchronize(h->stream));
-        }
-        double t2 = now_ms();
-        tm.h2d_ms += t1 - t0;
-        tm.fine_search_ms += t2 - t1;
-        for (int64_t b = 0; b < n; ++b) {
-            for (int t = 0; t < k; ++t) {
-                const int32_t id = hi[(size_t)b * k1 + t];
-                ids[(q0 + b) * k + t] = id;
-                float d = id >= 0 ? hd[(size_t)b * k1 + t] : inf;
-                if (h->metric == VS_METRIC_IP && id >= 0) d = -d;
-                dists[(q0 + b) * k + t] = d;
-            }
-            if (hf[(size_t)b]) flagged.push_back(q0 + b);
-        }
-    }
-    // Ties inside the k+1 best: the reference's order is history dependent (cpu_baseline.cpp:127-153),
-    // so recompute the full distance row on the GPU and replay the slot algorithm over it.
-    if (!flagged.empty() && h->metric == VS_METRIC_L2) {
-        const double t0 = now_ms();
-        const int group = 16;
-        const int64_t ld = (h->n_rows + 15) & ~int64_t(15);
-        if (h->scores_cap < (int64_t)group * ld) {
-            if (h->d_scores) (void)hipFree(h->d_scores);
-            h->d_scores = nullptr;
-            h->scores_cap = 0;
-            if ((rc = dev_alloc(&h->d_scores, (size_t)group * ld))) return rc;
-            h->scores_cap = (int64_t)group * ld;
-        }
-        std::vector<float> qbuf((size_t)group * vs::kDim), row((size_t)ld);
-        for (size_t f0 = 0; f0 < flagged.size(); f0 += group) {
-            const int B = (int)std::min<size_t>(group, flagged.size() - f0);
-            for (int b = 0; b < B; ++b)
-                std::memcpy(&qbuf[(size_t)b * vs::kDim], queries_host + flagged[f0 + b] * vs::kDim, vs::kDim * sizeof(float));
-            HIPCHK(hipMemcpyAsync(h->d_q, qbuf.data(), (size_t)B * vs::kDim * sizeof(float), hipMemcpyHostToDevice, h->stream));
-            rc = scores_dev(h, h->d_vecs, h->d_norm, h->n_rows, h->d_q, B, h->d_scores, ld, h->stream);
-            if (rc) return rc;
-            for (int b = 0; b < B; ++b) {
-                HIPCHK(hipMemcpyAsync(row.data(), h->d_scores + (size_t)b * ld, (size_t)h->n_rows * sizeof(float),
-                                      hipMemcpyDeviceToHost, h->stream));
+            return r2;
+        };
+        auto download = [&](vs_index::PipeSlot& S, hipStream_t st) -> int {
+            float* hd = reinterpret_cast<float*>(S.pin_out);
+            int32_t* hi = reinterpret_cast<int32_t*>(S.pin_out) + (size_t)chunk * k1;
+            int32_t* hf = hi + (size_t)chunk * k1;
+            HIPCHK(hipMemcpyAsync(hd, S.d_out_d, (size_t)S.n * k1 * sizeof(float), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipMemcpyAsync(hi, S.d_out_i, (size_t)S.n * k1 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipMemcpyAsync(hf, S.d_flags, (size_t)S.n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            return VS_OK;
+        };
+        auto enqueue = [&](vs_index::PipeSlot& S, int64_t q0, int64_t n) -> int {
+            const double t0 = now_ms();
+            S.q0 = q0;
+            S.n = n;
+            std::memcpy(S.pin_q, queries_host + q0 * vs::kDim, (size_t)n * vs::kDim * sizeof(float));
+            HIPCHK(hipMemcpyAsync(S.d_q, S.pin_q, (size_t)n * vs::kDim * sizeof(float), hipMemcpyHostToDevice, h->s_h2d));
+            HIPCHK(hipEventRecord(S.ev_h2d, h->s_h2d));
+            tm.h2d_ms += now_ms() - t0;
+            HIPCHK(hipStreamWaitEvent(h->stream, S.ev_h2d, 0));
+            int r2 = launch_chunk(S, false);
+            if (r2) return r2;
+            HIPCHK(hipEventRecord(S.ev_comp, h->stream));
+            HIPCHK(hipStreamWaitEvent(h->s_d2h, S.ev_comp, 0));
+            if ((r2 = download(S, h->s_d2h))) return r2;
+            HIPCHK(hipEventRecord(S.ev_d2h, h->s_d2h));
+            return VS_OK;
+        };
+        auto retire = [&](vs_index::PipeSlot& S) -> int {
+            if (S.q0 < 0) return VS_OK;
+            const double t0 = now_ms();
+            HIPCHK(hipEventSynchronize(S.ev_d2h));
+            const float* hd = reinterpret_cast<const float*>(S.pin_out);
+            const int32_t* hi = reinterpret_cast<const int32_t*>(S.pin_out) + (size_t)chunk * k1;
+            const int32_t* hf = hi + (size_t)chunk * k1;
+            bool rerun = false;
+            for (int64_t b = 0; b < S.n; ++b) rerun = rerun || hf[(size_t)b] == 2;
+            if (rerun) {
+                // a query of this chunk is not an integer in [0, 255]: the int8 scan skipped its batch -> fp32 path
+                int r2 = launch_chunk(S, true);
+                if (r2) return r2;
+                if ((r2 = download(S, h->stream))) return r2;
                 HIPCHK(hipStreamSynchronize(h->stream));
-                const int64_t qi = flagged[f0 + b];
-                vs::select_topk_slots_dense(row.data(), h->n_rows, k, (int32_t)h->id_offset, ids + qi * k, dists + qi * k);
             }
+            tm.d2h_ms += now_ms() - t0;
+            for (int64_t b = 0; b < S.n; ++b) {
+                for (int t = 0; t < k; ++t) {
+                    const int32_t id = hi[(size_t)b * k1 + t];
+                    ids[(S.q0 + b) * k + t] = id;
+                    float d = id >= 0 ? hd[(size_t)b * k1 + t] : inf;
+                    if (h->metric == VS_METRIC_IP && id >= 0) d = -d;
+                    dists[(S.q0 + b) * k + t] = d;
+                }
+                if (hf[(size_t)b]) flagged.push_back(S.q0 + b);
+            }
+            S.q0 = -1;
+            return VS_OK;
+        };
+        int c = 0;
+        for (int64_t q0 = 0; q0 < nq; q0 += chunk, ++c) {
+            vs_index::PipeSlot& S = h->pipe[c & 1];
+            if ((rc = retire(S))) return rc;
+            if ((rc = enqueue(S, q0, std::min<int64_t>(chunk, nq - q0)))) return rc;
         }
-        tm.tie_resolve_ms = now_ms() - t0;
-        tm.tie_queries = (int64_t)flagged.size();
-    }
-    tm.total_ms = now_ms() - t_start;
-    if (timing) *timing = tm;
-    return VS_OK;
+        if ((rc = retire(h->pipe[c & 1]))) return rc;        // the older chunk first
+        if ((rc = retire(h->pipe[(c + 1) & 1]))) return rc;
+        tm.fine_search_ms = now_ms() - t_start;
+        // Ties inside the k+1 best: the reference's order is history dependent (cpu_baseline.cpp:127-153) -> replay
+        // select_topk over the rows that can change its buffer (resolve_ties).
+        if (!flagged.empty() && h->metric == VS_METRIC_L2) {
+            const double t0 = now_ms();
+            if ((rc = resolve_ties(h, queries_host, flagged, k, ids, dists))) return rc;
+            tm.tie_resolve_ms = now_ms() - t0;
+            tm.tie_queries = (int64_t)flagged.size();
+        }
+        tm.total_ms = now_ms() - t_start;
+        if (timing) *timing = tm;
+        return order_end(h, h->stream);
+    });
 }
 
 // --------------------------------------------------------------------------------------------- IVF
@@ -1500,7 +1801,10 @@ int vs_ivf_search_dev(vs_index* h, const float* queries_dev, int B, int k, int n
     }
     int rc = set_device(h);
     if (rc) return rc;
-    return ivf_batch_dev(h, queries_dev, B, k, nprobe, dists_dev, ids_dev, static_cast<hipStream_t>(stream), nullptr);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if ((rc = order_begin(h, st))) return rc;
+    rc = ivf_batch_dev(h, queries_dev, B, k, nprobe, dists_dev, ids_dev, st, nullptr);
+    return rc ? rc : order_end(h, st);
 }
 
 int vs_ivf_search_dev_multi(vs_index* h, const float* queries_dev, int n_batches, int B, int k, int nprobe, int32_t* ids_dev,
@@ -1518,20 +1822,21 @@ int vs_ivf_search_dev_multi(vs_index* h, const float* queries_dev, int n_batches
     int rc = set_device(h);
     if (rc) return rc;
     hipStream_t user = static_cast<hipStream_t>(stream);
+    if ((rc = order_begin(h, user))) return rc;
     if (n_batches == 1 || g_ivf_lanes == 1) {
         for (int b = 0; b < n_batches && !rc; ++b)
             rc = ivf_batch_dev(h, queries_dev + (size_t)b * B * vs::kDim, B, k, nprobe, dists_dev + (size_t)b * B * k,
                                ids_dev + (size_t)b * B * k, user, nullptr);
-        return rc;
+        return rc ? rc : order_end(h, user);
     }
-    if (g_ivf_multi && g_ivf_grouped && g_ivf_plan && h->nlist <= 2048 && h->n_chunks > 0 && h->d_units && pick_kcap(k)) {
+    if (ivf_multi_ok(h, k)) {
         // every kernel once per group of up to kMaxMulti batches
         for (int b0 = 0; b0 < n_batches && !rc; b0 += kMaxMulti) {
             const int nb = std::min(kMaxMulti, n_batches - b0);
             rc = ivf_group_dev(h, queries_dev + (size_t)b0 * B * vs::kDim, nb, B, k, nprobe, dists_dev + (size_t)b0 * B * k,
                                ids_dev + (size_t)b0 * B * k, user);
         }
-        return rc;
+        return rc ? rc : order_end(h, user);
     }
     if ((rc = ensure_ivf_alt(h))) return rc;
     // the batches are independent: deal them round-robin to the streams (stream l > 0 uses scratch set l - 1)
@@ -1549,7 +1854,7 @@ int vs_ivf_search_dev_multi(vs_index* h, const float* queries_dev, int n_batches
         HIPCHK(hipEventRecord(h->ivf_join[i], h->ivf_stream[i]));
         HIPCHK(hipStreamWaitEvent(user, h->ivf_join[i], 0));
     }
-    return rc;
+    return rc ? rc : order_end(h, user);
 }
 
 int vs_ivf_search(vs_index* h, const float* queries_host, int64_t nq, int k, int nprobe, int32_t* ids, float* dists,
@@ -1563,56 +1868,96 @@ int vs_ivf_search(vs_index* h, const float* queries_host, int64_t nq, int k, int
         set_error("nprobe > 256 not supported");
         return VS_ERR_UNSUPPORTED;
     }
-    int rc = set_device(h);
-    if (rc) return rc;
-    const double t_start = now_ms();
-    vs_timing tm{};
-    HIPCHK(hipMemsetAsync(h->d_cand, 0, sizeof(unsigned long long), h->stream));
-    const float inf = std::numeric_limits<float>::infinity();
-    // Queries go up in chunks of kMaxMulti batches: every kernel is launched once per chunk (the harness loop of
-    // main_ivf.cpp:150-214 collapsed into a call); a ragged tail batch gets its own launches.
-    const bool multi = g_ivf_multi && g_ivf_grouped && g_ivf_plan && h->nlist <= 2048 && h->n_chunks > 0 && h->d_units && pick_kcap(k) &&
-                       k <= 64;  // d_out_* hold kMaxMulti * 32 * 64 words
-    const int64_t chunk = (int64_t)(multi ? kMaxMulti : 1) * h->batch;
-    std::vector<float> hd((size_t)chunk * k);
-    std::vector<int32_t> hi((size_t)chunk * k);
-    for (int64_t q0 = 0; q0 < nq; q0 += chunk) {
-        const int64_t n = std::min<int64_t>(chunk, nq - q0);
-        const int full = (int)(n / h->batch), rem = (int)(n % h->batch);
-        double t0 = now_ms();
-        HIPCHK(hipMemcpyAsync(h->d_q, queries_host + q0 * vs::kDim, (size_t)n * vs::kDim * sizeof(float),
-                              hipMemcpyHostToDevice, h->stream));
-        double t1 = now_ms();
-        if (full > 1) {
-            rc = ivf_group_dev(h, h->d_q, full, h->batch, k, nprobe, h->d_out_d, h->d_out_i, h->stream);
-        } else if (full == 1) {
-            rc = ivf_batch_dev(h, h->d_q, h->batch, k, nprobe, h->d_out_d, h->d_out_i, h->stream, nullptr);
-        }
-        if (rc) return rc;
-        if (rem) {
-            const size_t o = (size_t)full * h->batch;
-            rc = ivf_batch_dev(h, h->d_q + o * vs::kDim, rem, k, nprobe, h->d_out_d + o * k, h->d_out_i + o * k, h->stream, nullptr);
-            if (rc) return rc;
-        }
-        HIPCHK(hipMemcpyAsync(hd.data(), h->d_out_d, (size_t)n * k * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipMemcpyAsync(hi.data(), h->d_out_i, (size_t)n * k * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
-        double t2 = now_ms();
-        tm.h2d_ms += t1 - t0;
-        tm.fine_search_ms += t2 - t1;
-        for (int64_t b = 0; b < n; ++b)
-            for (int t = 0; t < k; ++t) {
-                const int32_t id = hi[(size_t)b * k + t];
-                ids[(q0 + b) * k + t] = id;
-                dists[(q0 + b) * k + t] = id >= 0 ? hd[(size_t)b * k + t] : inf;
-            }
+    if (k > 64) {
+        set_error("k > 64 not supported by the host-buffer API");
+        return VS_ERR_UNSUPPORTED;
     }
-    unsigned long long cand = 0;
-    HIPCHK(hipMemcpy(&cand, h->d_cand, sizeof(cand), hipMemcpyDeviceToHost));
-    if (total_candidates) *total_candidates = (int64_t)cand;
-    tm.total_ms = now_ms() - t_start;
-    if (timing) *timing = tm;
-    return VS_OK;
+    return guarded([&]() -> int {
+        int rc = set_device(h);
+        if (rc) return rc;
+        const double t_start = now_ms();
+        vs_timing tm{};
+        if ((rc = ensure_pipe(h)) || (rc = order_begin(h, h->stream))) return rc;
+        h->stage_on = true;
+        h->stage_used = 0;
+        HIPCHK(hipMemsetAsync(h->d_cand, 0, sizeof(unsigned long long), h->stream));
+        const float inf = std::numeric_limits<float>::infinity();
+        // Queries go through in chunks of kMaxMulti batches: every kernel is launched once per chunk (the harness loop of
+        // main_ivf.cpp:150-214 collapsed into a call); a ragged tail batch gets its own launches.  Two chunks in flight,
+        // copies on their own streams (see vs_bf_search).
+        const bool multi = ivf_multi_ok(h, k);
+        const int64_t chunk = (int64_t)(multi ? kMaxMulti : 1) * h->batch;
+        auto enqueue = [&](vs_index::PipeSlot& S, int64_t q0, int64_t n) -> int {
+            const double t0 = now_ms();
+            S.q0 = q0;
+            S.n = n;
+            std::memcpy(S.pin_q, queries_host + q0 * vs::kDim, (size_t)n * vs::kDim * sizeof(float));
+            HIPCHK(hipMemcpyAsync(S.d_q, S.pin_q, (size_t)n * vs::kDim * sizeof(float), hipMemcpyHostToDevice, h->s_h2d));
+            HIPCHK(hipEventRecord(S.ev_h2d, h->s_h2d));
+            tm.h2d_ms += now_ms() - t0;
+            HIPCHK(hipStreamWaitEvent(h->stream, S.ev_h2d, 0));
+            const int full = (int)(n / h->batch), rem = (int)(n % h->batch);
+            int r2 = VS_OK;
+            if (full > 1) r2 = ivf_group_dev(h, S.d_q, full, h->batch, k, nprobe, S.d_out_d, S.d_out_i, h->stream);
+            else if (full == 1) r2 = ivf_batch_dev(h, S.d_q, h->batch, k, nprobe, S.d_out_d, S.d_out_i, h->stream, nullptr);
+            if (r2) return r2;
+            if (rem) {
+                const size_t o = (size_t)full * h->batch;
+                r2 = ivf_batch_dev(h, S.d_q + o * vs::kDim, rem, k, nprobe, S.d_out_d + o * k, S.d_out_i + o * k, h->stream, nullptr);
+                if (r2) return r2;
+            }
+            HIPCHK(hipEventRecord(S.ev_comp, h->stream));
+            HIPCHK(hipStreamWaitEvent(h->s_d2h, S.ev_comp, 0));
+            float* hd = reinterpret_cast<float*>(S.pin_out);
+            int32_t* hi = reinterpret_cast<int32_t*>(S.pin_out) + (size_t)kMaxMulti * 32 * 64;
+            HIPCHK(hipMemcpyAsync(hd, S.d_out_d, (size_t)n * k * sizeof(float), hipMemcpyDeviceToHost, h->s_d2h));
+            HIPCHK(hipMemcpyAsync(hi, S.d_out_i, (size_t)n * k * sizeof(int32_t), hipMemcpyDeviceToHost, h->s_d2h));
+            HIPCHK(hipEventRecord(S.ev_d2h, h->s_d2h));
+            return VS_OK;
+        };
+        auto retire = [&](vs_index::PipeSlot& S) -> int {
+            if (S.q0 < 0) return VS_OK;
+            const double t0 = now_ms();
+            HIPCHK(hipEventSynchronize(S.ev_d2h));
+            tm.d2h_ms += now_ms() - t0;
+            const float* hd = reinterpret_cast<const float*>(S.pin_out);
+            const int32_t* hi = reinterpret_cast<const int32_t*>(S.pin_out) + (size_t)kMaxMulti * 32 * 64;
+            for (int64_t b = 0; b < S.n; ++b)
+                for (int t = 0; t < k; ++t) {
+                    const int32_t id = hi[(size_t)b * k + t];
+                    ids[(S.q0 + b) * k + t] = id;
+                    dists[(S.q0 + b) * k + t] = id >= 0 ? hd[(size_t)b * k + t] : inf;
+                }
+            S.q0 = -1;
+            return VS_OK;
+        };
+        int c = 0;
+        for (int64_t q0 = 0; q0 < nq; q0 += chunk, ++c) {
+            vs_index::PipeSlot& S = h->pipe[c & 1];
+            if ((rc = retire(S))) return rc;
+            if ((rc = enqueue(S, q0, std::min<int64_t>(chunk, nq - q0)))) return rc;
+        }
+        if ((rc = retire(h->pipe[c & 1]))) return rc;
+        if ((rc = retire(h->pipe[(c + 1) & 1]))) return rc;
+        unsigned long long cand = 0;
+        HIPCHK(hipMemcpyAsync(&cand, h->d_cand, sizeof(cand), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (total_candidates) *total_candidates = (int64_t)cand;
+        tm.total_ms = now_ms() - t_start;
+        // SearchTiming split (IVFIndex.h:31-36): device time of the three stages from the events between their launches,
+        // summed over the call's launch groups (they run back to back on one stream; uploads and downloads overlap them)
+        for (int i = 0; i + 3 < h->stage_used; i += 4) {
+            float ms[3] = {0, 0, 0};
+            for (int j = 0; j < 3; ++j) (void)hipEventElapsedTime(&ms[j], h->stage_ev[i + j], h->stage_ev[i + j + 1]);
+            tm.centroid_search_ms += ms[0];
+            tm.gather_ms += ms[1];
+            tm.fine_search_ms += ms[2];
+        }
+        h->stage_on = false;
+        h->stage_used = 0;
+        if (timing) *timing = tm;
+        return order_end(h, h->stream);
+    });
 }
 
 __attribute__((visibility("default"))) int vs_debug_buffer(int* dev_ptr) {

@@ -13,7 +13,7 @@ constexpr int kMaxBatch = 32;      // queries per scan pass (two 16-query MFMA c
 constexpr int kScanPadRows = 64;  // every row array handed to the scan is allocated with this many spare rows (tile DMAs are not clamped)
 constexpr int kSlotStride = 256;   // threshold-exchange slots: [32 queries][256 workgroups]
 
-enum ScanMode { kModeTopK = 0, kModeStore = 1, kModeAssign = 2 };
+enum ScanMode { kModeTopK = 0, kModeStore = 1, kModeAssign = 2, kModeFilter = 3 };
 
 struct ScanParams {
     const float* base;       // [n_rows][128] row-major (the flat fvecs payload, cpu_baseline.cpp:48-49)
@@ -44,6 +44,12 @@ struct ScanParams {
     float* best_d;           // [n_rows] (pre-set to +inf)
     int32_t* best_i;         // [n_rows] (pre-set to -1)
     int assign_base;
+    // kModeFilter (tie resolver): every (row, dist) with dist < tau0[query] is appended to the query's candidate list --
+    // the rows select_topk (cpu_baseline.cpp:139-150) can still act on once its buffer maximum is below tau0
+    int32_t* f_cnt;          // [32] entries appended per query (pre-set to 0; may exceed f_cap: overflow)
+    int32_t* f_row;          // [32][f_cap] row numbers (relative to the index, unordered)
+    float* f_d;              // [32][f_cap]
+    int f_cap;
 };
 
 // Brute-force / coarse scan.  kcap in {8, 16}; nqh = 1 (<=16 queries) or 2.
@@ -146,6 +152,9 @@ struct IvfGroup {
 // Coarse L2 scores against the centroids + the nprobe nearest lists per query, one launch (nlist <= 2048).
 hipError_t launch_ivf_coarse_pick(const float* q, int B, const float* cents, const float* cnorm, int nlist, int nprobe,
                                   int metric, int32_t* probes, const IvfGroup& grp, hipStream_t s, int n_batches = 1);
+// ... followed by the grouping + work-plan kernel (one workgroup per batch; no-op when grp.lcnt == nullptr)
+hipError_t launch_ivf_group_plan(const int32_t* probes, int B, int nlist, int nprobe, const IvfGroup& grp, hipStream_t s,
+                                 int n_batches = 1);
 
 struct IvfListScanParams {
     const float* vecs;        // [n_rows][128] cluster-reordered

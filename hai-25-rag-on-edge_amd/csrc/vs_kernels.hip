@@ -565,6 +565,27 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams 
         }
         return;
       }
+      if (MODE == kModeFilter) {
+        // candidate rows for the exact replay of select_topk: everything under the query's bound (a few per million)
+        const int rloc = tt * TR + 4 * g;
+#pragma unroll
+        for (int h = 0; h < NQH; ++h) {
+            const float dmin = fminf(fminf(dd[0][h][0], dd[0][h][1]), fminf(dd[0][h][2], dd[0][h][3]));
+            if (dmin < tau[h]) {
+                const int qidx = h * 16 + r;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (dd[0][h][j] < tau[h]) {
+                        const int pos = atomicAdd(p.f_cnt + qidx, 1);
+                        if (pos < p.f_cap) {
+                            p.f_row[(int64_t)qidx * p.f_cap + pos] = (int)p.row_begin + rloc + j;
+                            p.f_d[(int64_t)qidx * p.f_cap + pos] = dd[0][h][j];
+                        }
+                    }
+            }
+        }
+        return;
+      }
         const float (&d)[NQH][4] = dd[0];
         const int64_t rbase = p.row_begin + (int64_t)tt * TR + 4 * g;
 #pragma unroll
@@ -630,7 +651,7 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams 
 
     const bool exchange = MODE == kModeTopK && slots != nullptr;
     int t_cur = t_a, t_nxt = t_b, slot = 0;
-    if (MODE == kModeTopK && p.tau0) {  // bounds computed up front (launch_seed): stream from the first tile on
+    if ((MODE == kModeTopK || MODE == kModeFilter) && p.tau0) {  // bounds computed up front (launch_seed): stream from the first tile on
 #pragma unroll
         for (int h = 0; h < NQH; ++h) {
             tq[h] = p.tau0[batch * kMaxBatch + h * 16 + r];
@@ -805,7 +826,7 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams 
     VS_STAMP(5);
     VS_STAMPC(14);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // retire the discarded tail prefetches: LDS is reused below
-    if (MODE == kModeStore) return;
+    if (MODE == kModeStore || MODE == kModeFilter) return;
     if (MODE == kModeAssign) {
         __syncthreads();  // LDS is reused by the next centroid block
         continue;
@@ -904,12 +925,14 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams 
 template <int NQH, int KCAP, int MODE, int PREC = 0>
 static hipError_t launch_scan_t(const ScanParams& p, int grid, hipStream_t s) {
     auto kfn = scan_kernel<NQH, KCAP, MODE, PREC>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[64] = {};  // per device: the attribute belongs to the device's copy of the code object
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!attr_set[dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, kScanLds);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set[dev] = true;
     }
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(kScanThreads), kScanLds, s, p);
     return hipGetLastError();
@@ -1110,6 +1133,7 @@ hipError_t launch_scan(const ScanParams& p, int grid, int kcap, int nqh, int mod
         return hipErrorInvalidValue;
     }
     if (mode == kModeAssign) return launch_scan_t<2, 8, kModeAssign>(p, grid, s);
+    if (mode == kModeFilter) return launch_scan_t<2, 8, kModeFilter>(p, grid, s);
     if (mode == kModeStore) {
         return nqh == 1 ? launch_scan_t<1, 8, kModeStore>(p, grid, s) : launch_scan_t<2, 8, kModeStore>(p, grid, s);
     }
@@ -1970,8 +1994,13 @@ hipError_t launch_ivf_coarse_pick(const float* q, int B, const float* cents, con
     if (nlist <= 1024) hipLaunchKernelGGL(ivf_coarse_pick_kernel<4>, dim3(B, n_batches), dim3(1024), 0, s, q, cents, cnorm, nlist, nprobe, metric, probes, grp);
     else if (nlist <= 2048) hipLaunchKernelGGL(ivf_coarse_pick_kernel<8>, dim3(B, n_batches), dim3(1024), 0, s, q, cents, cnorm, nlist, nprobe, metric, probes, grp);
     else return hipErrorInvalidValue;
-    // grouping + work plan: one workgroup per batch
-    if (grp.lcnt) hipLaunchKernelGGL(ivf_group_plan_kernel, dim3(1, n_batches), dim3(1024), 0, s, probes, B, nlist, nprobe, grp);
+    return hipGetLastError();
+}
+
+// grouping + work plan: one workgroup per batch
+hipError_t launch_ivf_group_plan(const int32_t* probes, int B, int nlist, int nprobe, const IvfGroup& grp, hipStream_t s, int n_batches) {
+    if (!grp.lcnt) return hipSuccess;
+    hipLaunchKernelGGL(ivf_group_plan_kernel, dim3(1, n_batches), dim3(1024), 0, s, probes, B, nlist, nprobe, grp);
     return hipGetLastError();
 }
 

@@ -212,6 +212,10 @@ VS_API int vs_topk_merge_dev(const float* dists_dev, const int32_t* ids_dev, int
  * (bench.py's roofline leg).  which: 0 = brute-force scan, 1 = IVF list scan. */
 VS_API int vs_prof_enable(vs_index* h, int on);
 VS_API int vs_prof_read(vs_index* h, int which, double* total_ms, int64_t* launches);
+/* per-launch durations (ms) of the same window, oldest first; *launches = how many there were (may exceed cap).
+ * One brute-force launch serves up to 32 batches: the CLIs turn these into the per-batch statistics of
+ * main.cpp:262-330 (avg / stddev / min / max / P50 / P95 / P99 "graph execute time"). */
+VS_API int vs_prof_read_launches(vs_index* h, int which, double* ms_out, int64_t cap, int64_t* launches);
 
 VS_API int64_t vs_index_rows(const vs_index* h);
 VS_API int vs_index_dim(const vs_index* h);

@@ -366,3 +366,44 @@ def test_cluster_shards_multi_batch(gpu_pkg):
     a, b = i_all.cpu().numpy(), oi.cpu().numpy()
     for i in range(nb * 32):
         assert sorted(a[i].tolist()) == sorted(b[i].tolist())
+
+
+@pytest.mark.parametrize("nprobe", [8, 32])
+def test_nlist1024_nprobe_8_and_32(gpu_pkg, nprobe):
+    """BASELINE.json config 4 in shape (nlist = 1024, nprobe in {8, 32}, k = 5, batch 32) on a base the oracle covers in
+    seconds: index from the native builder; >= 97 % of the queries identical to the oracle's restatement of
+    IVFIndex::searchBatch (the rest: last-bit coarse ties on non-integer centroids), exact integer distances for every
+    returned id, recall@1 (main_ivf.cpp:52-59 with k = 1) against exact ground truth equal to the oracle's within 1 %,
+    host API == device multi-batch API."""
+    import torch
+    n, nlist, k = 150_000, 1024, 5
+    key = ("built", n, nlist)
+    if key not in _INDEX_CACHE:
+        base = gpu_pkg.synth_sift(n, seed=41)
+        _INDEX_CACHE[key] = (base,) + tuple(gpu_pkg.ivf_build(base, nlist, max_iter=8, seed=42))
+    base, vr, off, r2o, cents, _ = _INDEX_CACHE[key]
+    assert len(off) == nlist + 1 and off[-1] == n
+    q = gpu_pkg.synth_sift(8 * 32, seed=43)
+    oi, od, ototal = oracle.ivf_search(vr, off, r2o, cents, q, k, nprobe)
+    gt, _ = oracle.search_bf(base, q, k)
+    with gpu_pkg.IVFIndex(vectors_reordered=vr, centroids=cents, cluster_offsets=off, reorder_to_original=r2o) as ivf:
+        ids, d, total = ivf.searchBatch(q, len(q), k, nprobe)
+        dev = torch.device("cuda:0")
+        qd = torch.from_numpy(q).to(dev)
+        gi = torch.zeros((len(q), k), dtype=torch.int32, device=dev)
+        gd = torch.zeros((len(q), k), dtype=torch.float32, device=dev)
+        ivf.search_dev_multi(qd.data_ptr(), 8, 32, k, nprobe, gi.data_ptr(), gd.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+    assert np.array_equal(gd.cpu().numpy(), d) and np.array_equal(gi.cpu().numpy(), ids)
+    same = np.array([np.array_equal(d[i], od[i]) and np.array_equal(ids[i], oi[i]) for i in range(len(q))])
+    assert same.mean() >= 0.97, same.mean()
+    assert abs(total - ototal) <= 0.02 * ototal
+    ex = oracle.exact_int_dists(q, base)
+    valid = ids >= 0
+    assert valid.all()
+    assert np.array_equal(np.take_along_axis(ex, ids.astype(np.int64), 1).astype(np.float32), d)
+    r1, r1o = oracle.recall(ids[:, :1], gt[:, :1], 1), oracle.recall(oi[:, :1], gt[:, :1], 1)
+    assert abs(r1 - r1o) <= 0.01
+    assert abs(oracle.recall(ids, gt, k) - oracle.recall(oi, gt, k)) <= 0.01
+    if nprobe == 32:
+        assert r1 >= 0.91  # the north-star's bar

@@ -291,3 +291,92 @@ def test_seeded_multi_batch_non_integer_base(gpu_pkg):
     same = (ids == oi)
     gap = np.minimum(np.abs(np.diff(od, axis=1, prepend=-np.inf)), np.abs(np.diff(od, axis=1, append=np.inf)))
     assert same[gap > 4 * tol].all() and same.mean() > 0.99
+
+
+def test_tie_resolver_candidate_pass(gpu_pkg):
+    """Flagged queries on a base larger than the dense prefix of the tie resolver (4096 rows): the filtered
+    candidate pass + slot replay must reproduce select_topk's history-dependent order (cpu_baseline.cpp:127-153),
+    including ties between rows before and after the prefix, ties at the k-th position and duplicated rows."""
+    rng = np.random.default_rng(21)
+    base = rng.integers(0, 40, size=(60000, 128)).astype(np.float32)   # small alphabet: ties are common
+    q = rng.integers(0, 40, size=(70, 128)).astype(np.float32)
+    # planted duplicates: the same vector early, in the middle and late -> equal distances across the dense prefix
+    for t, src in enumerate((5, 77, 4000, 4095, 4096, 30000)):
+        base[4096 + 977 * (t + 1)] = base[src]
+        base[59000 - 13 * t] = base[src]
+        q[t] = base[src] + (t % 2)        # nearest rows are the planted copies (distance 0 or 128)
+    q[10] = base[3]                       # exact hit in the prefix
+    base[50001] = base[3]
+    for k in (1, 5, 10):
+        oi, od = oracle.search_bf(base, q, k)
+        with gpu_pkg.BruteForceIndex(base) as idx:
+            for precision in (1, 0):
+                idx.set_precision(precision)
+                tm = gpu_pkg.Timing()
+                ids, d = idx.search(q, k, tm)
+                assert np.array_equal(ids, oi) and np.array_equal(d, od), f"k={k} precision={precision}"
+                assert tm.tie_queries > 0  # the resolver ran (otherwise this test proves nothing)
+
+
+def test_tie_resolver_overflow_falls_back_to_full_rows(gpu_pkg):
+    # tiny alphabet on a base beyond the dense prefix: far more rows under the bound than candidate slots -> full-row path
+    rng = np.random.default_rng(22)
+    base = rng.integers(0, 2, size=(40000, 128)).astype(np.float32)
+    base[20000:30000] = base[0:10000]
+    q = np.concatenate([base[[0, 9999, 25000]], rng.integers(0, 2, size=(5, 128)).astype(np.float32)])
+    _check_exact(gpu_pkg, base, q, 5)
+
+
+def test_sift1m_brute_force_exact(gpu_pkg):
+    """BASELINE.json config 3 at full size: SIFT-1M-shaped base, batch 32, k = 5 -- 64 queries against the oracle,
+    ids and distances bit for bit, on the fp32 path and on the exact int8 path, host API and device API."""
+    import torch
+    base = gpu_pkg.synth_sift(1_000_000, seed=20251205)
+    q = gpu_pkg.synth_sift(64, seed=20251206)
+    oi, od = oracle.search_bf(base, q, 5)
+    with gpu_pkg.BruteForceIndex(base) as idx:
+        for precision in (1, 0):
+            idx.set_precision(precision)
+            ids, d = idx.search(q, 5)
+            assert np.array_equal(ids, oi) and np.array_equal(d, od), f"precision={precision}"
+        # the device-level multi-batch call the bench times: k + 1 best by (dist, id); flags mark ties
+        idx.set_precision(1)
+        dev = torch.device("cuda", 0)
+        qd = torch.from_numpy(q).to(dev)
+        o_d = torch.zeros((64, 6), dtype=torch.float32, device=dev)
+        o_i = torch.zeros((64, 6), dtype=torch.int32, device=dev)
+        fl = torch.zeros((64,), dtype=torch.int32, device=dev)
+        idx.search_dev_multi(qd.data_ptr(), 2, 32, 5, o_i.data_ptr(), o_d.data_ptr(), fl.data_ptr(),
+                             torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        keep = fl.cpu().numpy() == 0
+        assert keep.sum() >= 60
+        assert np.array_equal(o_i.cpu().numpy()[keep, :5], oi[keep]) and np.array_equal(o_d.cpu().numpy()[keep, :5], od[keep])
+
+
+def test_cli_no_arguments_reproduces_reference_run(gpu_pkg, golden_dir, tmp_path):
+    """`vsearch_bf` with no arguments = the reference's hard-coded run (cpu_baseline.cpp:323-345): k = 5,
+    siftsmall/siftsmall_{base,query}.fvecs relative to the CWD -> siftsmall_results.txt, byte for byte what the
+    reference wrote for the same inputs; the missing sift/ dataset is reported and skipped, exit code 0 (:194-197, :351)."""
+    import subprocess
+    z = np.load(os.path.join(golden_dir, "ref_synth10k_inputs.npz"))
+    os.makedirs(tmp_path / "siftsmall")
+    gpu_pkg.write_fvecs(str(tmp_path / "siftsmall" / "siftsmall_base.fvecs"), z["base"].astype(np.float32))
+    gpu_pkg.write_fvecs(str(tmp_path / "siftsmall" / "siftsmall_query.fvecs"), z["query"].astype(np.float32))
+    exe = os.path.join(os.path.dirname(gpu_pkg.LIB_PATH), "vsearch_bf")
+    assert os.path.exists(exe), "vsearch_bf not built (make -C hai-25-rag-on-edge_amd/csrc all)"
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = gpu_pkg.hip_runtime_dir() + os.pathsep + env.get("LD_LIBRARY_PATH", "")
+    r = subprocess.run([exe], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "Failed to load base file!" in r.stderr  # sift/ is absent, like a checkout without the 1M set
+    got = open(tmp_path / "siftsmall_results.txt").read()
+    assert got == open(os.path.join(golden_dir, "ref_synth10k_results.txt")).read()
+    # brute-force metrics.txt in the layout of qidk_bruteforce main.cpp:321-390
+    m = open(tmp_path / "siftsmall_metrics.txt").read()
+    for needle in ("Performance Metrics (Batched) ===", "Dataset Information:", "Number of queries: 100", "Number of documents: 10000",
+                   "Dimension: 128", "Batch size: 32", "Number of batches: 4", "Top-K: 5", "Operational Intensity Analysis:",
+                   "Overall Performance:", "Throughput:", "queries/sec", "Avg graph execute time:", "P95 graph exec time:",
+                   "P99 graph exec time:", "Avg GFLOPS:", "Per-Query Amortized Performance:", "Time Breakdown (% of end-to-end):"):
+        assert needle in m, needle
+    assert not os.path.exists(tmp_path / "sift_results.txt")
