@@ -122,6 +122,9 @@ def lib():
         "vs_ivf_load": (i32, [C.c_char_p, i32, i32, i32, C.POINTER(vp)]),
         "vs_ivf_create": (i32, [vp, i64, i32, vp, i32, vp, vp, i32, i32, i32, C.POINTER(vp)]),
         "vs_ivf_build": (i32, [vp, i64, i32, i32, i32, C.c_double, C.c_uint64, i32, vp, vp, C.POINTER(i32)]),
+        "vs_ivf_clamp_nlist": (i32, [i64, i32]),
+        "vs_ivf_layout": (i32, [vp, i64, i32, vp, vp]),
+        "vs_ivf_build_index": (i32, [vp, i64, i32, i32, i32, C.c_double, C.c_uint64, i32, C.POINTER(vp), C.POINTER(i32)]),
         "vs_ivf_save": (i32, [vp, C.c_char_p]),
         "vs_ivf_search": (i32, [vp, vp, i64, i32, i32, vp, vp, C.POINTER(i64), C.POINTER(Timing)]),
         "vs_ivf_search_dev": (i32, [vp, vp, i32, i32, i32, vp, vp, vp]),
@@ -322,6 +325,19 @@ class IVFIndex(_Index):
                                        _p(r2o) if r2o is not None else None, device, rank, world, C.byref(self._h)))
         self.d = self.getDim()
 
+    @classmethod
+    def build(cls, base, n_clusters: int, max_iter: int = 100, tol: float = 1e-4, seed: int = 42, device: int = 0):
+        """build_ivf_index_reordered (create_ivf_model_reordered.py:82-177) entirely inside the library
+        (vs_ivf_build_index); returns (index, n_iter).  `index.save(dir)` writes the reference's directory."""
+        base = _f32c(base)
+        self = cls.__new__(cls)
+        _Index.__init__(self)
+        it = C.c_int(0)
+        _check(lib().vs_ivf_build_index(_p(base), base.shape[0], base.shape[1], n_clusters, max_iter, tol, seed, device,
+                                        C.byref(self._h), C.byref(it)))
+        self.d = self.getDim()
+        return self, int(it.value)
+
     def getNumVectors(self) -> int:
         return self.getNumDocs()
 
@@ -366,12 +382,12 @@ def topk_merge_dev(dists_ptr: int, ids_ptr: int, G: int, B: int, kin: int, kout:
 
 # ------------------------------------------------------------------ IVF index building (host logic)
 def ivf_layout_from_assignment(vectors: np.ndarray, cluster_ids: np.ndarray, n_clusters: int):
-    """Reordered index layout of create_ivf_model_reordered.py:108-128: stable argsort by cluster,
-    offsets = cumsum(sizes).  Returns (vectors_reordered, cluster_offsets, reorder_to_original)."""
-    order = np.argsort(cluster_ids, kind="stable").astype(np.int32)
-    sizes = np.bincount(cluster_ids, minlength=n_clusters).astype(np.int64)
-    offsets = np.zeros(n_clusters + 1, dtype=np.int32)
-    offsets[1:] = np.cumsum(sizes)
+    """Reordered index layout of create_ivf_model_reordered.py:108-128 through the library (vs_ivf_layout: stable sort
+    by cluster, offsets = running sum of sizes).  Returns (vectors_reordered, cluster_offsets, reorder_to_original)."""
+    a = np.ascontiguousarray(cluster_ids, dtype=np.int32)
+    offsets = np.empty(n_clusters + 1, dtype=np.int32)
+    order = np.empty(a.shape[0], dtype=np.int32)
+    _check(lib().vs_ivf_layout(_p(a), a.shape[0], n_clusters, _p(offsets), _p(order)))
     return np.ascontiguousarray(vectors[order], dtype=np.float32), offsets, order
 
 
@@ -390,10 +406,8 @@ def ivf_build(base, n_clusters: int, max_iter: int = 100, tol: float = 1e-4, see
 
 
 def clamp_nlist(n_vectors: int, n_clusters: int) -> int:
-    """nlist clamp of create_ivf_model_reordered.py:92-94."""
-    if n_clusters > n_vectors // 10:
-        n_clusters = max(16, n_vectors // 100)
-    return n_clusters
+    """nlist clamp of create_ivf_model_reordered.py:92-94 (vs_ivf_clamp_nlist)."""
+    return int(lib().vs_ivf_clamp_nlist(n_vectors, n_clusters))
 
 
 # ------------------------------------------------------------------ multi-GPU host logic (no GPU needed)

@@ -143,7 +143,7 @@ struct vs_index {
     long long mb_slab_stride = 0, mb_zslab_stride = 0, mb_cand_stride = 0;
     int mb_nbk = 0;  // per-query score-block minima (32 scores per block) of the list scan
     long long mb_off_lq = 0, mb_off_lbase = 0, mb_off_qoff = 0, mb_off_probes = 0, mb_off_gd = 0, mb_off_gp = 0, mb_off_units = 0,
-              mb_off_cand = 0;
+              mb_off_cand = 0, mb_off_scores = 0;
     hipStream_t ivf_stream[8] = {};
     hipEvent_t ivf_fork = nullptr, ivf_join[8] = {};
     int64_t n_units_max = 0;
@@ -298,7 +298,7 @@ void scan_geometry(int64_t rows, int num_cus, int& grid, int& tiles_per_wg, int 
 // per-batch scratch of the IVF search (one set per stream that runs batches)
 int alloc_ivf_scratch(vs_index* h) {
     int rc;
-    h->scores_cap = (int64_t)32 * ((h->nlist + 15) & ~15);
+    h->scores_cap = (int64_t)32 * ((h->nlist + 63) & ~63);
     if ((rc = dev_alloc(&h->d_scores, (size_t)h->scores_cap))) return rc;
     if ((rc = dev_alloc(&h->d_probes, 32 * kMaxNprobe))) return rc;
     if ((rc = dev_alloc(&h->d_ipart_d, (size_t)32 * kMaxNprobe * kKcapMax))) return rc;
@@ -655,8 +655,8 @@ int ivf_batch_dev(vs_index* h, const float* q_dev, int B, int k, int nprobe, flo
         set_error("k too large for the compiled IVF kernels (k <= 16)");
         return VS_ERR_UNSUPPORTED;
     }
-    const int64_t ld = (h->nlist + 15) & ~15;
-    const bool grouped = g_ivf_grouped && h->nlist <= 2048 && h->n_chunks > 0;
+    const int64_t ld = (h->nlist + 63) & ~63;
+    const bool grouped = g_ivf_grouped && h->nlist <= vs::kIvfFastNlist && h->n_chunks > 0;
     vs::IvfGroup grp{};
     if (grouped) {
         // candidate-score array: a query's probed lists back to back
@@ -690,9 +690,10 @@ int ivf_batch_dev(vs_index* h, const float* q_dev, int B, int k, int nprobe, flo
         }
     }
     stage_mark(h, 0, s);
-    if (h->nlist <= 2048) {
-        // coarse scores + deterministic top-nprobe (IVFIndex.cpp:654-666, :697-723), then the grouping tables
-        HIPCHK(vs::launch_ivf_coarse_pick(q_dev, B, h->d_centroids, h->d_cnorm, h->nlist, nprobe, h->metric, h->d_probes, grp, s));
+    if (h->nlist <= vs::kIvfFastNlist) {
+        // coarse scores (MFMA) + deterministic top-nprobe (IVFIndex.cpp:654-666, :697-723), then the grouping tables
+        HIPCHK(vs::launch_ivf_coarse_pick(q_dev, B, h->d_centroids, h->d_cnorm, h->nlist, nprobe, h->metric, h->d_scores, (int)ld,
+                                          h->d_probes, grp, s));
         stage_mark(h, 1, s);
         HIPCHK(vs::launch_ivf_group_plan(h->d_probes, B, h->nlist, nprobe, grp, s));
     } else {
@@ -795,7 +796,7 @@ int g_ivf_multi = [] {
 }();
 
 bool ivf_multi_ok(const vs_index* h, int k) {
-    return g_ivf_multi && g_ivf_grouped && g_ivf_plan && h->nlist <= 2048 && h->n_chunks > 0 && h->d_units && pick_kcap(k);
+    return g_ivf_multi && g_ivf_grouped && g_ivf_plan && h->nlist <= vs::kIvfFastNlist && h->n_chunks > 0 && h->d_units && pick_kcap(k);
 }
 
 int ensure_ivf_mb(vs_index* h, int nprobe, hipStream_t s) {
@@ -816,6 +817,7 @@ int ensure_ivf_mb(vs_index* h, int nprobe, hipStream_t s) {
     h->mb_off_gd = off;      off = al(off + 32ll * 4096 * 4);
     h->mb_off_gp = off;      off = al(off + 32ll * 4096 * 4);
     h->mb_off_units = off;   off = al(off + std::max<long long>(h->n_units_max, 1) * 16);
+    h->mb_off_scores = off;  off = al(off + 32ll * ((h->nlist + 63) & ~63) * 4);
     h->mb_off_cand = off;    off = al(off + 32ll * cstride * 4);
     h->mb_slab_stride = off;
     h->mb_nbk = (int)(cstride / 32 + 2);
@@ -857,7 +859,8 @@ int ivf_group_dev(vs_index* h, const float* q_dev, int nb, int B, int k, int npr
     grp.units = reinterpret_cast<int32_t*>(sl + h->mb_off_units);
     grp.mb = mb;
     stage_mark(h, 0, s);
-    HIPCHK(vs::launch_ivf_coarse_pick(q_dev, B, h->d_centroids, h->d_cnorm, h->nlist, nprobe, h->metric, probes, grp, s, nb));
+    HIPCHK(vs::launch_ivf_coarse_pick(q_dev, B, h->d_centroids, h->d_cnorm, h->nlist, nprobe, h->metric,
+                                      reinterpret_cast<float*>(sl + h->mb_off_scores), (h->nlist + 63) & ~63, probes, grp, s, nb));
     stage_mark(h, 1, s);
     HIPCHK(vs::launch_ivf_group_plan(probes, B, h->nlist, nprobe, grp, s, nb));
     stage_mark(h, 2, s);
@@ -1681,6 +1684,27 @@ int vs_ivf_build(const float* base_host, int64_t n_rows, int dim, int nlist, int
     cleanup();
     if (iters_done) *iters_done = it;
     return VS_OK;
+}
+
+// build_ivf_index_reordered (create_ivf_model_reordered.py:82-177) end to end: k-means, reordered layout, resident index.
+int vs_ivf_build_index(const float* base_host, int64_t n_rows, int dim, int nlist, int max_iter, double tol, uint64_t seed,
+                       int device, vs_index** out, int* iters_done) {
+    if (!out || !base_host || n_rows <= 0 || nlist <= 0) {
+        set_error("vs_ivf_build_index: bad arguments");
+        return VS_ERR_INVALID;
+    }
+    return guarded([&]() -> int {
+        const int nl = vs_ivf_clamp_nlist(n_rows, nlist);
+        std::vector<float> cents((size_t)nl * dim);
+        std::vector<int32_t> assign((size_t)n_rows), off((size_t)nl + 1), r2o((size_t)n_rows);
+        int rc = vs_ivf_build(base_host, n_rows, dim, nl, max_iter, tol, seed, device, cents.data(), assign.data(), iters_done);
+        if (rc) return rc;
+        if ((rc = vs_ivf_layout(assign.data(), n_rows, nl, off.data(), r2o.data()))) return rc;
+        std::vector<float> vr((size_t)n_rows * dim);
+        for (int64_t i = 0; i < n_rows; ++i)
+            std::memcpy(&vr[(size_t)i * dim], base_host + (size_t)r2o[(size_t)i] * dim, (size_t)dim * sizeof(float));
+        return ivf_create_impl(vr.data(), n_rows, dim, cents.data(), nl, off.data(), r2o.data(), device, 0, 1, out);
+    });
 }
 
 int vs_ivf_create(const float* vectors_reordered, int64_t n_rows, int dim, const float* centroids, int nlist,

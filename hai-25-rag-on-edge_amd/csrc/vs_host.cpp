@@ -401,6 +401,38 @@ extern "C" {
 
 const char* vs_last_error(void) { return vs::get_error(); }
 
+// create_ivf_model_reordered.py:92-94
+int vs_ivf_clamp_nlist(int64_t n_vectors, int nlist) {
+    if (nlist > n_vectors / 10) nlist = (int)std::max<int64_t>(16, n_vectors / 100);
+    return nlist;
+}
+
+// create_ivf_model_reordered.py:108-128: rows sorted by cluster (stable: a counting sort, so rows of a cluster keep their
+// original order -- numpy's default argsort there leaves that order unspecified), offsets = running sum of the sizes.
+int vs_ivf_layout(const int32_t* assign, int64_t n_rows, int nlist, int32_t* cluster_offsets, int32_t* reorder_to_original) {
+    if (!assign || !cluster_offsets || !reorder_to_original || n_rows < 0 || nlist <= 0 || n_rows > 0x7fffffffll) {
+        vs::set_error("vs_ivf_layout: bad arguments");
+        return VS_ERR_INVALID;
+    }
+    for (int c = 0; c <= nlist; ++c) cluster_offsets[c] = 0;
+    for (int64_t i = 0; i < n_rows; ++i) {
+        if (assign[i] < 0 || assign[i] >= nlist) {
+            vs::set_error("vs_ivf_layout: cluster id out of range");
+            return VS_ERR_INVALID;
+        }
+        ++cluster_offsets[assign[i] + 1];
+    }
+    for (int c = 0; c < nlist; ++c) cluster_offsets[c + 1] += cluster_offsets[c];
+    try {
+        std::vector<int32_t> cursor(cluster_offsets, cluster_offsets + nlist);
+        for (int64_t i = 0; i < n_rows; ++i) reorder_to_original[cursor[(size_t)assign[i]]++] = (int32_t)i;
+    } catch (const std::bad_alloc&) {
+        vs::set_error("out of host memory");
+        return VS_ERR_NOMEM;
+    }
+    return VS_OK;
+}
+
 int vs_fvecs_shape(const char* path, int64_t* rows, int* dim) { return vs::xvecs_scan(path, nullptr, 0, rows, dim); }
 int vs_fvecs_read(const char* path, float* dst, int64_t cap, int64_t* rows, int* dim) {
     if (!dst) { vs::set_error("dst is NULL"); return VS_ERR_INVALID; }

@@ -149,9 +149,12 @@ struct IvfGroup {
     IvfMulti mb;
 };
 
-// Coarse L2 scores against the centroids + the nprobe nearest lists per query, one launch (nlist <= 2048).
+// Coarse stage: Q x C^T + L2 epilogue on MFMA into scores [n_batches][32][ld] (ld >= nlist rounded up to 64; batch y's
+// copy lies grp.mb.slab bytes further on), then the nprobe nearest lists per query (nlist <= kIvfFastNlist).
+constexpr int kIvfFastNlist = 4096;
 hipError_t launch_ivf_coarse_pick(const float* q, int B, const float* cents, const float* cnorm, int nlist, int nprobe,
-                                  int metric, int32_t* probes, const IvfGroup& grp, hipStream_t s, int n_batches = 1);
+                                  int metric, float* scores, int ld, int32_t* probes, const IvfGroup& grp, hipStream_t s,
+                                  int n_batches = 1);
 // ... followed by the grouping + work-plan kernel (one workgroup per batch; no-op when grp.lcnt == nullptr)
 hipError_t launch_ivf_group_plan(const int32_t* probes, int B, int nlist, int nprobe, const IvfGroup& grp, hipStream_t s,
                                  int n_batches = 1);
@@ -202,6 +205,7 @@ struct IvfSelectParams {
     int32_t* gdone;           // [B] arrival counters (pre-set to 0)
     int32_t* govf;            // [B] overflow flags (pre-set to 0)
     int nprobe, k;
+    int split;                // workgroups per query (set by launch_ivf_select)
     float* out_d;             // [B][k]
     int32_t* out_i;
     IvfMulti mb;

@@ -8,7 +8,7 @@
 //   seed_*_kernel        : bounds for a multi-batch scan from 2048 sample tiles (launch_seed).
 //   merge_compact_kernel : cross-workgroup / cross-GPU merge of partial lists (merge_kernel: general fallback).
 //   row_sqnorm_kernel    : compute_norms (cpu_baseline.cpp:95-125) in the reference's summation order.
-//   ivf_coarse_pick_kernel, ivf_group_plan_kernel, ivf_unit_scan_kernel, ivf_bound_kernel, ivf_select_kernel :
+//   ivf_coarse_mfma_kernel, ivf_pick_kernel, ivf_group_plan_kernel, ivf_unit_scan_kernel, ivf_bound_kernel, ivf_select_kernel :
 //                          IVFIndex::searchBatch (IVFIndex.cpp:640-859) as a list-major pipeline, blockIdx.y = batch;
 //                          ivf_list_scan_kernel / pick_probes_kernel / ivf_scan_kernel: fallback paths.
 //   kpp_*_kernel, kmeans_*_kernel : index builder (create_ivf_model_reordered.py:88-118).
@@ -747,7 +747,8 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams 
                 cf += dpp_mov_i<0x4E>(cf);
                 cf += dpp_mov_i<0x141>(cf);
                 cf += dpp_mov_i<0x140>(cf);  // row sum: workgroups that have published this row's query
-                if (__all(cf >= need) || spin >= 2048) break;
+                // (DPP rows of waves that hold no query -- 16-query launches use half of them -- have nothing to wait for)
+                if (__all(4 * wave + g >= NQH * 16 || cf >= need) || spin >= 2048) break;
                 __builtin_amdgcn_s_sleep(24);
                 const float* s0 = slots + (4 * wave + g) * kSlotStride + 16 * r;
                 asm volatile(
@@ -1620,108 +1621,121 @@ __device__ __forceinline__ T* mb_adv(T* ptr, long long bytes) {
     return ptr ? reinterpret_cast<T*>(reinterpret_cast<char*>(const_cast<typename std::remove_const<T>::type*>(ptr)) + bytes) : ptr;
 }
 
+// Coarse stage, part 1 (IVFIndex.cpp:654-666, the reference's NPU matmul): scores[q][c] = ||q||^2 + ||c||^2 - 2 q.c for
+// ALL queries of a launch group against all centroids, as one MFMA contraction: grid (nlist / 64, n_batches), four
+// waves per workgroup, wave w owns the 16-centroid tile 4 blockIdx.x + w as the A operand (fragments straight from
+// global memory: the centroids are L2 resident) and the batch's <= 32 queries as two 16-column B operands -- the same
+// v_mfma_f32_16x16x4_f32 chain and epilogue as the brute-force scan, so a centroid score is the number that scan
+// would produce.  1024 x 1024 x 128 per group of 32 batches: a few microseconds.
+__global__ __launch_bounds__(256) void ivf_coarse_mfma_kernel(const float* __restrict__ q, int B, const float* __restrict__ cents,
+                                                             const float* __restrict__ cnorm, int nlist, int metric,
+                                                             float* __restrict__ scores, int ld, IvfMulti mb) {
+    {
+        const long long y = blockIdx.y;
+        q = mb_adv(q, y * mb.q);
+        scores = mb_adv(scores, y * mb.slab);
+    }
+    __shared__ float qn_s[kMaxBatch];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    {   // ||q||^2 in the reference's AVX2 order (cpu_baseline.cpp:95-114): 8 lanes per query
+        const int row = tid >> 3, j = tid & 7;
+        float acc = 0.f;
+        if (row < B) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float x = q[row * kDim + 8 * i + j];
+                acc = fmaf(x, x, acc);
+            }
+        }
+        const int b8 = lane & ~7;
+        float sum = __shfl(acc, b8);
+#pragma unroll
+        for (int u = 1; u < 8; ++u) sum = sum + __shfl(acc, b8 + u);
+        if (j == 0) qn_s[row] = row < B ? sum : 0.f;
+    }
+    const int row0 = ((int)blockIdx.x * 4 + wave) * 16;  // centroid tile (the centroid array has kScanPadRows spare rows)
+    f32x4 a[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) a[c] = *reinterpret_cast<const f32x4*>(cents + (int64_t)(row0 + r) * kDim + 16 * c + 4 * g);
+    const f32x4 cn = *reinterpret_cast<const f32x4*>(cnorm + row0 + 4 * g);  // padded by 64
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int qrow = h * 16 + r;
+        if (h * 16 >= B) break;  // workgroup-uniform
+        const bool qv = qrow < B;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            f32x4 qf = *reinterpret_cast<const f32x4*>(q + (qv ? qrow : 0) * kDim + 16 * c + 4 * g);
+            if (!qv) qf = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][i], qf[i], acc, 0, 0, 0);
+        }
+        if (qv) {
+            const float qn = qn_s[qrow];
+            f32x4 d;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v = metric ? -acc[j] : fmaf(-2.0f, acc[j], qn + cn[j]);
+                if (!(v == v) || row0 + 4 * g + j >= nlist) v = VS_INF;  // NaN never wins; rows past nlist are padding
+                d[j] = v;
+            }
+            *reinterpret_cast<f32x4*>(scores + (int64_t)qrow * ld + row0 + 4 * g) = d;
+        }
+    }
+}
+
+// Coarse stage, part 2 (std::nth_element at IVFIndex.cpp:711, made deterministic: ascending (dist, id)): one 256-thread
+// workgroup per query reads its row of scores and selects without sorting rounds: the nprobe-th smallest of the 256
+// per-thread minima bounds the answer, the few scores under that bound are compacted and ranked by counting (every
+// candidate counts how many others precede it and writes itself to that slot).  Then the query's window offsets in the
+// candidate array (grouping tables of the list-major scan).
 template <int EPT>
-__global__ __launch_bounds__(1024) void ivf_coarse_pick_kernel(const float* __restrict__ q, const float* __restrict__ cents,
-                                                               const float* __restrict__ cnorm, int nlist, int nprobe,
-                                                               int metric, int32_t* __restrict__ probes, IvfGroup grp) {
+__global__ __launch_bounds__(256) void ivf_pick_kernel(const float* __restrict__ scores, int ld, int nlist, int nprobe,
+                                                       int32_t* __restrict__ probes, IvfGroup grp) {
     {   // multi-batch launch: this workgroup's batch
         const long long y = blockIdx.y;
-        q = mb_adv(q, y * grp.mb.q);
+        scores = mb_adv(scores, y * grp.mb.slab);
         probes = mb_adv(probes, y * grp.mb.slab);
-        grp.lcnt = mb_adv(grp.lcnt, y * grp.mb.zslab);
-        grp.plan_done = mb_adv(grp.plan_done, y * grp.mb.zslab);
-        grp.n_units = mb_adv(grp.n_units, y * grp.mb.zslab);
-        grp.lq = mb_adv(grp.lq, y * grp.mb.slab);
-        grp.lbase = mb_adv(grp.lbase, y * grp.mb.slab);
         grp.qoff = mb_adv(grp.qoff, y * grp.mb.slab);
-        grp.units = mb_adv(grp.units, y * grp.mb.slab);
     }
-    __shared__ float sc[256 * EPT];
     __shared__ int s_probe[256];
-    __shared__ int s_off[257];
     __shared__ float mn_d[256];
     __shared__ int mn_i[256];
     __shared__ float cd[256 * EPT];
     __shared__ int ci[256 * EPT];
-    __shared__ float s_qn, s_td;
+    __shared__ float s_td;
     __shared__ int s_ti, s_cnt;
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;  // 16 waves
-    if (tid < 8) {  // ||q||^2 in the reference's AVX2 order (cpu_baseline.cpp:95-114)
-        float a = 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const float x = q[b * kDim + 8 * i + tid];
-            a = fmaf(x, x, a);
-        }
-        float sum = __shfl(a, 0);
-#pragma unroll
-        for (int u = 1; u < 8; ++u) sum = sum + __shfl(a, u);
-        if (tid == 0) {
-            s_qn = sum;
-            s_cnt = 0;
-            s_td = VS_INF;
-            s_ti = 0x7fffffff;
-        }
+    if (tid == 0) {
+        s_cnt = 0;
+        s_td = VS_INF;
+        s_ti = 0x7fffffff;
     }
-    const int rr = lane >> 3, s8 = lane & 7;
-    f32x4 qf[4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) qf[m] = *reinterpret_cast<const f32x4*>(q + b * kDim + 4 * (s8 + 8 * m));
-    __syncthreads();
-    const float qn = s_qn;
-    // 16 waves x 8 rows = 128 rows per sweep; four sweeps are loaded together so that the loop pays
-    // two L2 round trips instead of one per sweep
-    constexpr int U = 4;
-    for (int row0 = wave * 8; row0 < nlist; row0 += 128 * U) {
-        f32x4 v[U][4];
-        float cn[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int row = row0 + 128 * u + rr;
-            const int rowc = row < nlist ? row : nlist - 1;
-            const float* src = cents + (int64_t)rowc * kDim + 4 * s8;
-#pragma unroll
-            for (int m = 0; m < 4; ++m) v[u][m] = *reinterpret_cast<const f32x4*>(src + 32 * m);
-            cn[u] = cnorm[rowc];
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int row = row0 + 128 * u + rr;
-            float acc = 0.f;
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc = fmaf(v[u][m][i], qf[m][i], acc);
-            acc = dpp_add_xor1(acc);
-            acc = dpp_add_xor2(acc);
-            acc = dpp_add_half_mirror(acc);
-            float d = metric ? -acc : fmaf(-2.0f, acc, qn + cn[u]);
-            if (!(d == d)) d = VS_INF;
-            if (row < nlist && s8 == 0) sc[row] = d;
-        }
-    }
-    __syncthreads();
-    // ---- selection by the first 256 threads (everyone keeps hitting the barriers) ----
     float md = VS_INF;
     int mi = 0x7fffffff;
     float mine[EPT];
-    if (tid < 256) {
+    const float* sc = scores + (int64_t)b * ld;
 #pragma unroll
-        for (int e = 0; e < EPT; ++e) {
-            const int idx = tid + 256 * e;
-            mine[e] = idx < nlist ? sc[idx] : VS_INF;
-            if (idx < nlist && lex_lt(mine[e], idx, md, mi)) {
-                md = mine[e];
-                mi = idx;
-            }
-        }
-        mn_d[tid] = md;
-        mn_i[tid] = mi;
+    for (int e = 0; e < EPT; ++e) {
+        const int idx = tid + 256 * e;
+        mine[e] = idx < nlist ? sc[idx] : VS_INF;
     }
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int idx = tid + 256 * e;
+        if (idx < nlist && lex_lt(mine[e], idx, md, mi)) {
+            md = mine[e];
+            mi = idx;
+        }
+    }
+    mn_d[tid] = md;
+    mn_i[tid] = mi;
     __syncthreads();
-    if (tid < 256 && nprobe <= 256) {
+    {
         int rank = 0;
         for (int j = 0; j < 256; ++j) rank += lex_lt(mn_d[j], mn_i[j], md, mi) ? 1 : 0;
         if (rank == nprobe - 1) {  // unique: the order is strict
@@ -1730,7 +1744,7 @@ __global__ __launch_bounds__(1024) void ivf_coarse_pick_kernel(const float* __re
         }
     }
     __syncthreads();
-    if (tid < 256) {
+    {
         const float td = s_td;
         const int ti = s_ti;
 #pragma unroll
@@ -1745,7 +1759,7 @@ __global__ __launch_bounds__(1024) void ivf_coarse_pick_kernel(const float* __re
     }
     __syncthreads();
     const int C = s_cnt;
-    for (int c = tid; c < C; c += 1024) {
+    for (int c = tid; c < C; c += 256) {
         const float d = cd[c];
         const int id = ci[c];
         int rank = 0;
@@ -1755,31 +1769,40 @@ __global__ __launch_bounds__(1024) void ivf_coarse_pick_kernel(const float* __re
             s_probe[rank] = id;
         }
     }
-    for (int c = C + tid; c < nprobe; c += 1024) {
+    for (int c = C + tid; c < nprobe; c += 256) {
         probes[(int64_t)b * nprobe + c] = -1;
         s_probe[c] = -1;
     }
     if (!grp.lcnt) return;
-    // ---- grouping for the list-major scan: every (query, probe) takes a slot in its list's query set and
-    //      a window [qoff[p], qoff[p+1]) in the query's candidate-score array (probe order) ----
+    // ---- every (query, probe) gets a window [qoff[p], qoff[p+1]) in the query's candidate-score array (probe order) ----
     __syncthreads();
-    __shared__ int s_sz[256];
-    for (int pp = tid; pp < nprobe; pp += 1024) {
-        const int c = s_probe[pp];
-        s_sz[pp] = c >= 0 ? grp.offsets[c + 1] - grp.offsets[c] : 0;
+    int sz = 0;
+    if (tid < nprobe) {
+        const int c = s_probe[tid];
+        sz = c >= 0 ? grp.offsets[c + 1] - grp.offsets[c] : 0;
     }
+    // exclusive scan of the <= 256 window sizes: wave scan + four wave totals
+    __shared__ int s_wt[4];
+    const int lane = tid & 63, wave = tid >> 6;
+    int incl = sz;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) s_wt[wave] = incl;
     __syncthreads();
+    int woff = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        if (w < wave) woff += s_wt[w];
+        tot += s_wt[w];
+    }
+    if (tid < nprobe) grp.qoff[(int64_t)b * (kIvfMaxProbe + 1) + tid] = woff + incl - sz;
     if (tid == 0) {
-        int acc = 0;
-        for (int pp = 0; pp < nprobe; ++pp) {
-            s_off[pp] = acc;
-            acc += s_sz[pp];
-        }
-        s_off[nprobe] = acc;
-        if (grp.cand_count) atomicAdd(grp.cand_count, (unsigned long long)acc);
+        grp.qoff[(int64_t)b * (kIvfMaxProbe + 1) + nprobe] = tot;
+        if (grp.cand_count) atomicAdd(grp.cand_count, (unsigned long long)tot);
     }
-    __syncthreads();
-    for (int pp = tid; pp <= nprobe; pp += 1024) grp.qoff[(int64_t)b * (kIvfMaxProbe + 1) + pp] = s_off[pp];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1931,7 +1954,7 @@ __global__ __launch_bounds__(1024) void ivf_group_plan_kernel(const int32_t* __r
         grp.qoff = mb_adv(grp.qoff, y * grp.mb.slab);
         grp.units = mb_adv(grp.units, y * grp.mb.slab);
     }
-    __shared__ int cnt_s[2048];
+    __shared__ int cnt_s[kIvfFastNlist];
     __shared__ int s_carry;
     __shared__ int s_wtot[16];
     const int tid = threadIdx.x;
@@ -1989,11 +2012,13 @@ __global__ __launch_bounds__(1024) void ivf_group_plan_kernel(const int32_t* __r
 }
 
 hipError_t launch_ivf_coarse_pick(const float* q, int B, const float* cents, const float* cnorm, int nlist, int nprobe,
-                                  int metric, int32_t* probes, const IvfGroup& grp, hipStream_t s, int n_batches) {
-    if (nprobe > 256) return hipErrorInvalidValue;
-    if (nlist <= 1024) hipLaunchKernelGGL(ivf_coarse_pick_kernel<4>, dim3(B, n_batches), dim3(1024), 0, s, q, cents, cnorm, nlist, nprobe, metric, probes, grp);
-    else if (nlist <= 2048) hipLaunchKernelGGL(ivf_coarse_pick_kernel<8>, dim3(B, n_batches), dim3(1024), 0, s, q, cents, cnorm, nlist, nprobe, metric, probes, grp);
-    else return hipErrorInvalidValue;
+                                  int metric, float* scores, int ld, int32_t* probes, const IvfGroup& grp, hipStream_t s, int n_batches) {
+    if (nprobe > 256 || nlist > kIvfFastNlist || ld < ((nlist + 63) & ~63)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(ivf_coarse_mfma_kernel, dim3((nlist + 63) / 64, n_batches), dim3(256), 0, s, q, B, cents, cnorm, nlist, metric,
+                       scores, ld, grp.mb);
+    if (nlist <= 1024) hipLaunchKernelGGL(ivf_pick_kernel<4>, dim3(B, n_batches), dim3(256), 0, s, scores, ld, nlist, nprobe, probes, grp);
+    else if (nlist <= 2048) hipLaunchKernelGGL(ivf_pick_kernel<8>, dim3(B, n_batches), dim3(256), 0, s, scores, ld, nlist, nprobe, probes, grp);
+    else hipLaunchKernelGGL(ivf_pick_kernel<16>, dim3(B, n_batches), dim3(256), 0, s, scores, ld, nlist, nprobe, probes, grp);
     return hipGetLastError();
 }
 
@@ -2541,7 +2566,8 @@ __global__ __launch_bounds__(256) void ivf_select_kernel(IvfSelectParams p) {
     __shared__ int cpos[1024];
     __shared__ int s_off[257];
     __shared__ int s_probe[256];
-    const int q = blockIdx.x / kSelSplit, part = blockIdx.x % kSelSplit;
+    const int split = p.split;  // workgroups per query: 1 when the block minima filter the candidates, else kSelSplit
+    const int q = blockIdx.x / split, part = blockIdx.x % split;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int S = p.qoff[(int64_t)q * (kIvfMaxProbe + 1) + p.nprobe];
@@ -2632,7 +2658,7 @@ __global__ __launch_bounds__(256) void ivf_select_kernel(IvfSelectParams p) {
     } else {
     // this workgroup's slice of the candidate array (16-byte loads, four in flight per thread)
     const int S4 = S >> 2;
-    const int per = (S4 + kSelSplit - 1) / kSelSplit;
+    const int per = (S4 + split - 1) / split;
     const int a4 = part * per, b4 = min(S4, a4 + per);
     const f32x4* sc4 = reinterpret_cast<const f32x4*>(sc);  // the candidate array is 64-float aligned
     for (int i0 = a4 + tid; i0 < b4; i0 += 1024) {
@@ -2651,12 +2677,34 @@ __global__ __launch_bounds__(256) void ivf_select_kernel(IvfSelectParams p) {
             }
         }
     }
-    if (part == kSelSplit - 1)
+    if (part == split - 1)
         for (int i = 4 * S4 + tid; i < S; i += 256) consider(i, sc[i]);
     }
     __syncthreads();
-    // append to the query's global candidate list (write-through), then take an arrival ticket
     const int C = s_cnt;
+    bool slow;
+    if (split == 1) {
+        // one workgroup per query: the candidates are ranked where they are (LDS), no hand-off
+        slow = C > 1024;
+        if (!slow) {
+            for (int c = tid; c < C; c += 256) {
+                const float d = cd[c];
+                const int id = cpos[c];
+                int rank = 0;
+                for (int j = 0; j < C; ++j) rank += lex_lt(cd[j], cpos[j], d, id) ? 1 : 0;
+                if (rank < p.k) {
+                    p.out_d[(int64_t)q * p.k + rank] = d;
+                    p.out_i[(int64_t)q * p.k + rank] = p.id_map ? p.id_map[id] : id;
+                }
+            }
+            for (int c = C + tid; c < p.k; c += 256) {
+                p.out_d[(int64_t)q * p.k + c] = VS_INF;
+                p.out_i[(int64_t)q * p.k + c] = -1;
+            }
+            return;
+        }
+    } else {
+    // append to the query's global candidate list (write-through), then take an arrival ticket
     if (tid == 0) s_base = atomicAdd(p.gcnt + q, C);
     __syncthreads();
     const int base = s_base;
@@ -2674,7 +2722,7 @@ __global__ __launch_bounds__(256) void ivf_select_kernel(IvfSelectParams p) {
         if (overflow) __hip_atomic_store(p.govf + q, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const int old = __hip_atomic_fetch_add(p.gdone + q, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = old == kSelSplit - 1;
+        const int last = old == split - 1;
         if (last) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -2702,6 +2750,7 @@ __global__ __launch_bounds__(256) void ivf_select_kernel(IvfSelectParams p) {
             p.out_i[(int64_t)q * p.k + c] = -1;
         }
         return;
+    }
     }
     // Too many scores under the bound (massive ties / no usable bound): exact but slow path -- k rounds of a
     // workgroup-wide minimum in (dist, position) order over everything not emitted yet.
@@ -2752,8 +2801,10 @@ __global__ __launch_bounds__(256) void ivf_select_kernel(IvfSelectParams p) {
 
 hipError_t launch_ivf_select(const IvfSelectParams& p, int B, hipStream_t s, int n_batches) {
     if (p.k > 16 || p.nprobe > 256) return hipErrorInvalidValue;
-    if (!p.slotmin && !p.bkt) hipLaunchKernelGGL(ivf_bound_kernel, dim3(B * kSelSplit, n_batches), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(ivf_select_kernel, dim3(B * kSelSplit, n_batches), dim3(256), 0, s, p);
+    IvfSelectParams pp = p;
+    pp.split = p.bkt ? 1 : kSelSplit;  // with per-block minima one workgroup reads the few blocks under the bound
+    if (!p.slotmin && !p.bkt) hipLaunchKernelGGL(ivf_bound_kernel, dim3(B * kSelSplit, n_batches), dim3(256), 0, s, pp);
+    hipLaunchKernelGGL(ivf_select_kernel, dim3(B * pp.split, n_batches), dim3(256), 0, s, pp);
     return hipGetLastError();
 }
 

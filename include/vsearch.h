@@ -15,7 +15,10 @@
  *   - "host" pointers are ordinary memory owned by the caller; "_dev" entry
  *     points take device (HBM) pointers and a hipStream_t passed as void*.
  *   - one vs_index = one GPU = one caller thread at a time (QnnRunner is not
- *     re-entrant either: shared I/O buffers, QnnRunner.cpp:322-323).
+ *     re-entrant either: shared I/O buffers, QnnRunner.cpp:322-323).  An index has ONE
+ *     set of scratch buffers: calls may come on different streams, but each call's work
+ *     is ordered behind the previous call's (an event the library records), so calls on
+ *     one index never overlap on the device.  Use one index per concurrent stream.
  *   - ids are 0-based row numbers of the base file (cpu_baseline.cpp:130,142),
  *     or reorder_to_original[] values for IVF (IVFIndex.cpp:774-779).
  *   - the product path never falls back to a CPU implementation: without a
@@ -134,10 +137,10 @@ VS_API int vs_bf_search_dev(vs_index* h, const float* queries_dev, int B, int k,
 
 /* The same for n_batches consecutive batches of exactly B queries each
  * (queries_dev [n_batches*B x d], outputs [n_batches*B x (k+1)], flags [n_batches*B]):
- * the harness loop of main.cpp:201-251 in one call.  Batches still stream the
- * base once each, but consecutive batches run on different internal HIP
- * streams so that one batch's start-up and tail overlap its neighbours'
- * streaming phase; the call forks from and joins into `stream`. */
+ * the harness loop of main.cpp:201-251 in one call.  Every batch still streams the
+ * base once; groups of up to 32 batches share ONE persistent scan launch (preceded by
+ * three small bound-seeding launches, followed by one merge launch), all on `stream`,
+ * so no launch gap, grid fill or drain separates consecutive batches. */
 VS_API int vs_bf_search_dev_multi(vs_index* h, const float* queries_dev, int n_batches, int B, int k,
                                   int32_t* ids_dev, float* dists_dev, int32_t* flags_dev, void* stream);
 
@@ -163,12 +166,26 @@ VS_API int vs_ivf_create(const float* vectors_reordered, int64_t n_rows, int dim
 /* GPU index builder, the device side of build_ivf_index_reordered (create_ivf_model_reordered.py:82-177):
  * Lloyd k-means under L2 with sklearn's stopping rule (sum of squared centre shifts <= tol * mean feature
  * variance, default tol 1e-4, max_iter 100 in the reference, :97-103).  Assignment runs on the MFMA scan
- * kernel, the update uses fixed-point integer atomics (deterministic).  Initial centres are nlist distinct
- * rows drawn from `seed` (the reference uses k-means++ with random_state=42: not reproducible here).
- * Outputs: centroids_out [nlist x dim], assign_out [n_rows] (cluster of every row); the reordered layout is
- * then argsort(assign, stable) exactly as :111-127 (hai-25-rag-on-edge_amd.ivf_layout_from_assignment). */
+ * kernel, the update uses fixed-point integer atomics (deterministic).  Initial centres: k-means++ (D^2 sampling
+ * on the GPU, sklearn's default init; its RNG stream and greedy multi-trial variant are not reproduced, so the
+ * centres are statistically, not bitwise, sklearn's; VSEARCH_KMEANS_INIT=random = nlist distinct random rows).
+ * Outputs: centroids_out [nlist x dim], assign_out [n_rows] (cluster of every row); vs_ivf_layout turns the
+ * assignment into the reordered layout of :108-128, vs_ivf_build_index does all of it. */
 VS_API int vs_ivf_build(const float* base_host, int64_t n_rows, int dim, int nlist, int max_iter, double tol,
                         uint64_t seed, int device, float* centroids_out, int32_t* assign_out, int* iters_done);
+
+/* The host side of the same builder (no GPU needed).  vs_ivf_clamp_nlist: the nlist rule of :92-94
+ * (nlist > N/10 -> max(16, N/100)).  vs_ivf_layout: :108-128 -- rows sorted by cluster id (stable), cluster_offsets
+ * [nlist+1] = running sum of the cluster sizes, reorder_to_original [n_rows] = the sort permutation
+ * (vectors_reordered[i] = base[reorder_to_original[i]]). */
+VS_API int vs_ivf_clamp_nlist(int64_t n_vectors, int nlist);
+VS_API int vs_ivf_layout(const int32_t* assign, int64_t n_rows, int nlist, int32_t* cluster_offsets,
+                         int32_t* reorder_to_original);
+
+/* build_ivf_index_reordered end to end (:82-177): nlist clamp, k-means (vs_ivf_build), reordered layout, and the
+ * resulting index resident on `device`; vs_ivf_save then writes the reference's directory.  No Python involved. */
+VS_API int vs_ivf_build_index(const float* base_host, int64_t n_rows, int dim, int nlist, int max_iter, double tol,
+                              uint64_t seed, int device, vs_index** out, int* iters_done);
 
 /* Writes the index held by h in the reference's directory format. */
 VS_API int vs_ivf_save(vs_index* h, const char* index_dir);
