@@ -131,6 +131,15 @@ def lib():
         "vs_ivf_search_dev_multi": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, vp]),
         "vs_ivf_list_owners": (i32, [vp, i32, i32, vp]),
         "vs_topk_merge_dev": (i32, [vp, vp, i32, i32, i32, i64, i32, vp, vp, vp, vp]),
+        "vs_comm_unique_id": (i32, [vp]),
+        "vs_comm_create": (i32, [vp, i32, i32, i32, C.POINTER(vp)]),
+        "vs_comm_rank": (i32, [vp]),
+        "vs_comm_world": (i32, [vp]),
+        "vs_comm_destroy": (None, [vp]),
+        "vs_bf_search_dev_sharded": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]),
+        "vs_bf_search_sharded": (i32, [vp, vp, vp, i64, i32, vp, vp, C.POINTER(Timing)]),
+        "vs_ivf_search_sharded": (i32, [vp, vp, vp, i64, i32, i32, vp, vp, C.POINTER(i64), C.POINTER(Timing)]),
+        "vs_ivf_search_dev_sharded": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp]),
         "vs_prof_enable": (i32, [vp, i32]),
         "vs_prof_read": (i32, [vp, i32, C.POINTER(C.c_double), C.POINTER(i64)]),
         "vs_prof_read_launches": (i32, [vp, i32, vp, i64, C.POINTER(i64)]),
@@ -294,6 +303,16 @@ class BruteForceIndex(_Index):
         _check(lib().vs_bf_search(self._h, _p(q), nq, k, _p(ids), _p(dists), C.byref(tm)))
         return ids, dists
 
+    def search_sharded(self, comm: "Comm", queries, k: int, timing: Timing | None = None):
+        """Collective host-buffer search over row shards (vs_bf_search_sharded); ties in (dist, id) order."""
+        q = _f32c(queries).reshape(-1, self.d)
+        nq = q.shape[0]
+        ids = np.empty((nq, k), dtype=np.int32)
+        dists = np.empty((nq, k), dtype=np.float32)
+        tm = timing if timing is not None else Timing()
+        _check(lib().vs_bf_search_sharded(self._h, comm._c, _p(q), nq, k, _p(ids), _p(dists), C.byref(tm)))
+        return ids, dists
+
     def search_dev(self, q_ptr: int, B: int, k: int, ids_ptr: int, dists_ptr: int, flags_ptr: int, stream: int):
         """Asynchronous device-pointer call (vs_bf_search_dev): outputs are [B, k+1]."""
         _check(lib().vs_bf_search_dev(self._h, q_ptr, B, k, ids_ptr, dists_ptr, flags_ptr, stream))
@@ -302,6 +321,11 @@ class BruteForceIndex(_Index):
                          flags_ptr: int, stream: int):
         """n_batches consecutive batches of B queries, pipelined over internal streams (vs_bf_search_dev_multi)."""
         _check(lib().vs_bf_search_dev_multi(self._h, q_ptr, n_batches, B, k, ids_ptr, dists_ptr, flags_ptr, stream))
+
+    def search_dev_sharded(self, comm: "Comm", q_ptr: int, n_batches: int, B: int, k: int, ids_ptr: int, dists_ptr: int,
+                           flags_ptr: int, stream: int):
+        """Collective: this rank's row shard + ONE RCCL all-gather of top-(k+1) lists per launch group + device merge."""
+        _check(lib().vs_bf_search_dev_sharded(self._h, comm._c, q_ptr, n_batches, B, k, ids_ptr, dists_ptr, flags_ptr, stream))
 
     def scores_dev(self, q_ptr: int, B: int, scores_ptr: int, ld: int, stream: int):
         """QnnRunner::executeBatchRaw analogue: raw [B, ld] score matrix on the device."""
@@ -315,7 +339,7 @@ class IVFIndex(_Index):
                  vectors_reordered=None, centroids=None, cluster_offsets=None, reorder_to_original=None):
         super().__init__()
         if index_dir is not None:
-            _check(lib().vs_ivf_load(index_dir.encode(), device, rank, world, C.byref(self._h)))
+            _check(lib().vs_ivf_load(os.fspath(index_dir).encode(), device, rank, world, C.byref(self._h)))
         else:
             v = _f32c(vectors_reordered)
             c = _f32c(centroids)
@@ -359,6 +383,17 @@ class IVFIndex(_Index):
         _check(lib().vs_ivf_search(self._h, _p(q), nq, k, nprobe, _p(ids), _p(dists), C.byref(total), C.byref(tm)))
         return ids, dists, int(total.value)
 
+    def searchBatch_sharded(self, comm: "Comm", queries, k: int, nprobe: int):
+        """Collective host-buffer search over list shards (vs_ivf_search_sharded)."""
+        q = _f32c(queries).reshape(-1, self.d)
+        nq = q.shape[0]
+        ids = np.empty((nq, k), dtype=np.int32)
+        dists = np.empty((nq, k), dtype=np.float32)
+        total = C.c_int64(0)
+        tm = Timing()
+        _check(lib().vs_ivf_search_sharded(self._h, comm._c, _p(q), nq, k, nprobe, _p(ids), _p(dists), C.byref(total), C.byref(tm)))
+        return ids, dists, int(total.value)
+
     def search(self, query, k: int, nprobe: int):
         """IVFIndex::search (IVFIndex.h:25-26) for one query."""
         ids, dists, total = self.searchBatch(np.asarray(query).reshape(1, -1), 1, k, nprobe)
@@ -371,6 +406,42 @@ class IVFIndex(_Index):
                          stream: int):
         """n_batches independent batches [n_batches][B][128] -> [n_batches][B][k]; asynchronous on `stream`."""
         _check(lib().vs_ivf_search_dev_multi(self._h, q_ptr, n_batches, B, k, nprobe, ids_ptr, dists_ptr, stream))
+
+    def search_dev_sharded(self, comm: "Comm", q_ptr: int, n_batches: int, B: int, k: int, nprobe: int, ids_ptr: int,
+                           dists_ptr: int, stream: int):
+        """Collective: this rank's lists + ONE RCCL all-gather of top-k lists per launch group + device merge."""
+        _check(lib().vs_ivf_search_dev_sharded(self._h, comm._c, q_ptr, n_batches, B, k, nprobe, ids_ptr, dists_ptr, stream))
+
+
+class Comm:
+    """vs_comm: an RCCL communicator owned by the library (one process per GPU).  rank 0: ``uid = Comm.unique_id()``,
+    ship the bytes to the other ranks, then every rank: ``Comm(uid, rank, world, device)``."""
+
+    ID_BYTES = 128
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(Comm.ID_BYTES)
+        _check(lib().vs_comm_unique_id(buf))
+        return buf.raw
+
+    def __init__(self, unique_id: bytes, rank: int, world: int, device: int = 0):
+        self._c = C.c_void_p(None)
+        if len(unique_id) != Comm.ID_BYTES:
+            raise ValueError("unique_id must be VS_COMM_ID_BYTES bytes")
+        _check(lib().vs_comm_create(C.create_string_buffer(unique_id, Comm.ID_BYTES), rank, world, device, C.byref(self._c)))
+        self.rank, self.world = rank, world
+
+    def close(self):
+        if self._c:
+            lib().vs_comm_destroy(self._c)
+            self._c = C.c_void_p(None)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
 
 
 def topk_merge_dev(dists_ptr: int, ids_ptr: int, G: int, B: int, kin: int, kout: int, out_d_ptr: int,

@@ -6,6 +6,9 @@
 //   vsearch_bf <context_binary> <queries.fvecs> <results_dir> <backend.so> <documents.fvecs> <top_k> [batch]
 //                                              : the qidk_bruteforce form (main.cpp:73-85); the model and backend
 //                                                slots are accepted and ignored, results_dir gets results.txt + metrics.txt
+//   ... --gpus N                               : any form on N GPUs, one process per GPU (forked before HIP starts): the base
+//                                                is row-sharded, per-shard top-(k+1) lists meet in one RCCL all-gather per
+//                                                32 batches (vs_bf_search_sharded); rank 0 writes the files
 //
 // results: grammar of cpu_baseline.cpp:155-175.  metrics: sections of qidk_bruteforce main.cpp:321-390 with the
 // device's own stages in place of the NPU's (upload instead of quantisation, scan + top-k instead of graphExecute,
@@ -23,6 +26,7 @@
 #include <vector>
 
 #include "../../include/vsearch.hpp"
+#include "cli_ranks.hpp"
 
 namespace {
 
@@ -103,6 +107,8 @@ void write_metrics(const std::string& path, const RunStats& r) {
       << (100.0 - (scan_total + r.tm.h2d_ms + r.tm.tie_resolve_ms) / total_ms * 100.0) << "%\n";
 }
 
+vsearch::RankSet g_ranks;
+
 bool run_benchmark(const std::string& dataset_name, const std::string& base_file, const std::string& query_file, int k,
                    const std::string& output_file, const std::string& metrics_file, int batch) {
     using namespace std::chrono;
@@ -130,8 +136,14 @@ bool run_benchmark(const std::string& dataset_name, const std::string& base_file
     }
     try {
         std::cout << "Uploading base to HBM and pre-computing norms..." << std::endl;
-        vsearch::ExactSearch index(B_data, B_rows, B_dim);
-        index.setBatchSize(batch);
+        // --gpus N: this rank keeps rows [r0, r1) of the base on device `rank`
+        const int64_t r0 = vsearch::shard_bound(B_rows, g_ranks.world, g_ranks.rank);
+        const int64_t r1 = vsearch::shard_bound(B_rows, g_ranks.world, g_ranks.rank + 1);
+        if (r1 <= r0) throw std::runtime_error("more GPUs than 16-row tiles in the base");
+        vsearch::ExactSearch index(B_data.data() + (size_t)r0 * B_dim, r1 - r0, B_dim, r0, g_ranks.rank);
+        // the device scans at most 32 queries per pass: a model batch of 64 (run_all.sh's grid) is two passes
+        const int dev_batch = std::min(std::max(batch, 1), 32);
+        index.setBatchSize(dev_batch);
         std::vector<std::vector<vsearch::Result>> results;
         RunStats r;
         r.Q_rows = Q_rows;
@@ -141,7 +153,8 @@ bool run_benchmark(const std::string& dataset_name, const std::string& base_file
         r.batch = batch;
         vsearch::check(vs_prof_enable(index.handle(), 1));
         auto t0 = high_resolution_clock::now();
-        index.search(Q_data, Q_rows, k, results, &r.tm);
+        if (g_ranks.world > 1) index.searchSharded(g_ranks.comm, Q_data, Q_rows, k, results, &r.tm);
+        else index.search(Q_data, Q_rows, k, results, &r.tm);
         auto t1 = high_resolution_clock::now();
         r.total_s = duration_cast<duration<double>>(t1 - t0).count();
         {   // per-batch device times: launch l served min(32, remaining) batches
@@ -150,14 +163,23 @@ bool run_benchmark(const std::string& dataset_name, const std::string& base_file
             std::vector<double> ms((size_t)n);
             if (n > 0) vsearch::check(vs_prof_read_launches(index.handle(), 0, ms.data(), n, &n));
             std::vector<int> sizes;  // batches per scan launch, in launch order (vs_bf_search: chunks of 32 batches + ragged tail)
-            for (int left = Q_rows / batch; left > 0; left -= std::min(left, 32)) sizes.push_back(std::min(left, 32));
-            if (Q_rows % batch) sizes.push_back(1);
+            for (int left = Q_rows / dev_batch; left > 0; left -= std::min(left, 32)) sizes.push_back(std::min(left, 32));
+            if (Q_rows % dev_batch) sizes.push_back(1);
+            std::vector<double> pass_ms;
             for (size_t l = 0; l < sizes.size() && l < ms.size(); ++l)
-                for (int b = 0; b < sizes[l]; ++b) r.batch_ms.push_back(ms[l] / sizes[l]);
+                for (int b = 0; b < sizes[l]; ++b) pass_ms.push_back(ms[l] / sizes[l]);
+            const size_t per = (size_t)((batch + dev_batch - 1) / dev_batch);  // passes per model batch
+            for (size_t i = 0; i < pass_ms.size(); i += per) {
+                double t = 0;
+                for (size_t j = i; j < std::min(pass_ms.size(), i + per); ++j) t += pass_ms[j];
+                r.batch_ms.push_back(t);
+            }
             vsearch::check(vs_prof_enable(index.handle(), 0));
         }
 
+        if (g_ranks.rank != 0) return true;  // rank 0 reports and writes
         std::cout << "\n=== MI355X RAG Performance Metrics ===" << std::endl;
+        if (g_ranks.world > 1) std::cout << "  GPUs (row shards): " << g_ranks.world << std::endl;
         std::cout << "\nDataset Information:" << std::endl;
         std::cout << "  Number of queries: " << Q_rows << std::endl;
         std::cout << "  Number of documents: " << B_rows << std::endl;
@@ -205,8 +227,16 @@ std::string metrics_name(const std::string& out) {
 }  // namespace
 
 int main(int argc, char* argv[]) {
+    int status = 0;
+    try {
+        g_ranks = vsearch::fork_ranks(vsearch::take_gpus_flag(argc, argv));  // before anything touches HIP
+        vsearch::connect_ranks(g_ranks);
+    } catch (const std::exception& e) {
+        std::cerr << "FATAL ERROR: " << e.what() << std::endl;
+        return vsearch::join_ranks(g_ranks, 1);
+    }
     std::cout << "=== MI355X (gfx950) backend for k-NN Search ===" << std::endl;
-    std::cout << vs_version() << ", " << vs_device_count() << " HIP device(s)" << std::endl;
+    std::cout << vs_version() << ", " << vs_device_count() << " HIP device(s), " << g_ranks.world << " rank(s)" << std::endl;
     std::cout << "====================================\n" << std::endl;
     if (argc == 7 || argc == 8) {
         // qidk_bruteforce form (main.cpp:73-85); unlike cpu_baseline this one fails loudly (main.cpp:400-403)
@@ -216,7 +246,7 @@ int main(int argc, char* argv[]) {
         mkdir(results_dir.c_str(), 0755);
         if (!run_benchmark(argv[5], argv[5], argv[2], k, results_dir + "/results.txt", results_dir + "/metrics.txt", batch)) {
             std::cerr << "FATAL ERROR" << std::endl;
-            return 1;
+            status = 1;
         }
     } else if (argc >= 5) {
         const int k = std::stoi(argv[3]);
@@ -231,5 +261,5 @@ int main(int argc, char* argv[]) {
     std::cout << "\n========================================" << std::endl;
     std::cout << "All benchmarks completed!" << std::endl;
     std::cout << "========================================" << std::endl;
-    return 0;  // the reference always returns 0 (cpu_baseline.cpp:351)
+    return vsearch::join_ranks(g_ranks, status);  // single GPU: 0 like the reference (cpu_baseline.cpp:351), except the qidk form
 }

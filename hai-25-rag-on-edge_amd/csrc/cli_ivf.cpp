@@ -2,6 +2,9 @@
 //   vsearch_ivf <index_dir> <queries.fvecs> <results_dir> <backend.so> <top_k> [nprobe=16] [groundtruth.ivecs] [batch=1]
 // Writes <results_dir>/results.txt and metrics.txt in the reference's layouts.  The <backend.so>
 // slot is accepted and ignored (the reference passes libQnnHtp.so there).
+//   ... --gpus N : one process per GPU (forked before HIP starts); every rank loads the lists it owns (longest-first
+//   round robin), runs the same coarse stage and scans its lists; per-shard top-k lists meet in one RCCL all-gather per
+//   32 batches (vs_ivf_search_sharded); rank 0 writes the files ("Avg candidates" is then rank 0's share).
 #include <sys/stat.h>
 
 #include <algorithm>
@@ -13,20 +16,31 @@
 #include <vector>
 
 #include "../../include/vsearch.hpp"
+#include "cli_ranks.hpp"
 
 int main(int argc, char* argv[]) {
-    if (argc < 6) {
-        std::cerr << "Usage: " << argv[0]
-                  << " <index_dir> <queries.fvecs> <results_dir> <backend.so> <top_k> [nprobe] [groundtruth.ivecs] [batch]"
-                  << std::endl;
+    vsearch::RankSet ranks;
+    try {
+        ranks = vsearch::fork_ranks(vsearch::take_gpus_flag(argc, argv));  // before anything touches HIP
+    } catch (const std::exception& e) {
+        std::cerr << "FATAL ERROR: " << e.what() << std::endl;
         return 1;
+    }
+    if (argc < 6) {
+        if (ranks.rank == 0)
+            std::cerr << "Usage: " << argv[0]
+                      << " <index_dir> <queries.fvecs> <results_dir> <backend.so> <top_k> [nprobe] [groundtruth.ivecs] [batch] [--gpus N]"
+                      << std::endl;
+        return vsearch::join_ranks(ranks, 1);
     }
     const std::string index_dir = argv[1], query_file = argv[2], results_dir = argv[3], backend_path = argv[4];
     const int TOP_K = std::stoi(argv[5]);
     const int NPROBE = (argc > 6) ? std::stoi(argv[6]) : 16;  // main_ivf.cpp:76
     const std::string gt_file = (argc > 7) ? argv[7] : "";
     const int BATCH_SIZE = (argc > 8) ? std::stoi(argv[8]) : 1;  // main_ivf.cpp:78
+    int status = 0;
     try {
+        vsearch::connect_ranks(ranks);
         mkdir(results_dir.c_str(), 0755);
         const std::string results_txt = results_dir + "/results.txt", metrics_txt = results_dir + "/metrics.txt";
         std::cout << "Loading queries..." << std::endl;
@@ -41,12 +55,12 @@ int main(int argc, char* argv[]) {
             std::cout << "Loaded " << ground_truth.size() << " ground truth entries." << std::endl;
         }
         std::cout << "Loading IVF index..." << std::endl;
-        vsearch::IVFIndex ivf(index_dir, backend_path);
+        vsearch::IVFIndex ivf(index_dir, backend_path, ranks.rank, ranks.rank, ranks.world);
         if (query_dim != static_cast<int>(ivf.getDim()))
             throw std::runtime_error("Query dim (" + std::to_string(query_dim) + ") != index dim (" +
                                      std::to_string(ivf.getDim()) + ")");
         ivf.setBatchSize(std::min(std::max(BATCH_SIZE, 1), 32));
-        std::ofstream results_file(results_txt);
+        std::ofstream results_file(ranks.rank == 0 ? results_txt : std::string("/dev/null"));
         if (!results_file) throw std::runtime_error("Cannot open output file: " + results_txt);
 
         double total_centroid_ms = 0, total_gather_ms = 0, total_fine_ms = 0, total_search_ms = 0, total_recall = 0;
@@ -65,7 +79,8 @@ int main(int argc, char* argv[]) {
             std::vector<std::vector<float>> bs;
             vsearch::IVFIndex::SearchTiming timing;
             auto b0 = std::chrono::high_resolution_clock::now();
-            total_candidates += ivf.searchBatch(batch, (int)cur, TOP_K, NPROBE, bi, bs, timing);
+            if (ranks.world > 1) total_candidates += ivf.searchBatchSharded(ranks.comm, batch, (int)cur, TOP_K, NPROBE, bi, bs, timing);
+            else total_candidates += ivf.searchBatch(batch, (int)cur, TOP_K, NPROBE, bi, bs, timing);
             auto b1 = std::chrono::high_resolution_clock::now();
             const double call_ms = std::chrono::duration<double, std::milli>(b1 - b0).count();
             const size_t n_b = (cur + (size_t)std::max(BATCH_SIZE, 1) - 1) / (size_t)std::max(BATCH_SIZE, 1);
@@ -98,7 +113,7 @@ int main(int argc, char* argv[]) {
         const double p99 = latencies[static_cast<size_t>(latencies.size() * 0.99)];
         const double speedup_candidates = ivf.getNumVectors() / avg_candidates;
 
-        std::ofstream m(metrics_txt);
+        std::ofstream m(ranks.rank == 0 ? metrics_txt : std::string("/dev/null"));
         if (!m) throw std::runtime_error("Cannot open metrics file: " + metrics_txt);
         m << std::fixed << std::setprecision(6);
         m << "=== IVF Search Performance Metrics ===\n\n";
@@ -133,7 +148,7 @@ int main(int argc, char* argv[]) {
         std::cout << "Metrics saved to: " << metrics_txt << std::endl;
     } catch (const std::exception& e) {
         std::cerr << "FATAL ERROR: " << e.what() << std::endl;  // main_ivf.cpp:287-290
-        return 1;
+        status = 1;
     }
-    return 0;
+    return vsearch::join_ranks(ranks, status);
 }

@@ -5,6 +5,8 @@
 // staging) and a HIP stream.  Nothing here computes distances on the host: without a HIP device
 // every create/search call fails (VS_ERR_DEVICE).
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <chrono>
@@ -1178,8 +1180,13 @@ int vs_prof_read_launches(vs_index* h, int which, double* ms_out, int64_t cap, i
 }
 
 // ------------------------------------------------------------------------------------- brute force
+static int bf_create_impl(const float* base_host, int64_t n_rows, int dim, int metric, int device, int64_t id_offset, vs_index** out);
 int vs_bf_create(const float* base_host, int64_t n_rows, int dim, int metric, int device, int64_t id_offset,
                  vs_index** out) {
+    return guarded([&]() -> int { return bf_create_impl(base_host, n_rows, dim, metric, device, id_offset, out); });
+}
+static int bf_create_impl(const float* base_host, int64_t n_rows, int dim, int metric, int device, int64_t id_offset,
+                          vs_index** out) {
     if (!out || !base_host || n_rows <= 0) {
         set_error("vs_bf_create: bad arguments");
         return VS_ERR_INVALID;
@@ -1199,7 +1206,11 @@ int vs_bf_create(const float* base_host, int64_t n_rows, int dim, int metric, in
     int rc = check_device(device);
     if (rc) return rc;
     HIPCHK(hipSetDevice(device));
-    vs_index* h = new vs_index();
+    vs_index* h = new (std::nothrow) vs_index();
+    if (!h) {
+        set_error("out of host memory");
+        return VS_ERR_NOMEM;
+    }
     h->kind = 0;
     h->device = device;
     h->dim = dim;
@@ -1427,7 +1438,11 @@ static int ivf_create_impl(const float* vectors, int64_t n_rows, int dim, const 
     int rc = check_device(device);
     if (rc) return rc;
     HIPCHK(hipSetDevice(device));
-    vs_index* h = new vs_index();
+    vs_index* h = new (std::nothrow) vs_index();
+    if (!h) {
+        set_error("out of host memory");
+        return VS_ERR_NOMEM;
+    }
     h->kind = 1;
     h->device = device;
     h->dim = dim;
@@ -1524,8 +1539,16 @@ static int ivf_create_impl(const float* vectors, int64_t n_rows, int dim, const 
 
 // GPU index builder: Lloyd k-means on the scan kernel (assignment = the brute-force MFMA scan with the
 // centroids as "queries", 32 per pass) + deterministic fixed-point update.
+static int ivf_build_impl(const float* base_host, int64_t n_rows, int dim, int nlist, int max_iter, double tol, uint64_t seed,
+                          int device, float* centroids_out, int32_t* assign_out, int* iters_done);
 int vs_ivf_build(const float* base_host, int64_t n_rows, int dim, int nlist, int max_iter, double tol, uint64_t seed,
                  int device, float* centroids_out, int32_t* assign_out, int* iters_done) {
+    return guarded([&]() -> int {
+        return ivf_build_impl(base_host, n_rows, dim, nlist, max_iter, tol, seed, device, centroids_out, assign_out, iters_done);
+    });
+}
+static int ivf_build_impl(const float* base_host, int64_t n_rows, int dim, int nlist, int max_iter, double tol, uint64_t seed,
+                          int device, float* centroids_out, int32_t* assign_out, int* iters_done) {
     if (!base_host || !centroids_out || !assign_out || n_rows <= 0 || nlist <= 0 || nlist > n_rows || max_iter < 0) {
         set_error("vs_ivf_build: bad arguments");
         return VS_ERR_INVALID;
@@ -1710,8 +1733,10 @@ int vs_ivf_build_index(const float* base_host, int64_t n_rows, int dim, int nlis
 int vs_ivf_create(const float* vectors_reordered, int64_t n_rows, int dim, const float* centroids, int nlist,
                   const int32_t* cluster_offsets, const int32_t* reorder_to_original, int device, int rank, int world,
                   vs_index** out) {
-    return ivf_create_impl(vectors_reordered, n_rows, dim, centroids, nlist, cluster_offsets, reorder_to_original,
-                           device, rank, world, out);
+    return guarded([&]() -> int {
+        return ivf_create_impl(vectors_reordered, n_rows, dim, centroids, nlist, cluster_offsets, reorder_to_original, device, rank,
+                               world, out);
+    });
 }
 
 int vs_ivf_load(const char* index_dir, int device, int rank, int world, vs_index** out) {
@@ -1719,6 +1744,7 @@ int vs_ivf_load(const char* index_dir, int device, int rank, int world, vs_index
         set_error("vs_ivf_load: bad arguments");
         return VS_ERR_INVALID;
     }
+    return guarded([&]() -> int {
     const std::string dir(index_dir);
     vs::IvfConfig cfg;
     if (!vs::ivf_config_read(dir + "/ivf_config.json", cfg)) return VS_ERR_IO;
@@ -1764,10 +1790,16 @@ int vs_ivf_load(const char* index_dir, int device, int rank, int world, vs_index
         set_error("vector count does not match ivf_config.json");
         return VS_ERR_IO;
     }
+    for (int32_t v : r2o)
+        if (v < 0 || v >= n) {
+            set_error("reorder_to_original.npy holds an id outside [0, n_vectors)");
+            return VS_ERR_IO;
+        }
     int rc = ivf_create_impl(vecs.data(), n, (int)cfg.dim, cents.data(), (int)cfg.n_clusters, offsets.data(), r2o.data(),
                              device, rank, world, out);
     if (rc == VS_OK && cfg.avg_cluster_size > 0) (*out)->avg_cluster_size = cfg.avg_cluster_size;
     return rc;
+    });
 }
 
 int vs_ivf_save(vs_index* h, const char* index_dir) {
@@ -2008,6 +2040,386 @@ int vs_topk_merge_dev(const float* dists_dev, const int32_t* ids_dev, int G, int
     m.flags = flags_dev;
     HIPCHK(vs::launch_merge_layout(m, stride_g > 0 ? stride_g : (int64_t)B * kin, kin, static_cast<hipStream_t>(stream)));
     return VS_OK;
+}
+
+}  // extern "C"
+
+// --------------------------------------------------------------------------------------- multi-GPU
+// One process per GPU.  The only data-path collective of the hot path is the all-gather of per-shard top-k lists
+// (SURVEY.md 8e); it lives here, behind the ABI: a vs_comm owns an RCCL communicator, a stream for the collective
+// and two sets of exchange buffers, so that all-gather + merge of launch group g run beside the scan of group g + 1.
+// RCCL is bound at run time (dlopen of librccl.so.1: inside a PyTorch process that is the copy torch already loaded,
+// otherwise ROCm's), so single-GPU users of the library do not need it at all.
+namespace {
+
+struct RcclApi {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string err;
+};
+
+RcclApi& rccl() {
+    static RcclApi api = [] {
+        RcclApi a;
+        std::vector<std::string> names = {"librccl.so.1", "librccl.so"};
+        if (const char* rp = getenv("ROCM_PATH")) names.push_back(std::string(rp) + "/lib/librccl.so.1");
+        names.push_back("/opt/rocm/lib/librccl.so.1");
+        for (const std::string& n : names) {
+            a.lib = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL);
+            if (a.lib) break;
+            if (const char* e = dlerror()) a.err = e;
+        }
+        if (!a.lib) return a;
+        a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(dlsym(a.lib, "ncclGetUniqueId"));
+        a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(dlsym(a.lib, "ncclCommInitRank"));
+        a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(a.lib, "ncclCommDestroy"));
+        a.AllGather = reinterpret_cast<decltype(a.AllGather)>(dlsym(a.lib, "ncclAllGather"));
+        a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(a.lib, "ncclGetErrorString"));
+        if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllGather || !a.GetErrorString) {
+            a.err = "librccl is missing a required symbol";
+            a.lib = nullptr;
+        }
+        return a;
+    }();
+    return api;
+}
+
+int rccl_ready() {
+    if (rccl().lib) return VS_OK;
+    set_error("RCCL not available: " + rccl().err);
+    return VS_ERR_DEVICE;
+}
+
+#define NCCLCHK(expr)                                                                                  \
+    do {                                                                                               \
+        ncclResult_t _r = (expr);                                                                      \
+        if (_r != ncclSuccess) {                                                                       \
+            set_error(std::string(#expr) + ": " + rccl().GetErrorString(_r));                          \
+            return VS_ERR_DEVICE;                                                                      \
+        }                                                                                              \
+    } while (0)
+
+}  // namespace
+
+struct vs_comm {
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1, device = 0;
+    hipStream_t s_coll = nullptr;
+    hipEvent_t ev_scan[2] = {}, ev_coll[2] = {};
+    bool coll_used[2] = {false, false};
+    int32_t* d_loc[2] = {};   // this rank's lists of one launch group: [dists n*kin][ids n*kin] as 32-bit words
+    int32_t* d_gath[2] = {};  // [world] x the same
+    size_t cap_words = 0;     // per-rank capacity of d_loc
+};
+
+namespace {
+
+int comm_reserve(vs_comm* c, size_t words) {
+    if (c->cap_words >= words) return VS_OK;
+    HIPCHK(hipDeviceSynchronize());
+    for (int i = 0; i < 2; ++i) {
+        if (c->d_loc[i]) (void)hipFree(c->d_loc[i]);
+        if (c->d_gath[i]) (void)hipFree(c->d_gath[i]);
+        c->d_loc[i] = c->d_gath[i] = nullptr;
+    }
+    c->cap_words = 0;
+    for (int i = 0; i < 2; ++i) {
+        int rc;
+        if ((rc = dev_alloc(&c->d_loc[i], words))) return rc;
+        if ((rc = dev_alloc(&c->d_gath[i], words * (size_t)c->world))) return rc;
+    }
+    c->cap_words = words;
+    return VS_OK;
+}
+
+// groups of <= kMaxMulti batches: local top-kin of group g on `user` -> event -> (collective stream) all-gather + merge
+// into the caller's outputs; the local search of group g + 1 is enqueued on `user` right away and runs meanwhile.
+template <class LocalSearch>
+int sharded_groups(vs_index* h, vs_comm* c, int n_batches, int B, int kin, int kout, int32_t* ids_dev, float* dists_dev,
+                   int32_t* flags_dev, const int32_t* id_map_unused, hipStream_t user, LocalSearch local) {
+    (void)id_map_unused;
+    if (h->device != c->device) {
+        set_error("index and communicator live on different devices");
+        return VS_ERR_INVALID;
+    }
+    int rc = comm_reserve(c, (size_t)2 * kMaxMulti * 32 * kin);
+    if (rc) return rc;
+    int g = 0;
+    for (int b0 = 0; b0 < n_batches; b0 += kMaxMulti, ++g) {
+        const int nb = std::min(kMaxMulti, n_batches - b0);
+        const int buf = g & 1;
+        const size_t n = (size_t)nb * B;         // queries of the group
+        const size_t words = 2 * n * kin;        // per rank
+        if (c->coll_used[buf]) HIPCHK(hipStreamWaitEvent(user, c->ev_coll[buf], 0));  // group g - 2 is done with the buffers
+        float* loc_d = reinterpret_cast<float*>(c->d_loc[buf]);
+        int32_t* loc_i = c->d_loc[buf] + n * kin;
+        if ((rc = local(b0, nb, loc_d, loc_i, user))) return rc;
+        HIPCHK(hipEventRecord(c->ev_scan[buf], user));
+        HIPCHK(hipStreamWaitEvent(c->s_coll, c->ev_scan[buf], 0));
+        const int32_t* src = c->d_loc[buf];
+        if (c->world > 1) {
+            NCCLCHK(rccl().AllGather(c->d_loc[buf], c->d_gath[buf], words, ncclInt32, c->comm, c->s_coll));
+            src = c->d_gath[buf];
+        }
+        vs::MergeParams m{};
+        m.part_d = reinterpret_cast<const float*>(src);
+        m.part_i = src + n * kin;
+        m.G = c->world;
+        m.kin = kin;
+        m.nq = (int)n;
+        m.kout = kout;
+        m.out_d = dists_dev + (size_t)b0 * B * kout;
+        m.out_i = ids_dev + (size_t)b0 * B * kout;
+        m.flags = flags_dev ? flags_dev + (size_t)b0 * B : nullptr;
+        m.flag_empty = 1;
+        HIPCHK(vs::launch_merge_layout(m, (int64_t)words, kin, c->s_coll));
+        HIPCHK(hipEventRecord(c->ev_coll[buf], c->s_coll));
+        c->coll_used[buf] = true;
+    }
+    // the caller's stream continues after the last two groups' merges
+    for (int buf = 0; buf < 2; ++buf)
+        if (c->coll_used[buf]) HIPCHK(hipStreamWaitEvent(user, c->ev_coll[buf], 0));
+    return VS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vs_comm_unique_id(void* id_out) {
+    if (!id_out) {
+        set_error("vs_comm_unique_id: id_out is NULL");
+        return VS_ERR_INVALID;
+    }
+    int rc = rccl_ready();
+    if (rc) return rc;
+    ncclUniqueId id;
+    NCCLCHK(rccl().GetUniqueId(&id));
+    static_assert(sizeof(id) == VS_COMM_ID_BYTES, "ncclUniqueId size");
+    std::memcpy(id_out, &id, sizeof(id));
+    return VS_OK;
+}
+
+int vs_comm_create(const void* unique_id, int rank, int world, int device, vs_comm** out) {
+    if (!out || !unique_id || world < 1 || rank < 0 || rank >= world) {
+        set_error("vs_comm_create: bad arguments");
+        return VS_ERR_INVALID;
+    }
+    int rc = check_device(device);
+    if (rc) return rc;
+    if ((rc = rccl_ready())) return rc;
+    HIPCHK(hipSetDevice(device));
+    vs_comm* c = new (std::nothrow) vs_comm();
+    if (!c) {
+        set_error("out of host memory");
+        return VS_ERR_NOMEM;
+    }
+    c->rank = rank;
+    c->world = world;
+    c->device = device;
+    ncclUniqueId id;
+    std::memcpy(&id, unique_id, sizeof(id));
+    ncclResult_t r = rccl().CommInitRank(&c->comm, world, id, rank);
+    if (r != ncclSuccess) {
+        set_error(std::string("ncclCommInitRank: ") + rccl().GetErrorString(r));
+        delete c;
+        return VS_ERR_DEVICE;
+    }
+    hipError_t e = hipStreamCreateWithFlags(&c->s_coll, hipStreamNonBlocking);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+        e = hipEventCreateWithFlags(&c->ev_scan[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_coll[i], hipEventDisableTiming);
+    }
+    if (e != hipSuccess) {
+        set_error(std::string("vs_comm_create: ") + hipGetErrorString(e));
+        vs_comm_destroy(c);
+        return VS_ERR_DEVICE;
+    }
+    *out = c;
+    return VS_OK;
+}
+
+int vs_comm_rank(const vs_comm* c) { return c ? c->rank : -1; }
+int vs_comm_world(const vs_comm* c) { return c ? c->world : 0; }
+
+void vs_comm_destroy(vs_comm* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->s_coll) (void)hipStreamSynchronize(c->s_coll);
+    if (c->comm && rccl().lib) (void)rccl().CommDestroy(c->comm);
+    for (int i = 0; i < 2; ++i) {
+        if (c->d_loc[i]) (void)hipFree(c->d_loc[i]);
+        if (c->d_gath[i]) (void)hipFree(c->d_gath[i]);
+        if (c->ev_scan[i]) (void)hipEventDestroy(c->ev_scan[i]);
+        if (c->ev_coll[i]) (void)hipEventDestroy(c->ev_coll[i]);
+    }
+    if (c->s_coll) (void)hipStreamDestroy(c->s_coll);
+    delete c;
+}
+
+int vs_bf_search_dev_sharded(vs_index* h, vs_comm* c, const float* queries_dev, int n_batches, int B, int k, int32_t* ids_dev,
+                             float* dists_dev, int32_t* flags_dev, void* stream) {
+    if (!h || !c || h->kind != 0 || !queries_dev || !ids_dev || !dists_dev || n_batches < 1 || B < 1 || B > vs::kMaxBatch || k < 1) {
+        set_error("vs_bf_search_dev_sharded: bad arguments");
+        return VS_ERR_INVALID;
+    }
+    int rc = set_device(h);
+    if (rc) return rc;
+    const int k1 = k + 1;
+    if (!pick_kcap(k1)) {
+        set_error("k too large for the compiled scan kernels (k <= 15)");
+        return VS_ERR_UNSUPPORTED;
+    }
+    hipStream_t user = static_cast<hipStream_t>(stream);
+    if ((rc = order_begin(h, user))) return rc;
+    rc = sharded_groups(h, c, n_batches, B, k1, k1, ids_dev, dists_dev, flags_dev, nullptr, user,
+                        [&](int b0, int nb, float* loc_d, int32_t* loc_i, hipStream_t s) {
+                            return bf_launch(h, h->lane[0], queries_dev + (size_t)b0 * B * vs::kDim, nb, B, k1, loc_d, loc_i, h->d_flags, s);
+                        });
+    return rc ? rc : order_end(h, user);
+}
+
+int vs_ivf_search_dev_sharded(vs_index* h, vs_comm* c, const float* queries_dev, int n_batches, int B, int k, int nprobe,
+                              int32_t* ids_dev, float* dists_dev, void* stream) {
+    if (!h || !c || h->kind != 1 || !queries_dev || !ids_dev || !dists_dev || n_batches < 1 || B < 1 || B > vs::kMaxBatch || k < 1 ||
+        nprobe < 1) {
+        set_error("vs_ivf_search_dev_sharded: bad arguments");
+        return VS_ERR_INVALID;
+    }
+    nprobe = std::min(nprobe, h->nlist);  // IVFIndex.cpp:647
+    if (nprobe > kMaxNprobe || !pick_kcap(k)) {
+        set_error("nprobe > 256 or k > 16 not supported");
+        return VS_ERR_UNSUPPORTED;
+    }
+    if (h->world != c->world || h->rank != c->rank) {
+        set_error("the index was sharded for a different (rank, world) than the communicator's");
+        return VS_ERR_INVALID;
+    }
+    int rc = set_device(h);
+    if (rc) return rc;
+    hipStream_t user = static_cast<hipStream_t>(stream);
+    if ((rc = order_begin(h, user))) return rc;
+    const bool multi = ivf_multi_ok(h, k);
+    rc = sharded_groups(h, c, n_batches, B, k, k, ids_dev, dists_dev, nullptr, nullptr, user,
+                        [&](int b0, int nb, float* loc_d, int32_t* loc_i, hipStream_t s) -> int {
+                            const float* q = queries_dev + (size_t)b0 * B * vs::kDim;
+                            if (multi && nb > 1) return ivf_group_dev(h, q, nb, B, k, nprobe, loc_d, loc_i, s);
+                            int r2 = VS_OK;
+                            for (int b = 0; b < nb && !r2; ++b)
+                                r2 = ivf_batch_dev(h, q + (size_t)b * B * vs::kDim, B, k, nprobe, loc_d + (size_t)b * B * k,
+                                                   loc_i + (size_t)b * B * k, s, nullptr);
+                            return r2;
+                        });
+    return rc ? rc : order_end(h, user);
+}
+
+
+// Host-buffer forms of the sharded searches (what the CLIs call with --gpus N): every rank passes the same queries and
+// receives the same merged result.  Chunks of kMaxMulti batches: upload, vs_*_search_dev_sharded, download.
+int vs_bf_search_sharded(vs_index* h, vs_comm* c, const float* queries_host, int64_t nq, int k, int32_t* ids, float* dists,
+                         vs_timing* timing) {
+    if (!h || !c || h->kind != 0 || !queries_host || !ids || !dists || nq < 0 || k < 1) {
+        set_error("vs_bf_search_sharded: bad arguments");
+        return VS_ERR_INVALID;
+    }
+    return guarded([&]() -> int {
+        int rc = set_device(h);
+        if (rc) return rc;
+        const double t_start = now_ms();
+        vs_timing tm{};
+        const int k1 = k + 1;
+        if (!pick_kcap(k1)) {
+            set_error("k too large for the compiled scan kernels (k <= 15)");
+            return VS_ERR_UNSUPPORTED;
+        }
+        const int64_t chunk = (int64_t)kMaxMulti * h->batch;
+        std::vector<float> hd((size_t)chunk * k1);
+        std::vector<int32_t> hi((size_t)chunk * k1), hf((size_t)chunk);
+        const float inf = std::numeric_limits<float>::infinity();
+        for (int64_t q0 = 0; q0 < nq; q0 += chunk) {
+            const int64_t n = std::min<int64_t>(chunk, nq - q0);
+            const int full = (int)(n / h->batch), rem = (int)(n % h->batch);
+            HIPCHK(hipMemcpyAsync(h->d_q, queries_host + q0 * vs::kDim, (size_t)n * vs::kDim * sizeof(float), hipMemcpyHostToDevice, h->stream));
+            if (full && (rc = vs_bf_search_dev_sharded(h, c, h->d_q, full, h->batch, k, h->d_out_i, h->d_out_d, h->d_flags, h->stream))) return rc;
+            if (rem) {
+                const size_t o = (size_t)full * h->batch;
+                if ((rc = vs_bf_search_dev_sharded(h, c, h->d_q + o * vs::kDim, 1, rem, k, h->d_out_i + o * k1, h->d_out_d + o * k1,
+                                                   h->d_flags + o, h->stream)))
+                    return rc;
+            }
+            HIPCHK(hipMemcpyAsync(hd.data(), h->d_out_d, (size_t)n * k1 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipMemcpyAsync(hi.data(), h->d_out_i, (size_t)n * k1 * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipMemcpyAsync(hf.data(), h->d_flags, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            for (int64_t b = 0; b < n; ++b) {
+                if (hf[(size_t)b] == 2) {
+                    set_error("a query batch is not byte valued: call vs_set_precision(h, 1) on every rank (the sharded call has no fp32 rerun)");
+                    return VS_ERR_UNSUPPORTED;
+                }
+                for (int t = 0; t < k; ++t) {
+                    const int32_t id = hi[(size_t)b * k1 + t];
+                    ids[(q0 + b) * k + t] = id;
+                    float d = id >= 0 ? hd[(size_t)b * k1 + t] : inf;
+                    if (h->metric == VS_METRIC_IP && id >= 0) d = -d;
+                    dists[(q0 + b) * k + t] = d;
+                }
+                tm.tie_queries += hf[(size_t)b] == 1;  // reported, not re-resolved: ties come out in (dist, id) order
+            }
+        }
+        tm.total_ms = tm.fine_search_ms = now_ms() - t_start;
+        if (timing) *timing = tm;
+        return VS_OK;
+    });
+}
+
+int vs_ivf_search_sharded(vs_index* h, vs_comm* c, const float* queries_host, int64_t nq, int k, int nprobe, int32_t* ids,
+                          float* dists, int64_t* total_candidates, vs_timing* timing) {
+    if (!h || !c || h->kind != 1 || !queries_host || !ids || !dists || nq < 0 || k < 1 || k > 16 || nprobe < 1) {
+        set_error("vs_ivf_search_sharded: bad arguments");
+        return VS_ERR_INVALID;
+    }
+    return guarded([&]() -> int {
+        int rc = set_device(h);
+        if (rc) return rc;
+        const double t_start = now_ms();
+        vs_timing tm{};
+        HIPCHK(hipMemsetAsync(h->d_cand, 0, sizeof(unsigned long long), h->stream));
+        const int64_t chunk = (int64_t)kMaxMulti * h->batch;
+        std::vector<float> hd((size_t)chunk * k);
+        std::vector<int32_t> hi((size_t)chunk * k);
+        const float inf = std::numeric_limits<float>::infinity();
+        for (int64_t q0 = 0; q0 < nq; q0 += chunk) {
+            const int64_t n = std::min<int64_t>(chunk, nq - q0);
+            const int full = (int)(n / h->batch), rem = (int)(n % h->batch);
+            HIPCHK(hipMemcpyAsync(h->d_q, queries_host + q0 * vs::kDim, (size_t)n * vs::kDim * sizeof(float), hipMemcpyHostToDevice, h->stream));
+            if (full && (rc = vs_ivf_search_dev_sharded(h, c, h->d_q, full, h->batch, k, nprobe, h->d_out_i, h->d_out_d, h->stream))) return rc;
+            if (rem) {
+                const size_t o = (size_t)full * h->batch;
+                if ((rc = vs_ivf_search_dev_sharded(h, c, h->d_q + o * vs::kDim, 1, rem, k, nprobe, h->d_out_i + o * k, h->d_out_d + o * k,
+                                                    h->stream)))
+                    return rc;
+            }
+            HIPCHK(hipMemcpyAsync(hd.data(), h->d_out_d, (size_t)n * k * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipMemcpyAsync(hi.data(), h->d_out_i, (size_t)n * k * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            for (int64_t b = 0; b < n; ++b)
+                for (int t = 0; t < k; ++t) {
+                    const int32_t id = hi[(size_t)b * k + t];
+                    ids[(q0 + b) * k + t] = id;
+                    dists[(q0 + b) * k + t] = id >= 0 ? hd[(size_t)b * k + t] : inf;
+                }
+        }
+        unsigned long long cand = 0;  // rows THIS rank scanned (IVFIndex::searchBatch's return value, per shard)
+        HIPCHK(hipMemcpy(&cand, h->d_cand, sizeof(cand), hipMemcpyDeviceToHost));
+        if (total_candidates) *total_candidates = (int64_t)cand;
+        tm.total_ms = tm.fine_search_ms = now_ms() - t_start;
+        if (timing) *timing = tm;
+        return VS_OK;
+    });
 }
 
 }  // extern "C"

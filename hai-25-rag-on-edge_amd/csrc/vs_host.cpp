@@ -182,9 +182,29 @@ static bool npy_read_t(const std::string& path, const char* want_a, const char* 
         set_error("Fortran-ordered array not supported: " + path);
         return false;
     }
+    // the payload must be in the file: a corrupt or hostile shape is an I/O error, not an allocation
+    const std::streampos payload = file.tellg();
+    file.seekg(0, std::ios::end);
+    const int64_t remaining = (int64_t)(file.tellg() - payload);
+    file.seekg(payload);
     int64_t total = 1;
-    for (int64_t s : shape) total *= s;
-    data.resize((size_t)total);
+    for (int64_t s : shape) {
+        if (s < 0 || (s > 0 && total > remaining / s)) {  // total * s would exceed what the file can hold (or overflow)
+            set_error("Truncated .npy payload (shape larger than the file): " + path);
+            return false;
+        }
+        total *= s;
+    }
+    if (total > remaining / (int64_t)sizeof(T)) {
+        set_error("Truncated .npy payload: " + path);
+        return false;
+    }
+    try {
+        data.resize((size_t)total);
+    } catch (const std::bad_alloc&) {
+        set_error("out of host memory reading " + path);
+        return false;
+    }
     file.read(reinterpret_cast<char*>(data.data()), total * (int64_t)sizeof(T));
     if (file.gcount() != total * (int64_t)sizeof(T)) {
         set_error("Truncated .npy payload: " + path);

@@ -94,6 +94,7 @@ struct MergeParams {
     const int32_t* id_map;   // optional: out id = id_map[id] (IVF reorder_to_original)
     int q_group_out, q_group_in;  // output query q reads input query (q / out) * in + q % out (0 = identity)
     const int32_t* invalid;  // optional [nq / q_group_out]: batches skipped by the int8 scan -> flags = 2
+    int flag_empty;          // flags = 2 for a query with no finite entry at all (cross-GPU merge: every shard skipped its batch)
 };
 hipError_t launch_merge(const MergeParams& p, hipStream_t s);  // scan-partial layout [G][nq_stride][kin]
 // general layout: entry (g, q, j) at g*stride_g + q*stride_q + j

@@ -1239,6 +1239,7 @@ __global__ __launch_bounds__(256) void merge_kernel(const MergeParams p, const M
             int f = 0;
             for (int i = 0; i + 1 < n; ++i)
                 if (outd[i] == outd[i + 1] && outd[i] < VS_INF) f = 1;
+            if (p.flag_empty && !(outd[0] < VS_INF)) f = 2;
             p.flags[q] = f;
         }
         if (p.tau_out) {
@@ -1410,6 +1411,7 @@ __global__ __launch_bounds__(256) void merge_compact_kernel(const MergeParams p,
             int f = 0;
             for (int i = 0; i + 1 < n_track; ++i)
                 if (outd[i] == outd[i + 1] && outd[i] < VS_INF) f = 1;
+            if (p.flag_empty && !(outd[0] < VS_INF)) f = 2;
             p.flags[q] = f;
         }
         if (p.tau_out) {

@@ -224,6 +224,41 @@ VS_API int vs_topk_merge_dev(const float* dists_dev, const int32_t* ids_dev, int
                              int64_t stride_g, int kout, float* out_dists_dev, int32_t* out_ids_dev,
                              int32_t* flags_dev, void* stream);
 
+/* One process per GPU.  A vs_comm owns an RCCL communicator over the ranks of the job, a stream for
+ * the collective and the exchange buffers.  Bootstrap like any NCCL program: rank 0 calls vs_comm_unique_id and
+ * hands the VS_COMM_ID_BYTES bytes to the other ranks by whatever channel the host program has (MPI, a pipe, a file,
+ * torch.distributed's store), then EVERY rank calls vs_comm_create (collective).  RCCL is loaded on first use
+ * (dlopen of librccl.so.1): single-GPU users never need it.  The reference is single device; this replaces nothing
+ * there -- it is the north-star's "cluster-sharded IVF / row-sharded brute force over the 8 GPUs of a node". */
+#define VS_COMM_ID_BYTES 128
+typedef struct vs_comm vs_comm;
+VS_API int vs_comm_unique_id(void* id_out /* VS_COMM_ID_BYTES */);
+VS_API int vs_comm_create(const void* unique_id, int rank, int world, int device, vs_comm** out);
+VS_API int vs_comm_rank(const vs_comm* c);
+VS_API int vs_comm_world(const vs_comm* c);
+VS_API void vs_comm_destroy(vs_comm* c);
+
+/* Sharded search, collective over the communicator: every rank passes the SAME queries (device memory) and its own
+ * shard -- vs_bf_create(rows of this rank, id_offset = first row) or vs_ivf_create/load(..., rank, world) -- and every
+ * rank receives the merged global result.  Per launch group of up to 32 batches: local scan -> ONE ncclAllGather of
+ * the per-shard top-(k+1) [brute force] / top-k [IVF] lists (dists and ids as 32-bit words) -> device merge by
+ * (dist, id); all-gather + merge of group g run on the communicator's stream beside the local scan of group g + 1.
+ * Outputs and flags as vs_bf_search_dev_multi / vs_ivf_search_dev_multi (flags = 2: no shard produced a result for
+ * the query because the int8 path skipped its batch).  Asynchronous on `stream`. */
+VS_API int vs_bf_search_dev_sharded(vs_index* h, vs_comm* c, const float* queries_dev, int n_batches, int B, int k,
+                                    int32_t* ids_dev, float* dists_dev, int32_t* flags_dev, void* stream);
+VS_API int vs_ivf_search_dev_sharded(vs_index* h, vs_comm* c, const float* queries_dev, int n_batches, int B, int k,
+                                     int nprobe, int32_t* ids_dev, float* dists_dev, void* stream);
+
+/* Host-buffer forms (what the CLIs run with --gpus N): same contract, queries and results in host memory on every
+ * rank.  Brute force: a tie inside the k+1 best is counted in timing->tie_queries but comes out in (dist, id) order
+ * -- the exact select_topk replay needs all rows in one place and is single-GPU only (vs_bf_search).
+ * IVF: *total_candidates = rows scanned by THIS rank's shard. */
+VS_API int vs_bf_search_sharded(vs_index* h, vs_comm* c, const float* queries_host, int64_t nq, int k, int32_t* ids,
+                                float* dists, vs_timing* timing);
+VS_API int vs_ivf_search_sharded(vs_index* h, vs_comm* c, const float* queries_host, int64_t nq, int k, int nprobe,
+                                 int32_t* ids, float* dists, int64_t* total_candidates, vs_timing* timing);
+
 /* ------------------------------------------------------------------ profiling */
 /* HIP-event timing of the dominant scan kernel on the stream it is launched on
  * (bench.py's roofline leg).  which: 0 = brute-force scan, 1 = IVF list scan. */

@@ -72,6 +72,10 @@ public:
     ExactSearch(const std::vector<float>& base, int rows, int dim, int device = 0, int metric = VS_METRIC_L2) {
         check(vs_bf_create(base.data(), rows, dim, metric, device, 0, &h_));
     }
+    // one rank's row shard of a larger base: ids are shard rows + id_offset (multi-GPU, vs_bf_search_sharded)
+    ExactSearch(const float* shard, int64_t rows, int dim, int64_t id_offset, int device, int metric = VS_METRIC_L2) {
+        check(vs_bf_create(shard, rows, dim, metric, device, id_offset, &h_));
+    }
     ~ExactSearch() { vs_destroy(h_); }
     ExactSearch(const ExactSearch&) = delete;
     ExactSearch& operator=(const ExactSearch&) = delete;
@@ -86,6 +90,17 @@ public:
         std::vector<int32_t> ids((size_t)nq * k);
         std::vector<float> dists((size_t)nq * k);
         check(vs_bf_search(h_, queries.data(), nq, k, ids.data(), dists.data(), timing));
+        results.assign((size_t)nq, {});
+        for (int i = 0; i < nq; ++i)
+            for (int t = 0; t < k; ++t)
+                if (ids[(size_t)i * k + t] >= 0) results[(size_t)i].push_back({dists[(size_t)i * k + t], ids[(size_t)i * k + t]});
+    }
+    // collective over `comm` (every rank: same queries, own shard); ties come out in (dist, id) order
+    void searchSharded(vs_comm* comm, const std::vector<float>& queries, int nq, int k, std::vector<std::vector<Result>>& results,
+                       vs_timing* timing = nullptr) {
+        std::vector<int32_t> ids((size_t)nq * k);
+        std::vector<float> dists((size_t)nq * k);
+        check(vs_bf_search_sharded(h_, comm, queries.data(), nq, k, ids.data(), dists.data(), timing));
         results.assign((size_t)nq, {});
         for (int i = 0; i < nq; ++i)
             for (int t = 0; t < k; ++t)
@@ -150,6 +165,29 @@ public:
                 }
         timing.centroid_search_ms = tm.centroid_search_ms;
         timing.gather_ms = tm.gather_ms;
+        timing.fine_search_ms = tm.fine_search_ms;
+        timing.total_ms = tm.total_ms;
+        return (size_t)total;
+    }
+
+    // collective over `comm`: this index holds rank's lists (constructed with the same rank / world); returns the rows
+    // scanned by THIS rank
+    size_t searchBatchSharded(vs_comm* comm, const std::vector<float>& queries, int batchSize, int k, int nprobe,
+                              std::vector<std::vector<int>>& allIndices, std::vector<std::vector<float>>& allScores,
+                              SearchTiming& timing) {
+        std::vector<int32_t> ids((size_t)batchSize * k);
+        std::vector<float> dists((size_t)batchSize * k);
+        int64_t total = 0;
+        vs_timing tm{};
+        check(vs_ivf_search_sharded(h_, comm, queries.data(), batchSize, k, nprobe, ids.data(), dists.data(), &total, &tm));
+        allIndices.assign((size_t)batchSize, {});
+        allScores.assign((size_t)batchSize, {});
+        for (int b = 0; b < batchSize; ++b)
+            for (int t = 0; t < k; ++t)
+                if (ids[(size_t)b * k + t] >= 0) {
+                    allIndices[(size_t)b].push_back(ids[(size_t)b * k + t]);
+                    allScores[(size_t)b].push_back(dists[(size_t)b * k + t]);
+                }
         timing.fine_search_ms = tm.fine_search_ms;
         timing.total_ms = tm.total_ms;
         return (size_t)total;

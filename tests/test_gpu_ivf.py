@@ -407,3 +407,63 @@ def test_nlist1024_nprobe_8_and_32(gpu_pkg, nprobe):
     assert abs(oracle.recall(ids, gt, k) - oracle.recall(oi, gt, k)) <= 0.01
     if nprobe == 32:
         assert r1 >= 0.91  # the north-star's bar
+
+
+def test_library_collective_world_1_ivf(gpu_pkg):
+    """vs_ivf_search_dev_sharded / vs_ivf_search_sharded over a one-rank RCCL communicator == the unsharded calls."""
+    import torch
+    dev = torch.device("cuda:0")
+    base, cents, vr, off, r2o = _make_index(gpu_pkg, n=16000, nlist=64, seed=6)
+    nb, k, nprobe = 37, 5, 16
+    q = gpu_pkg.synth_sift(32 * nb, seed=68)
+    qd = torch.from_numpy(q).to(dev)
+    s = torch.cuda.current_stream().cuda_stream
+    with gpu_pkg.Comm(gpu_pkg.Comm.unique_id(), 0, 1, 0) as comm, \
+            gpu_pkg.IVFIndex(vectors_reordered=vr, centroids=cents, cluster_offsets=off, reorder_to_original=r2o) as ivf:
+        a_d = torch.zeros((nb * 32, k), dtype=torch.float32, device=dev)
+        a_i = torch.zeros((nb * 32, k), dtype=torch.int32, device=dev)
+        b_d, b_i = torch.zeros_like(a_d), torch.zeros_like(a_i)
+        ivf.search_dev_multi(qd.data_ptr(), nb, 32, k, nprobe, a_i.data_ptr(), a_d.data_ptr(), s)
+        ivf.search_dev_sharded(comm, qd.data_ptr(), nb, 32, k, nprobe, b_i.data_ptr(), b_d.data_ptr(), s)
+        torch.cuda.synchronize()
+        assert torch.equal(a_d, b_d)
+        a, b = a_i.cpu().numpy(), b_i.cpu().numpy()
+        for i in range(nb * 32):  # equal distances may swap ids between the two merges: compare as sets
+            assert sorted(a[i].tolist()) == sorted(b[i].tolist())
+        ids, d, total = ivf.searchBatch(q[:200], 200, k, nprobe)
+        sid, sd, stotal = ivf.searchBatch_sharded(comm, q[:200], k, nprobe)
+        assert np.array_equal(sd, d) and stotal == total
+
+
+def test_native_index_builder_end_to_end(gpu_pkg, tmp_path):
+    """vs_ivf_build_index -> vs_ivf_save -> vs_ivf_load with no Python in the layout step (create_ivf_model_reordered.py:
+    82-177): the directory holds the reference's files, the reordered layout is the stable sort by cluster of the
+    assignment, and the loaded index searches like the built one."""
+    base = gpu_pkg.synth_sift(30000, seed=61)
+    ivf, n_it = gpu_pkg.IVFIndex.build(base, 64, max_iter=5, seed=42)
+    with ivf:
+        assert ivf.getNumClusters() == 64 and ivf.getNumVectors() == 30000 and n_it >= 1
+        d = str(tmp_path / "idx")
+        ivf.save(d)
+        q = gpu_pkg.synth_sift(64, seed=62)
+        ids, dd, total = ivf.searchBatch(q, 64, 5, 8)
+    for f in ("ivf_config.json", "cluster_offsets.npy", "vectors_reordered.npy", "reorder_to_original.npy", "centroids.npy",
+              "cluster_sizes.npy"):
+        assert os.path.exists(os.path.join(d, f)), f
+    off = np.load(os.path.join(d, "cluster_offsets.npy"))
+    r2o = np.load(os.path.join(d, "reorder_to_original.npy"))
+    vr = np.load(os.path.join(d, "vectors_reordered.npy"))
+    cents = np.load(os.path.join(d, "centroids.npy"))
+    assert off[0] == 0 and off[-1] == 30000 and np.all(np.diff(off) >= 0)
+    assert np.array_equal(np.sort(r2o), np.arange(30000)) and np.array_equal(vr, base[r2o])
+    # every row sits in the list of its nearest centroid (float64 check, ties aside), rows of a list keep their order
+    x = base.astype(np.float64)
+    dist = (x ** 2).sum(1)[:, None] - 2 * x @ cents.astype(np.float64).T + (cents.astype(np.float64) ** 2).sum(1)[None]
+    lst = np.searchsorted(off, np.arange(30000), side="right") - 1
+    assert (dist.argmin(1)[r2o] == lst).mean() > 0.999
+    for c in range(64):
+        seg = r2o[off[c]:off[c + 1]]
+        assert np.all(np.diff(seg) > 0)
+    with gpu_pkg.IVFIndex(d) as ivf2:
+        ids2, dd2, total2 = ivf2.searchBatch(q, 64, 5, 8)
+    assert np.array_equal(ids2, ids) and np.array_equal(dd2, dd) and total2 == total

@@ -380,3 +380,63 @@ def test_cli_no_arguments_reproduces_reference_run(gpu_pkg, golden_dir, tmp_path
                    "P99 graph exec time:", "Avg GFLOPS:", "Per-Query Amortized Performance:", "Time Breakdown (% of end-to-end):"):
         assert needle in m, needle
     assert not os.path.exists(tmp_path / "sift_results.txt")
+
+
+def test_library_collective_world_1(gpu_pkg):
+    """vs_comm_* + vs_bf_search_dev_sharded / vs_bf_search_sharded with a one-rank RCCL communicator: the whole
+    in-library path (local scan -> ncclAllGather on the communicator's stream -> device merge, double-buffered over
+    launch groups) must reproduce the unsharded calls.  More ranks need more GPUs (driver's SCALE run)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    base = gpu_pkg.synth_sift(70000, seed=51)
+    nb = 70  # three launch groups: 32 + 32 + 6 -> both exchange buffers are reused
+    q = gpu_pkg.synth_sift(nb * 32, seed=52)
+    qd = torch.from_numpy(q).to(dev)
+    s = torch.cuda.current_stream().cuda_stream
+    with gpu_pkg.Comm(gpu_pkg.Comm.unique_id(), 0, 1, 0) as comm, gpu_pkg.BruteForceIndex(base) as idx:
+        for precision in (1, 0):
+            idx.set_precision(precision)
+            a_d = torch.zeros((nb * 32, 6), dtype=torch.float32, device=dev)
+            a_i = torch.zeros((nb * 32, 6), dtype=torch.int32, device=dev)
+            a_f = torch.zeros((nb * 32,), dtype=torch.int32, device=dev)
+            b_d, b_i, b_f = torch.zeros_like(a_d), torch.zeros_like(a_i), torch.zeros_like(a_f)
+            idx.search_dev_multi(qd.data_ptr(), nb, 32, 5, a_i.data_ptr(), a_d.data_ptr(), a_f.data_ptr(), s)
+            idx.search_dev_sharded(comm, qd.data_ptr(), nb, 32, 5, b_i.data_ptr(), b_d.data_ptr(), b_f.data_ptr(), s)
+            torch.cuda.synchronize()
+            assert torch.equal(a_d, b_d) and torch.equal(a_i, b_i) and torch.equal(a_f, b_f)
+        ids, d = idx.search(q[:300], 5)
+        tm = gpu_pkg.Timing()
+        sid, sd = idx.search_sharded(comm, q[:300], 5, tm)
+        assert np.array_equal(sd, d)
+        unflagged = np.array([len(set(d[i])) == 5 for i in range(300)])
+        assert np.array_equal(sid[unflagged], ids[unflagged])
+
+
+def test_bf_batch_sweep_driver_end_to_end(gpu_pkg, golden_dir, tmp_path):
+    """scripts/sweep_bf.py = qidk_bruteforce/scripts/run_all.sh on this backend: batch grid {1, 8, 16, 32, 64}, one CLI
+    run each (qidk argument form), CSV with the reference's columns; every run's results.txt is the reference's."""
+    import csv
+    import subprocess
+    import sys
+    z = np.load(os.path.join(golden_dir, "ref_synth10k_inputs.npz"))
+    os.makedirs(tmp_path / "siftsmall")
+    gpu_pkg.write_fvecs(str(tmp_path / "siftsmall" / "siftsmall_base.fvecs"), z["base"].astype(np.float32))
+    gpu_pkg.write_fvecs(str(tmp_path / "siftsmall" / "siftsmall_query.fvecs"), z["query"].astype(np.float32))
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = gpu_pkg.hip_runtime_dir() + os.pathsep + env.get("LD_LIBRARY_PATH", "")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "sweep_bf.py"), "--datasets", "siftsmall", "sift",
+                        "--data-root", str(tmp_path), "--out", str(tmp_path / "results")], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert "dataset sift:" in r.stdout and "skipped" in r.stdout
+    csvs = [f for f in os.listdir(tmp_path / "results") if f.endswith(".csv")]
+    rows = list(csv.DictReader(open(tmp_path / "results" / csvs[0])))
+    assert [int(x["batch_size"]) for x in rows] == [1, 8, 16, 32, 64]
+    ref = open(os.path.join(golden_dir, "ref_synth10k_results.txt")).read()
+    for x in rows:
+        assert float(x["throughput_qps"]) > 0 and float(x["gflops"]) > 0 and float(x["avg_latency_ms"]) > 0
+        b = int(x["batch_size"])
+        rdir = tmp_path / "results" / ("siftsmall" if b == 1 else f"siftsmall_b{b}")
+        assert open(rdir / "results.txt").read() == ref
+        assert f"Batch size: {b}" in open(rdir / "metrics.txt").read()

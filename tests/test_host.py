@@ -4,6 +4,7 @@ compute entry point fails loudly when there is no GPU (no CPU fallback)."""
 import ctypes as C
 import os
 import re
+import sys
 import subprocess
 
 import numpy as np
@@ -189,3 +190,58 @@ def test_sweep_metrics_parser_reads_the_cli_layout():
                  "p95_latency_ms": "0.400000", "p99_latency_ms": "0.500000", "avg_candidates": "1234.500000",
                  "candidate_reduction": "8.100000"}
     assert mod.COLUMNS[:3] == ["dataset", "nprobe", "top_k"] and len(mod.COLUMNS) == 11
+
+
+def test_index_layout_is_stable_sort_by_cluster(pkg):
+    """vs_ivf_layout / vs_ivf_clamp_nlist (host side of create_ivf_model_reordered.py:92-94, :108-128) against numpy."""
+    rng = np.random.default_rng(5)
+    for n, nlist in ((1, 1), (50, 7), (10000, 64), (4097, 1024)):
+        a = rng.integers(0, nlist, size=n).astype(np.int32)
+        x = rng.standard_normal((n, 4)).astype(np.float32)
+        vr, off, order = pkg.ivf_layout_from_assignment(x, a, nlist)
+        ref = np.argsort(a, kind="stable")
+        assert np.array_equal(order, ref) and np.array_equal(vr, x[ref])
+        assert np.array_equal(off[1:], np.cumsum(np.bincount(a, minlength=nlist)))
+    with pytest.raises(pkg.VSearchError):
+        pkg.ivf_layout_from_assignment(np.zeros((3, 4), np.float32), np.array([0, 5, 1], dtype=np.int32), 4)
+    assert pkg.clamp_nlist(1_000_000, 1024) == 1024 and pkg.clamp_nlist(10_000, 1024) == 100 and pkg.clamp_nlist(500, 256) == 16
+
+
+def test_corrupt_npy_header_is_an_error_not_an_exception(pkg, tmp_path):
+    """A hostile shape in a .npy header must come back as VS_ERR_IO through the C ABI (no C++ exception, no giant allocation)."""
+    d = _write_index(tmp_path)
+    p = os.path.join(d, "centroids.npy")
+    raw = open(p, "rb").read()
+    hl = int.from_bytes(raw[8:10], "little")
+    hdr = raw[10:10 + hl].decode()
+    bad = hdr.replace("(4, 128)", "(400000000000, 128)")
+    bad = bad[:hl - 1].ljust(hl - 1) + "\n"
+    open(p, "wb").write(raw[:10] + bad.encode() + raw[10 + hl:])
+    with pytest.raises(pkg.VSearchError) as e:
+        pkg.IVFIndex(d)
+    assert e.value.status in (-2, -4)
+
+
+def test_comm_argument_validation(pkg):
+    L = pkg.lib()
+    import ctypes as C
+    out = C.c_void_p(None)
+    assert L.vs_comm_create(None, 0, 1, 0, C.byref(out)) == -1
+    buf = C.create_string_buffer(128)
+    assert L.vs_comm_create(buf, 2, 2, 0, C.byref(out)) == -1  # rank out of range
+    if pkg.device_count() == 0:
+        assert L.vs_comm_create(buf, 0, 1, 0, C.byref(out)) == -3  # no device: no communicator, no fallback
+
+
+def test_bf_sweep_metrics_parser_reads_the_cli_layout():
+    """scripts/sweep_bf.py greps the same lines out of metrics.txt as run_all.sh:87-91 does."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import sweep_bf
+    text = ("Overall Performance:\n  Total execution time: 0.010000 s\n  Throughput: 123456.500000 queries/sec\n\n"
+            "GPU Execution (per batch):\n  Avg upload time: 0.001 ms\n  Avg graph execute time: 0.085000 ms\n"
+            "  P50 graph exec time: 0.084 ms\n  P95 graph exec time: 0.090000 ms\n  P99 graph exec time: 0.095000 ms\n\n"
+            "GPU Performance (per batch):\n  Avg GFLOPS: 96000.250000\n")
+    m = sweep_bf.parse_metrics(text)
+    assert m == {"throughput_qps": "123456.500000", "gflops": "96000.250000", "avg_latency_ms": "0.085000",
+                 "p95_latency_ms": "0.090000", "p99_latency_ms": "0.095000"}
+    assert sweep_bf.COLUMNS == ["dataset", "batch_size", "throughput_qps", "gflops", "avg_latency_ms", "p95_latency_ms", "p99_latency_ms"]
