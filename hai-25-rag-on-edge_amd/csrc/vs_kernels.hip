@@ -1617,6 +1617,16 @@ __device__ __forceinline__ float dpp_add_xor1(float x);
 __device__ __forceinline__ float dpp_add_xor2(float x);
 __device__ __forceinline__ float dpp_add_half_mirror(float x);
 
+// order-preserving map float -> unsigned (for atomicMin on distances of either sign)
+__device__ __forceinline__ unsigned f32_ordered(float x) {
+    const unsigned b = __builtin_bit_cast(unsigned, x);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float f32_unordered(unsigned u) {
+    const unsigned b = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    return __builtin_bit_cast(float, b);
+}
+
 // multi-batch launches: advance a per-batch pointer to batch blockIdx.y's copy (see IvfMulti)
 template <class T>
 __device__ __forceinline__ T* mb_adv(T* ptr, long long bytes) {
@@ -1703,70 +1713,75 @@ __global__ __launch_bounds__(256) void ivf_pick_kernel(const float* __restrict__
         probes = mb_adv(probes, y * grp.mb.slab);
         grp.qoff = mb_adv(grp.qoff, y * grp.mb.slab);
     }
+    // (score, list) pairs are compared as ONE 64-bit key (ordered float bits << 32 | list): the counting loops below
+    // then read two keys per 16-byte LDS load and cost one compare each
+    typedef unsigned long long u64;
+    typedef u64 u64x2 __attribute__((ext_vector_type(2)));
     __shared__ int s_probe[256];
-    __shared__ float mn_d[256];
-    __shared__ int mn_i[256];
-    __shared__ float cd[256 * EPT];
-    __shared__ int ci[256 * EPT];
-    __shared__ float s_td;
-    __shared__ int s_ti, s_cnt;
+    __shared__ __attribute__((aligned(16))) u64 mnk[256];
+    __shared__ __attribute__((aligned(16))) u64 cdk[256 * EPT + 2];
+    __shared__ u64 s_tk;
+    __shared__ int s_cnt;
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
     if (tid == 0) {
         s_cnt = 0;
-        s_td = VS_INF;
-        s_ti = 0x7fffffff;
+        s_tk = ~0ull;
     }
-    float md = VS_INF;
-    int mi = 0x7fffffff;
-    float mine[EPT];
+    u64 mine[EPT];
+    u64 mk = ~0ull;
     const float* sc = scores + (int64_t)b * ld;
+    float v[EPT];
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
         const int idx = tid + 256 * e;
-        mine[e] = idx < nlist ? sc[idx] : VS_INF;
+        v[e] = idx < nlist ? sc[idx] : VS_INF;
     }
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
         const int idx = tid + 256 * e;
-        if (idx < nlist && lex_lt(mine[e], idx, md, mi)) {
-            md = mine[e];
-            mi = idx;
-        }
+        mine[e] = idx < nlist ? (((u64)f32_ordered(v[e]) << 32) | (unsigned)idx) : ~0ull;
+        mk = mine[e] < mk ? mine[e] : mk;
     }
-    mn_d[tid] = md;
-    mn_i[tid] = mi;
+    mnk[tid] = mk;
     __syncthreads();
     {
         int rank = 0;
-        for (int j = 0; j < 256; ++j) rank += lex_lt(mn_d[j], mn_i[j], md, mi) ? 1 : 0;
-        if (rank == nprobe - 1) {  // unique: the order is strict
-            s_td = md;
-            s_ti = mi;
+        const u64x2* p2 = reinterpret_cast<const u64x2*>(mnk);
+#pragma unroll 8
+        for (int j = 0; j < 128; ++j) {
+            const u64x2 w = p2[j];
+            rank += (w.x < mk ? 1 : 0) + (w.y < mk ? 1 : 0);
         }
+        if (rank == nprobe - 1 && mk != ~0ull) s_tk = mk;  // unique: keys are distinct
     }
     __syncthreads();
     {
-        const float td = s_td;
-        const int ti = s_ti;
+        const u64 tk = s_tk;
 #pragma unroll
-        for (int e = 0; e < EPT; ++e) {
-            const int idx = tid + 256 * e;
-            if (idx < nlist && !lex_lt(td, ti, mine[e], idx)) {  // (d, idx) <= bound
+        for (int e = 0; e < EPT; ++e)
+            if (mine[e] != ~0ull && mine[e] <= tk) {
                 const int pos = atomicAdd(&s_cnt, 1);
-                cd[pos] = mine[e];
-                ci[pos] = idx;
+                cdk[pos] = mine[e];
             }
-        }
     }
     __syncthreads();
     const int C = s_cnt;
+    if (tid == 0) {  // pad to an even count for the paired reads
+        cdk[C] = ~0ull;
+        cdk[C + 1] = ~0ull;
+    }
+    __syncthreads();
     for (int c = tid; c < C; c += 256) {
-        const float d = cd[c];
-        const int id = ci[c];
+        const u64 key = cdk[c];
         int rank = 0;
-        for (int j = 0; j < C; ++j) rank += lex_lt(cd[j], ci[j], d, id) ? 1 : 0;
+        const u64x2* p2 = reinterpret_cast<const u64x2*>(cdk);
+        for (int j = 0; j < (C + 1) / 2; ++j) {
+            const u64x2 w = p2[j];
+            rank += (w.x < key ? 1 : 0) + (w.y < key ? 1 : 0);
+        }
         if (rank < nprobe) {
+            const int id = (int)(unsigned)(key & 0xffffffffull);
             probes[(int64_t)b * nprobe + rank] = id;
             s_probe[rank] = id;
         }
@@ -1944,6 +1959,7 @@ __global__ __launch_bounds__(256) void ivf_scan_kernel(const IvfScanParams p) {
 // through global atomics and a last-arriver, the grouping cost grew with the number of batches in flight), then
 // the plan of the list scan is written: the 32-row units of every chunk whose list is probed by some query.
 // ------------------------------------------------------------------------------------------------
+constexpr int kPlanSplit = 8;  // workgroups per batch: each writes the unit records of a slice of the chunk table
 __global__ __launch_bounds__(1024) void ivf_group_plan_kernel(const int32_t* __restrict__ probes, int B, int nlist, int nprobe,
                                                               IvfGroup grp) {
     {   // multi-batch launch: this workgroup's batch
@@ -1960,9 +1976,12 @@ __global__ __launch_bounds__(1024) void ivf_group_plan_kernel(const int32_t* __r
     __shared__ int s_carry;
     __shared__ int s_wtot[16];
     const int tid = threadIdx.x;
+    const bool first = blockIdx.x == 0;  // the slice that also writes the lists' query sets
     for (int c = tid; c < nlist; c += 1024) cnt_s[c] = 0;
     if (tid == 0) s_carry = 0;
     __syncthreads();
+    // every slice counts the queries per list (it needs them for its unit records); the slot a query takes in its list's
+    // set is whatever slice 0 hands out -- only that slice writes lq / lbase
     for (int e = tid; e < B * nprobe; e += 1024) {
         const int b = e / nprobe, pp = e - b * nprobe;
         const int c = probes[(int64_t)b * nprobe + pp];
@@ -1970,17 +1989,36 @@ __global__ __launch_bounds__(1024) void ivf_group_plan_kernel(const int32_t* __r
         const int o0 = grp.qoff[(int64_t)b * (kIvfMaxProbe + 1) + pp], o1 = grp.qoff[(int64_t)b * (kIvfMaxProbe + 1) + pp + 1];
         if (o1 == o0) continue;  // empty (or not resident) list
         const int slot = atomicAdd(&cnt_s[c], 1);  // < 32: a list is probed at most once per query, B <= 32
-        grp.lq[c * kMaxBatch + slot] = b;
-        grp.lbase[c * kMaxBatch + slot] = (int64_t)b * grp.cand_stride + o0;
+        if (first) {
+            grp.lq[c * kMaxBatch + slot] = b;
+            grp.lbase[c * kMaxBatch + slot] = (int64_t)b * grp.cand_stride + o0;
+        }
     }
     __syncthreads();
-    for (int c = tid; c < nlist; c += 1024) grp.lcnt[c] = cnt_s[c];
+    if (first)
+        for (int c = tid; c < nlist; c += 1024) grp.lcnt[c] = cnt_s[c];
     if (!grp.units) return;
     const int pl = tid & 63, wv = tid >> 6;
-    for (int base = 0; base < grp.n_chunks; base += 1024) {
+    const int nsl = (int)gridDim.x;
+    const int c0 = (int)((long long)grp.n_chunks * blockIdx.x / nsl), c1 = (int)((long long)grp.n_chunks * (blockIdx.x + 1) / nsl);
+    auto units_of = [&](int chunk) { return cnt_s[grp.chunk_list[chunk]] > 0 ? (grp.chunk_rows[chunk] + 31) >> 5 : 0; };
+    {   // units of the chunks in front of this slice
+        int pre = 0;
+        for (int chunk = tid; chunk < c0; chunk += 1024) pre += units_of(chunk);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) pre += __shfl_xor(pre, o);
+        if (pl == 0) s_wtot[wv] = pre;
+        __syncthreads();
+        if (tid == 0) {
+            int t = 0;
+            for (int w = 0; w < 16; ++w) t += s_wtot[w];
+            s_carry = t;
+        }
+        __syncthreads();
+    }
+    for (int base = c0; base < c1; base += 1024) {
         const int chunk = base + tid;
-        int nu = 0;
-        if (chunk < grp.n_chunks && cnt_s[grp.chunk_list[chunk]] > 0) nu = (grp.chunk_rows[chunk] + 31) >> 5;
+        const int nu = chunk < c1 ? units_of(chunk) : 0;
         int incl = nu;  // inclusive wave scan
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -2010,7 +2048,7 @@ __global__ __launch_bounds__(1024) void ivf_group_plan_kernel(const int32_t* __r
         if (tid == 0) s_carry += tot;
         __syncthreads();
     }
-    if (tid == 0) *grp.n_units = s_carry;
+    if (tid == 0 && (int)blockIdx.x == nsl - 1) *grp.n_units = s_carry;  // the last slice ends at the total
 }
 
 hipError_t launch_ivf_coarse_pick(const float* q, int B, const float* cents, const float* cnorm, int nlist, int nprobe,
@@ -2027,7 +2065,7 @@ hipError_t launch_ivf_coarse_pick(const float* q, int B, const float* cents, con
 // grouping + work plan: one workgroup per batch
 hipError_t launch_ivf_group_plan(const int32_t* probes, int B, int nlist, int nprobe, const IvfGroup& grp, hipStream_t s, int n_batches) {
     if (!grp.lcnt) return hipSuccess;
-    hipLaunchKernelGGL(ivf_group_plan_kernel, dim3(1, n_batches), dim3(1024), 0, s, probes, B, nlist, nprobe, grp);
+    hipLaunchKernelGGL(ivf_group_plan_kernel, dim3(n_batches > 1 ? kPlanSplit : 2 * kPlanSplit, n_batches), dim3(1024), 0, s, probes, B, nlist, nprobe, grp);
     return hipGetLastError();
 }
 
@@ -2040,16 +2078,6 @@ hipError_t launch_ivf_group_plan(const int32_t* probes, int B, int nlist, int np
 // here: they go to the query's candidate-score array in probe order (computeDotProductsContiguous
 // writes `scores[i]` the same way, IVFIndex.cpp:313-320) and ivf_select_kernel picks the top-k.
 // ------------------------------------------------------------------------------------------------
-// order-preserving map float -> unsigned (for atomicMin on distances of either sign)
-__device__ __forceinline__ unsigned f32_ordered(float x) {
-    const unsigned b = __builtin_bit_cast(unsigned, x);
-    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-}
-__device__ __forceinline__ float f32_unordered(unsigned u) {
-    const unsigned b = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
-    return __builtin_bit_cast(float, b);
-}
-
 constexpr int kIvfScanThreads = 1024;  // 16 waves: a popular list's rows are spread thin
 
 __global__ __launch_bounds__(kIvfScanThreads) void ivf_list_scan_kernel(const IvfListScanParams p, int n_chunks) {
@@ -2582,7 +2610,7 @@ __global__ __launch_bounds__(256) void ivf_select_kernel(IvfSelectParams p) {
         const unsigned u = p.slotmin ? 0u : p.tq[q];  // bound from ivf_bound_kernel (0 = none)
         s_t = u ? f32_unordered(~u) : VS_INF;
     }
-    __shared__ float s_mn[256];
+    __shared__ __attribute__((aligned(16))) float s_mn[256];
     __shared__ int s_blk[1024];
     __shared__ int s_nblk;
     const unsigned* bk = p.bkt ? p.bkt + (long long)q * p.nbk : nullptr;
@@ -2605,7 +2633,13 @@ __global__ __launch_bounds__(256) void ivf_select_kernel(IvfSelectParams p) {
     if (bk) {
         const float v = s_mn[tid];
         int rank = 0;
-        for (int j = 0; j < 256; ++j) rank += (s_mn[j] < v || (s_mn[j] == v && j < tid)) ? 1 : 0;
+        const f32x4* m4 = reinterpret_cast<const f32x4*>(s_mn);
+#pragma unroll 8
+        for (int j4 = 0; j4 < 64; ++j4) {
+            const f32x4 w = m4[j4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) rank += (w[e] < v || (w[e] == v && 4 * j4 + e < tid)) ? 1 : 0;
+        }
         if (rank == min(p.k, 256) - 1) s_t = v;
     }
     if (!bk && p.slotmin && tid < kIvfSlots) {
@@ -2689,13 +2723,23 @@ __global__ __launch_bounds__(256) void ivf_select_kernel(IvfSelectParams p) {
         // one workgroup per query: the candidates are ranked where they are (LDS), no hand-off
         slow = C > 1024;
         if (!slow) {
+            // (dist, position) as one 64-bit key: two keys per 16-byte LDS read, one compare each
+            typedef unsigned long long u64;
+            typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+            __shared__ __attribute__((aligned(16))) u64 ck[1024 + 2];
+            for (int c = tid; c < C + 2; c += 256) ck[c] = c < C ? (((u64)f32_ordered(cd[c]) << 32) | (unsigned)cpos[c]) : ~0ull;
+            __syncthreads();
             for (int c = tid; c < C; c += 256) {
-                const float d = cd[c];
-                const int id = cpos[c];
+                const u64 key = ck[c];
                 int rank = 0;
-                for (int j = 0; j < C; ++j) rank += lex_lt(cd[j], cpos[j], d, id) ? 1 : 0;
+                const u64x2* p2 = reinterpret_cast<const u64x2*>(ck);
+                for (int j = 0; j < (C + 1) / 2; ++j) {
+                    const u64x2 w = p2[j];
+                    rank += (w.x < key ? 1 : 0) + (w.y < key ? 1 : 0);
+                }
                 if (rank < p.k) {
-                    p.out_d[(int64_t)q * p.k + rank] = d;
+                    const int id = cpos[c];
+                    p.out_d[(int64_t)q * p.k + rank] = cd[c];
                     p.out_i[(int64_t)q * p.k + rank] = p.id_map ? p.id_map[id] : id;
                 }
             }
