@@ -40,6 +40,7 @@ constexpr int kMaxNprobe = 256;
 constexpr int kSlotWords = 32 * vs::kIvfSlots;  // per-batch slot minima of the IVF list scan (in the zeroed block)
 constexpr int kMaxLanes = 4;
 constexpr int kMaxMulti = 32;  // batches per persistent scan launch
+constexpr int kWideCap = 2048;    // candidate slots per query of the wide int8 scan (more: the batch is rerun in fp32)
 constexpr int kTieDense = 4096;   // rows whose distances the tie resolver takes densely
 constexpr int kTieCap = 8192;     // candidate slots per flagged query (more: full-row fallback)
 
@@ -99,6 +100,12 @@ struct vs_index {
         float* seed_qnorm = nullptr; // [kMaxMulti][32]   scratch of launch_seed
         float* seed_wmin = nullptr;  // [kMaxMulti][kSeedWaves][32]
         float* tau0 = nullptr;       // [kMaxMulti][32]   bounds of the current multi-batch launch
+        // wide int8 scan (several batches per pass over the rows): prepared queries + per-query candidate lists
+        int8_t* q8 = nullptr;        // [kMaxMulti][32][128]
+        int32_t* qterm = nullptr;    // [kMaxMulti][32]
+        int32_t* wcnt = nullptr;     // [kMaxMulti][32]
+        float* wcand_d = nullptr;    // [kMaxMulti][32][kWideCap]
+        int32_t* wcand_i = nullptr;
     };
     Lane lane[kMaxLanes];
     int n_lanes = 1;
@@ -219,6 +226,9 @@ void free_all(vs_index* h) {
         if (L.seed_qnorm) (void)hipFree(L.seed_qnorm);
         if (L.seed_wmin) (void)hipFree(L.seed_wmin);
         if (L.tau0) (void)hipFree(L.tau0);
+        void* wide[] = {L.q8, L.qterm, L.wcnt, L.wcand_d, L.wcand_i};
+        for (void* w : wide)
+            if (w) (void)hipFree(w);
         if (L.done_ev) (void)hipEventDestroy(L.done_ev);
         if (L.s) (void)hipStreamDestroy(L.s);
     }
@@ -504,6 +514,25 @@ int g_seed_i8 = [] {
     return e ? atoi(e) : 1;
 }();
 
+// tuning knob (VSEARCH_I8_WIDE): query column blocks per pass of the wide int8 scan (8 = four 32-query batches share one
+// pass over the rows, 4 = two, 0 = off: the per-batch int8 scan)
+int g_i8_wide = [] {
+    const char* e = getenv("VSEARCH_I8_WIDE");
+    const int v = e ? atoi(e) : 8;
+    return v >= 8 ? 8 : (v >= 4 ? 4 : 0);
+}();
+
+int ensure_wide(vs_index::Lane& L) {
+    if (L.q8) return VS_OK;
+    int rc;
+    if ((rc = dev_alloc(&L.q8, (size_t)kMaxMulti * 32 * vs::kDim))) return rc;
+    if ((rc = dev_alloc(&L.qterm, (size_t)kMaxMulti * 32))) return rc;
+    if ((rc = dev_alloc(&L.wcnt, (size_t)kMaxMulti * 32))) return rc;
+    if ((rc = dev_alloc(&L.wcand_d, (size_t)kMaxMulti * 32 * kWideCap))) return rc;
+    if ((rc = dev_alloc(&L.wcand_i, (size_t)kMaxMulti * 32 * kWideCap))) return rc;
+    return VS_OK;
+}
+
 int pick_kcap(int need) { return need <= 8 ? 8 : (need <= 16 ? 16 : 0); }
 
 // nb <= kMaxMulti batches of B queries in ONE persistent launch on stream s (preceded by the seed launches or the
@@ -538,6 +567,14 @@ int bf_launch(vs_index* h, vs_index::Lane& L, const float* q_dev, int nb, int B,
     int grid, tp;
     scan_geometry(h->n_rows, h->num_cus, grid, tp, seeded ? 0 : (u8_path ? 16 : 6) * vs::kScanWaves);
     const bool exchange = !seeded && grid >= 16 && tp >= (u8_path ? 16 : 6) * vs::kScanWaves && g_xchg_first_it >= 0;
+    const bool use_u8 = u8_path;
+    if (use_u8) HIPCHK(hipMemsetAsync(h->d_invalid, 0, (size_t)nb * sizeof(int32_t), s));
+    // several batches per pass over the rows (exact int8 rows, bounds known up front): the wide scan
+    const bool wide = use_u8 && seeded && g_i8_wide > 0 && h->metric == VS_METRIC_L2 && g_seed_i8;
+    if (wide) {
+        int rc = ensure_wide(L);
+        if (rc) return rc;
+    }
     if (seeded) {
         vs::SeedParams sp{};
         sp.base = h->d_vecs;
@@ -556,6 +593,11 @@ int bf_launch(vs_index* h, vs_index::Lane& L, const float* q_dev, int nb, int B,
         sp.qnorm = L.seed_qnorm;
         sp.wmin = L.seed_wmin;
         sp.tau0 = L.tau0;
+        if (wide) {
+            sp.q8 = L.q8;
+            sp.qterm = L.qterm;
+            sp.invalid = h->d_invalid;
+        }
         HIPCHK(vs::launch_seed(sp, s));
         p.tau0 = L.tau0;
     } else if (exchange) {
@@ -563,27 +605,7 @@ int bf_launch(vs_index* h, vs_index::Lane& L, const float* q_dev, int nb, int B,
         HIPCHK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(L.slots), 0x7f800000, (size_t)nb * 32 * vs::kSlotStride, s));
         p.slots_cur = L.slots;
     }
-    p.row_begin = 0;
-    p.row_end = h->n_rows;
-    p.tiles_per_wg = tp;
-    p.part_d = L.part_d;
-    p.part_i = L.part_i;
-    const bool use_u8 = h->d_vecs_u8 && h->precision != 1 && !force_f32;
-    if (use_u8) {
-        p.base_u8 = h->d_vecs_u8;
-        p.rterm = h->d_rterm;
-        p.invalid = h->d_invalid;
-        HIPCHK(hipMemsetAsync(h->d_invalid, 0, (size_t)nb * sizeof(int32_t), s));
-    }
-    prof_begin(h, 0, s);
-    HIPCHK(vs::launch_scan(p, grid, kcap, nqh, vs::kModeTopK, s));
-    prof_end(h, 0, s);
-    // one merge launch ranks every (batch, query): lists are [batch*32 + q][workgroup][kcap]
     vs::MergeParams m{};
-    m.part_d = L.part_d;
-    m.part_i = L.part_i;
-    m.G = grid;
-    m.kin = kcap;
     m.nq = nb * B;
     m.kout = k1;
     m.out_d = out_d;
@@ -592,6 +614,56 @@ int bf_launch(vs_index* h, vs_index::Lane& L, const float* q_dev, int nb, int B,
     m.q_group_out = B;
     m.q_group_in = vs::kMaxBatch;
     m.invalid = use_u8 ? h->d_invalid : nullptr;
+    if (wide) {
+        HIPCHK(hipMemsetAsync(L.wcnt, 0, (size_t)nb * 32 * sizeof(int32_t), s));
+        vs::WideParams wp{};
+        wp.base_u8 = h->d_vecs_u8;
+        wp.rterm = h->d_rterm;
+        wp.n_rows = h->n_rows;
+        wp.q8 = L.q8;
+        wp.qterm = L.qterm;
+        wp.tau0 = L.tau0;
+        wp.invalid = h->d_invalid;
+        wp.n_batches = nb;
+        wp.nq_valid = B;
+        wp.bpb = nqh;
+        wp.id_offset = (int32_t)h->id_offset;
+        wp.cnt = L.wcnt;
+        wp.cand_d = L.wcand_d;
+        wp.cand_i = L.wcand_i;
+        wp.cap = kWideCap;
+        const int64_t tiles64 = (h->n_rows + 63) / 64;
+        const int wgrid = (int)std::max<int64_t>(1, std::min<int64_t>(h->num_cus, tiles64));
+        prof_begin(h, 0, s);
+        HIPCHK(vs::launch_scan_i8_wide(wp, wgrid, g_i8_wide, s));
+        prof_end(h, 0, s);
+        // every query's candidate list (unsorted, a few hundred entries) -> k1 best by (dist, id), tie flags
+        m.part_d = L.wcand_d;
+        m.part_i = L.wcand_i;
+        m.G = 1;
+        m.kin = kWideCap;
+        m.flat_len = L.wcnt;
+        HIPCHK(vs::launch_merge_layout(m, 0, kWideCap, s));
+        return VS_OK;
+    }
+    p.row_begin = 0;
+    p.row_end = h->n_rows;
+    p.tiles_per_wg = tp;
+    p.part_d = L.part_d;
+    p.part_i = L.part_i;
+    if (use_u8) {
+        p.base_u8 = h->d_vecs_u8;
+        p.rterm = h->d_rterm;
+        p.invalid = h->d_invalid;
+    }
+    prof_begin(h, 0, s);
+    HIPCHK(vs::launch_scan(p, grid, kcap, nqh, vs::kModeTopK, s));
+    prof_end(h, 0, s);
+    // one merge launch ranks every (batch, query): lists are [batch*32 + q][workgroup][kcap]
+    m.part_d = L.part_d;
+    m.part_i = L.part_i;
+    m.G = grid;
+    m.kin = kcap;
     HIPCHK(vs::launch_merge_layout(m, kcap, (int64_t)vs::kSlotStride * kcap, s));
     return VS_OK;
 }

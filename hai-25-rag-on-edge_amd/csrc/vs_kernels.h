@@ -75,8 +75,37 @@ struct SeedParams {
     float* qnorm;            // scratch [n_batches][32]
     float* wmin;             // scratch [n_batches][64 groups][32]
     float* tau0;             // out [n_batches][32]
+    // optional outputs of the query-preparation launch for the wide int8 scan (launch_scan_i8_wide): the queries as
+    // bytes (x - 128), qterm = ||q||^2 - 256 sum(q - 128) - 2 * 128^3 per query, invalid[batch] = 1 when a query of the
+    // batch is not an integer in [0, 255] (pre-set to 0)
+    int8_t* q8;              // [n_batches][32][128]
+    int32_t* qterm;          // [n_batches][32]
+    int32_t* invalid;        // [n_batches]
 };
 hipError_t launch_seed(const SeedParams& p, hipStream_t s);
+
+// Wide exact-int8 brute-force scan: ONE pass over the byte rows serves NQH 16-query column blocks = NQH / bpb query
+// batches (bpb = 1 for batches of <= 16 queries, else 2), with the bounds of launch_seed in force from the first tile.
+// No lane lists, no workgroup merge: a distance under its query's bound is appended to that query's candidate list in
+// global memory (a few hundred per query per million rows); launch_merge_flat ranks the lists.  Waves are independent:
+// tiles of ALL passes are handed out through one monotonic ticket counter per workgroup, so nothing synchronises
+// between batches.
+struct WideParams {
+    const int8_t* base_u8;   // [n_rows (+64)][128] bytes (x - 128)
+    const int32_t* rterm;    // [n_rows + 64]
+    int64_t n_rows;
+    const int8_t* q8;        // [n_batches][32][128] from launch_seed
+    const int32_t* qterm;    // [n_batches][32]
+    const float* tau0;       // [n_batches][32]
+    const int32_t* invalid;  // [n_batches]
+    int n_batches, nq_valid, bpb;
+    int32_t id_offset;
+    int32_t* cnt;            // [n_batches][32] candidates appended per query (pre-set to 0; may exceed cap)
+    float* cand_d;           // [n_batches][32][cap]
+    int32_t* cand_i;
+    int cap;
+};
+hipError_t launch_scan_i8_wide(const WideParams& p, int grid, int nqh, hipStream_t s);  // nqh in {4, 8}
 
 // Cross-workgroup merge of sorted partial lists -> [nq][kout] + tie flags (+ seed thresholds).
 struct MergeParams {
@@ -95,6 +124,8 @@ struct MergeParams {
     int q_group_out, q_group_in;  // output query q reads input query (q / out) * in + q % out (0 = identity)
     const int32_t* invalid;  // optional [nq / q_group_out]: batches skipped by the int8 scan -> flags = 2
     int flag_empty;          // flags = 2 for a query with no finite entry at all (cross-GPU merge: every shard skipped its batch)
+    const int32_t* flat_len; // optional [queries]: the query's row holds min(flat_len, kin) UNSORTED candidates (G = 1);
+                             // flat_len > kin = the list overflowed -> flags = 2
 };
 hipError_t launch_merge(const MergeParams& p, hipStream_t s);  // scan-partial layout [G][nq_stride][kin]
 // general layout: entry (g, q, j) at g*stride_g + q*stride_q + j

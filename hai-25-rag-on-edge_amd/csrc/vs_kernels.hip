@@ -923,6 +923,200 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams 
     VS_STAMP(6);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Wide exact-int8 scan (see WideParams).  The data path is the PREC = 1 path of scan_kernel: per-wave ring of two
+// 64-row tile slots filled by LDS-DMA, XOR-swizzled so that the A fragments read conflict free, hand-counted vmcnt.
+// What differs: NQH query column blocks per pass (the B operands come straight from global memory, prepared by
+// seed_qnorm_kernel), the bound is fixed (launch_seed), survivors go to global candidate lists, and the tile ticket
+// runs over all passes of the launch (ticket = pass * T + n), so a wave slides from one pass into the next without
+// meeting anybody: the kernel has one barrier (ticket initialisation).
+// ------------------------------------------------------------------------------------------------
+constexpr int kWideLds = kRingBytes + 64;
+
+template <int NQH>
+__global__ __launch_bounds__(kScanThreads, 2) void scan_i8w_kernel(const WideParams p) {
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    constexpr int TR = 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* lds_ticket = reinterpret_cast<int*>(smem + kRingBytes);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    const int tiles_total = (int)((p.n_rows + TR - 1) / TR);
+    const int G = (int)gridDim.x;
+    const int T = (tiles_total - (int)blockIdx.x + G - 1) / G;  // tiles of this workgroup per pass (grid <= tiles_total)
+    const int NB = NQH / p.bpb;                                  // batches per pass
+    const int n_pass = (p.n_batches + NB - 1) / NB;
+    const int total = T * n_pass;                                // tickets of this workgroup
+    if (threadIdx.x == 0) lds_ticket[0] = 2 * kScanWaves;
+    __syncthreads();
+
+    char* ring = smem + wave * (kDepth * kSlotBytes);
+    unsigned voff[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int row_in = 8 * j + (lane >> 3);
+        voff[j] = (unsigned)(row_in * 128 + 16 * ((lane & 7) ^ ((row_in >> 1) & 7)));
+    }
+    const unsigned voff_n = (unsigned)lane * 4u;
+    auto issue_tile = [&](int tile, int slot) __attribute__((always_inline)) {
+        const int64_t row0 = (int64_t)tile * TR;
+        char* dst = ring + slot * kSlotBytes;
+        const char* tb = reinterpret_cast<const char*>(p.base_u8) + row0 * kDim;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            unsigned vo = voff[j];
+            asm volatile("" : "+v"(vo));
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tb + vo),
+                                             (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, 0, 0);
+        }
+        const char* nb = reinterpret_cast<const char*>(p.rterm + row0);
+        unsigned vn = voff_n;
+        asm volatile("" : "+v"(vn));
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(nb + vn),
+                                         (__attribute__((address_space(3))) void*)(dst + 8192), 4, 0, 0);
+    };
+    unsigned fa[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int row_in = 16 * (c >> 1) + r;
+        fa[c] = (unsigned)(wave * (kDepth * kSlotBytes) + row_in * 128 + ((((c & 1) * 4 + g) ^ ((row_in >> 1) & 7)) << 4));
+    }
+    const unsigned fa_n = (unsigned)(wave * (kDepth * kSlotBytes) + 8192 + 16 * g);
+    const unsigned ticket_addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) int*)lds_ticket;
+    auto next_ticket = [&]() -> int {
+        int tk = 0;
+        if (lane == 0)
+            asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(tk) : "v"(ticket_addr), "v"(1) : "memory");
+        return __builtin_amdgcn_readfirstlane(tk);
+    };
+    // ticket -> (pass, tile): tickets of a wave only grow, so the pass is tracked incrementally (no division per tile)
+    int dec_pass = 0, dec_base = 0;
+    auto tile_of = [&](int tk, int& pass_out) __attribute__((always_inline)) -> int {
+        if (tk >= total) {
+            pass_out = n_pass;
+            return (int)blockIdx.x;  // past the end: the DMA still goes out (queue accounting), to a tile nobody uses
+        }
+        while (tk - dec_base >= T) {
+            dec_base += T;
+            ++dec_pass;
+        }
+        pass_out = dec_pass;
+        return (int)blockIdx.x + (tk - dec_base) * G;
+    };
+
+    // per-pass state: B operands of the NQH column blocks, the queries' constant terms and integer bounds
+    i32x4 qb[NQH][2];
+    int qt[NQH], tau[NQH], qglob[NQH];
+    auto load_pass = [&](int pass) __attribute__((always_inline)) {
+#pragma unroll
+        for (int h = 0; h < NQH; ++h) {
+            const int batch = pass * NB + h / p.bpb;
+            const int qrow = 16 * (h % p.bpb) + r;
+            const bool live = batch < p.n_batches && qrow < p.nq_valid;
+            const int bq = live ? batch * kMaxBatch + qrow : 0;
+            const int8_t* src = p.q8 + (int64_t)bq * kDim;
+            qb[h][0] = *reinterpret_cast<const i32x4*>(src + 16 * g);
+            qb[h][1] = *reinterpret_cast<const i32x4*>(src + 64 + 16 * g);
+            qt[h] = p.qterm[bq];
+            const float t0 = p.tau0[bq];
+            const bool dead = !live || p.invalid[live ? batch : 0] != 0;
+            // d < tau0 for integer d  <=>  d < ceil(tau0)  (tau0 is next_up of an integer-valued float, or +inf)
+            tau[h] = dead ? (int)0x80000000 : (t0 < 2147483520.f ? (int)ceilf(t0) : 0x7fffffff);
+            qglob[h] = bq;
+        }
+    };
+
+    int tk_cur = wave, tk_nxt = wave + kScanWaves, pass_cur, pass_nxt;
+    int tile_cur = tile_of(tk_cur, pass_cur);
+    int tile_nxt = tile_of(tk_nxt, pass_nxt);
+    issue_tile(tile_cur, 0);
+    issue_tile(tile_nxt, 1);
+    int have_pass = -1;
+
+    auto step = [&](const int sl) __attribute__((always_inline)) {
+        if (pass_cur != have_pass) {  // wave-uniform: this wave enters a new pass
+            load_pass(pass_cur);
+            have_pass = pass_cur;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // operands are here (and so are both staged tiles)
+        }
+        const int tk_new = next_ticket();
+        int pass_new;
+        const int tile_new = tile_of(tk_new, pass_new);
+        asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        const char* src = smem + sl * kSlotBytes;
+        i32x4 a0[4], a1[4], rtv[4];
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            a0[rg] = *reinterpret_cast<const i32x4*>(src + fa[2 * rg]);
+            a1[rg] = *reinterpret_cast<const i32x4*>(src + fa[2 * rg + 1]);
+            rtv[rg] = *reinterpret_cast<const i32x4*>(src + fa_n + 64 * rg);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        issue_tile(tile_new, sl);  // the slot is refilled as soon as its fragments sit in registers
+        const int row_t = tile_cur * TR + 4 * g;
+#pragma unroll
+        for (int h = 0; h < NQH; ++h) {
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                i32x4 acc = (i32x4){0, 0, 0, 0};
+                acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0[rg], qb[h][0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1[rg], qb[h][1], acc, 0, 0, 0);
+                // the integer the fp32 path computes exactly: ||q||^2 + ||b||^2 - 2 q.b  (|acc| < 2^23: 24-bit multiply)
+                int d[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) d[j] = __mul24(acc[j], -2) + (qt[h] + rtv[rg][j]);
+                const int dmin = min(min(d[0], d[1]), min(d[2], d[3]));
+                if (dmin < tau[h]) {  // rare: a few hundred rows per query per million
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int row = row_t + 16 * rg + j;
+                        if (d[j] < tau[h] && row < (int)p.n_rows) {
+                            const int pos = atomicAdd(p.cnt + qglob[h], 1);
+                            if (pos < p.cap) {
+                                p.cand_d[(int64_t)qglob[h] * p.cap + pos] = (float)d[j];
+                                p.cand_i[(int64_t)qglob[h] * p.cap + pos] = row + p.id_offset;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        tk_cur = tk_nxt;
+        tile_cur = tile_nxt;
+        pass_cur = pass_nxt;
+        tk_nxt = tk_new;
+        tile_nxt = tile_new;
+        pass_nxt = pass_new;
+    };
+    while (tk_cur < total) {
+        step(0);
+        if (tk_cur >= total) break;
+        step(1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // retire the tail prefetches before the wave ends
+}
+
+hipError_t launch_scan_i8_wide(const WideParams& p, int grid, int nqh, hipStream_t s) {
+    static bool attr_set[64][2] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    auto k4 = scan_i8w_kernel<4>;
+    auto k8 = scan_i8w_kernel<8>;
+    const int which = nqh == 8 ? 1 : 0;
+    if (nqh != 4 && nqh != 8) return hipErrorInvalidValue;
+    if (!attr_set[dev][which]) {
+        hipError_t e = hipFuncSetAttribute(which ? reinterpret_cast<const void*>(k8) : reinterpret_cast<const void*>(k4),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kWideLds);
+        if (e != hipSuccess) return e;
+        attr_set[dev][which] = true;
+    }
+    if (which) hipLaunchKernelGGL(k8, dim3(grid), dim3(kScanThreads), kWideLds, s, p);
+    else hipLaunchKernelGGL(k4, dim3(grid), dim3(kScanThreads), kWideLds, s, p);
+    return hipGetLastError();
+}
+
 template <int NQH, int KCAP, int MODE, int PREC = 0>
 static hipError_t launch_scan_t(const ScanParams& p, int grid, hipStream_t s) {
     auto kfn = scan_kernel<NQH, KCAP, MODE, PREC>;
@@ -950,18 +1144,36 @@ __global__ __launch_bounds__(256) void seed_qnorm_kernel(const SeedParams p) {
     const int row = tid >> 3, j = tid & 7;
     const float* qb = p.q + (int64_t)batch * p.q_batch_stride;
     float acc = 0.f;
+    int part = 0;        // sum(q - 128) over this thread's 16 elements
+    bool q_ok = true;    // ... all of them integers in [0, 255]
     if (row < p.nq_valid) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const float x = qb[row * kDim + 8 * i + j];
             acc = fmaf(x, x, acc);
+            if (p.q8) {
+                const int xi = (int)x;
+                q_ok = q_ok && ((float)xi == x) && xi >= 0 && xi <= 255;
+                part += xi - 128;
+                p.q8[((int64_t)batch * kMaxBatch + row) * kDim + 8 * i + j] = (int8_t)(xi - 128);
+            }
         }
+    } else if (p.q8) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) p.q8[((int64_t)batch * kMaxBatch + row) * kDim + 8 * i + j] = 0;  // padding queries
     }
     const int b8 = lane & ~7;
     float sum = __shfl(acc, b8);
 #pragma unroll
     for (int u = 1; u < 8; ++u) sum = sum + __shfl(acc, b8 + u);
     if (j == 0) p.qnorm[batch * kMaxBatch + row] = sum;
+    if (p.q8) {
+        part += __shfl_xor(part, 1);
+        part += __shfl_xor(part, 2);
+        part += __shfl_xor(part, 4);
+        if (j == 0) p.qterm[batch * kMaxBatch + row] = (int)sum - 256 * part - 4194304;
+        if (!q_ok) p.invalid[batch] = 1;  // same value from every thread that sees a bad element
+    }
 }
 
 // One wave = (batch, chunk of kSeedTilesPerWave sample tiles): the batch's queries stay in registers as the B
@@ -1331,6 +1543,23 @@ __global__ __launch_bounds__(256) void merge_compact_kernel(const MergeParams p,
     }
     if (tid == 0) cnt = 0;
     __syncthreads();
+    if (p.flat_len) {
+        // one unsorted candidate list per query (wide int8 scan): the first min(len, kin) entries of the query's row
+        const int len = p.flat_len[q_in];
+        if (len > p.kin) {  // the list overflowed: the caller reruns the batch on another path
+            for (int t = tid; t < p.kout; t += 256) {
+                if (p.out_d) p.out_d[(int64_t)q * p.kout + t] = VS_INF;
+                if (p.out_i) p.out_i[(int64_t)q * p.kout + t] = -1;
+            }
+            if (tid == 0 && p.flags) p.flags[q] = 2;
+            return;
+        }
+        for (int e = tid; e < len; e += 256) {
+            cd[e] = p.part_d[(int64_t)q_in * L.stride_q + e];
+            ci[e] = p.part_i[(int64_t)q_in * L.stride_q + e];
+        }
+        if (tid == 0) cnt = len;
+    } else
     for (int g = tid; g < p.G; g += 256) {
         const int64_t off = (int64_t)g * L.stride_g + (int64_t)q_in * L.stride_q;
         for (int j = 0; j < p.kin; ++j) {
@@ -2522,6 +2751,7 @@ hipError_t launch_ivf_list_scan(const IvfListScanParams& p, int n_chunks, hipStr
 // ------------------------------------------------------------------------------------------------
 constexpr int kSelSplit = 2;      // workgroups per query
 constexpr int kSelCap = 4096;     // global candidate slots per query
+constexpr int kSelBkPer = 16;     // block minima a thread keeps in registers (covers 4096 blocks = 131072 candidate scores)
 
 // Pass 1 of the selection: every workgroup takes 1/8 of a query's candidate scores, computes its 256
 // thread minima and their k-th smallest -- a bound backed by k distinct candidates -- and folds it
@@ -2617,10 +2847,20 @@ __global__ __launch_bounds__(256) void ivf_select_kernel(IvfSelectParams p) {
     const int nb_used = min(p.nbk, (S + 31) / 32 + 1);
     if (bk) {
         // per-block minima of the unit scan: the k-th smallest of the 256 thread minima is backed by k distinct candidates
+        // (fixed trip count: the loads of a thread are independent and go out together; beyond 4096 blocks a plain loop)
         float mine = VS_INF;
-        for (int j = tid; j < nb_used; j += 256) {
-            const unsigned u = bk[j];
-            if (u) mine = fminf(mine, f32_unordered(~u));
+        if (nb_used <= 256 * kSelBkPer) {
+            unsigned bv[kSelBkPer];
+#pragma unroll
+            for (int i = 0; i < kSelBkPer; ++i) bv[i] = tid + 256 * i < nb_used ? bk[tid + 256 * i] : 0u;
+#pragma unroll
+            for (int i = 0; i < kSelBkPer; ++i)
+                if (bv[i]) mine = fminf(mine, f32_unordered(~bv[i]));
+        } else {
+            for (int j = tid; j < nb_used; j += 256) {
+                const unsigned u = bk[j];
+                if (u) mine = fminf(mine, f32_unordered(~u));
+            }
         }
         s_mn[tid] = mine;
         if (tid == 0) s_nblk = 0;
@@ -2672,13 +2912,26 @@ __global__ __launch_bounds__(256) void ivf_select_kernel(IvfSelectParams p) {
         // only the 32-score blocks that can hold a score under the bound are read: block j is needed when a unit that
         // starts in block j or j - 1 has a minimum <= T (a unit's 32 scores span at most two blocks)
         if (part == 0) {
-            for (int j = tid; j < nb_used; j += 256) {
-                const unsigned u0 = bk[j], u1 = j > 0 ? bk[j - 1] : 0u;
+            auto need_block = [&](int j, unsigned u0, unsigned u1) {
                 const bool need = (u0 && f32_unordered(~u0) <= T) || (u1 && f32_unordered(~u1) <= T);
                 if (need) {
                     const int pos = atomicAdd(&s_nblk, 1);
                     if (pos < 1024) s_blk[pos] = j;
                 }
+            };
+            if (nb_used <= 256 * kSelBkPer) {
+                unsigned b0[kSelBkPer], b1[kSelBkPer];
+#pragma unroll
+                for (int i = 0; i < kSelBkPer; ++i) {
+                    const int j = tid + 256 * i;
+                    b0[i] = j < nb_used ? bk[j] : 0u;
+                    b1[i] = (j < nb_used && j > 0) ? bk[j - 1] : 0u;
+                }
+#pragma unroll
+                for (int i = 0; i < kSelBkPer; ++i)
+                    if (tid + 256 * i < nb_used) need_block(tid + 256 * i, b0[i], b1[i]);
+            } else {
+                for (int j = tid; j < nb_used; j += 256) need_block(j, bk[j], j > 0 ? bk[j - 1] : 0u);
             }
             __syncthreads();
             const int nblk = s_nblk;

@@ -440,3 +440,62 @@ def test_bf_batch_sweep_driver_end_to_end(gpu_pkg, golden_dir, tmp_path):
         rdir = tmp_path / "results" / ("siftsmall" if b == 1 else f"siftsmall_b{b}")
         assert open(rdir / "results.txt").read() == ref
         assert f"Batch size: {b}" in open(rdir / "metrics.txt").read()
+
+
+def test_wide_int8_scan_equals_fp32_path(gpu_pkg):
+    """Launches of >= 4 batches on byte-valued data take the wide int8 scan (several batches per pass over the rows,
+    candidates appended to per-query lists, flat merge).  Its k+1 lists and tie flags must be bit-identical to the
+    fp32 path's for every batch shape: 32-query batches (two column blocks each), <= 16-query batches (one block),
+    batch counts that do not fill the last pass, k + 1 beyond the lane-list sizes of the per-batch kernels, an id offset."""
+    import torch
+    dev = torch.device("cuda", 0)
+    base = gpu_pkg.synth_sift(150000, seed=71)
+    base[149000] = base[11]
+    q = gpu_pkg.synth_sift(13 * 32, seed=72)
+    q[5] = base[11]          # exact hit with a far-apart duplicate: tie flag
+    q[40] = base[77777]
+    qd = torch.from_numpy(q).to(dev)
+    s = torch.cuda.current_stream().cuda_stream
+    with gpu_pkg.BruteForceIndex(base, id_offset=1000) as idx:
+        for nb, B, k in ((7, 32, 5), (13, 32, 10), (9, 16, 5), (13, 5, 1), (4, 32, 15), (26, 9, 5)):
+            out = {}
+            for precision in (1, 2):
+                idx.set_precision(precision)
+                o_d = torch.zeros((nb * B, k + 1), dtype=torch.float32, device=dev)
+                o_i = torch.zeros((nb * B, k + 1), dtype=torch.int32, device=dev)
+                fl = torch.zeros((nb * B,), dtype=torch.int32, device=dev)
+                idx.search_dev_multi(qd.data_ptr(), nb, B, k, o_i.data_ptr(), o_d.data_ptr(), fl.data_ptr(), s)
+                torch.cuda.synchronize()
+                out[precision] = (o_d.cpu().numpy(), o_i.cpu().numpy(), fl.cpu().numpy())
+            assert np.array_equal(out[1][0], out[2][0]), (nb, B, k)
+            assert np.array_equal(out[1][1], out[2][1]), (nb, B, k)
+            assert np.array_equal(out[1][2], out[2][2]), (nb, B, k)
+            assert out[1][1].min() >= 1000
+        assert out[1][2].max() <= 1
+
+
+def test_wide_int8_scan_overflow_reruns_in_fp32(gpu_pkg):
+    """More rows under a query's bound than its candidate list holds (here: tens of thousands of identical rows): the
+    device API says so (flags = 2) and the host API reruns the batch on the fp32 path -- results stay exact."""
+    import torch
+    rng = np.random.default_rng(73)
+    base = gpu_pkg.synth_sift(100000, seed=74)
+    base[20000:60000] = base[7]           # 40 000 copies of one row
+    q = gpu_pkg.synth_sift(5 * 32, seed=75)
+    q[0] = base[7]
+    q[33] = base[7] + 1
+    dev = torch.device("cuda", 0)
+    qd = torch.from_numpy(q).to(dev)
+    with gpu_pkg.BruteForceIndex(base) as idx:
+        idx.set_precision(2)
+        o_d = torch.zeros((160, 6), dtype=torch.float32, device=dev)
+        o_i = torch.zeros((160, 6), dtype=torch.int32, device=dev)
+        fl = torch.zeros((160,), dtype=torch.int32, device=dev)
+        idx.search_dev_multi(qd.data_ptr(), 5, 32, 5, o_i.data_ptr(), o_d.data_ptr(), fl.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        f = fl.cpu().numpy()
+        assert f[0] == 2 and f[33] == 2
+        idx.set_precision(0)
+        ids, d = idx.search(q, 5)
+    oi, od = oracle.search_bf(base, q, 5)
+    assert np.array_equal(ids, oi) and np.array_equal(d, od)
