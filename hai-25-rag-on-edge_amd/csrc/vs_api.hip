@@ -40,6 +40,7 @@ constexpr int kMaxNprobe = 256;
 constexpr int kSlotWords = 32 * vs::kIvfSlots;  // per-batch slot minima of the IVF list scan (in the zeroed block)
 constexpr int kMaxLanes = 4;
 constexpr int kMaxMulti = 32;  // batches per persistent scan launch
+constexpr int kWideWaveCap = 1024;  // entries per wave buffer of the wide int8 scan (expected fill: about 100 per launch)
 constexpr int kWideCap = 2048;    // candidate slots per query of the wide int8 scan (more: the batch is rerun in fp32)
 constexpr int kTieDense = 4096;   // rows whose distances the tie resolver takes densely
 constexpr int kTieCap = 8192;     // candidate slots per flagged query (more: full-row fallback)
@@ -106,6 +107,8 @@ struct vs_index {
         int32_t* wcnt = nullptr;     // [kMaxMulti][32]
         float* wcand_d = nullptr;    // [kMaxMulti][32][kWideCap]
         int32_t* wcand_i = nullptr;
+        int4* wbuf = nullptr;        // [256 * 8][kWideWaveCap] wave-private candidate buffers of the scan
+        int32_t* wcount = nullptr;   // [256 * 8] + [1] overflow word
     };
     Lane lane[kMaxLanes];
     int n_lanes = 1;
@@ -226,7 +229,7 @@ void free_all(vs_index* h) {
         if (L.seed_qnorm) (void)hipFree(L.seed_qnorm);
         if (L.seed_wmin) (void)hipFree(L.seed_wmin);
         if (L.tau0) (void)hipFree(L.tau0);
-        void* wide[] = {L.q8, L.qterm, L.wcnt, L.wcand_d, L.wcand_i};
+        void* wide[] = {L.q8, L.qterm, L.wcnt, L.wcand_d, L.wcand_i, L.wbuf, L.wcount};
         for (void* w : wide)
             if (w) (void)hipFree(w);
         if (L.done_ev) (void)hipEventDestroy(L.done_ev);
@@ -522,6 +525,13 @@ int g_i8_wide = [] {
     return v >= 8 ? 8 : (v >= 4 ? 4 : 0);
 }();
 
+// tuning knob (VSEARCH_STREAM=0): seeded launches use the per-batch scan kernels (lane lists + workgroup merge) instead of
+// the streaming scans
+int g_stream = [] {
+    const char* e = getenv("VSEARCH_STREAM");
+    return e ? atoi(e) : 1;
+}();
+
 int ensure_wide(vs_index::Lane& L) {
     if (L.q8) return VS_OK;
     int rc;
@@ -530,6 +540,8 @@ int ensure_wide(vs_index::Lane& L) {
     if ((rc = dev_alloc(&L.wcnt, (size_t)kMaxMulti * 32))) return rc;
     if ((rc = dev_alloc(&L.wcand_d, (size_t)kMaxMulti * 32 * kWideCap))) return rc;
     if ((rc = dev_alloc(&L.wcand_i, (size_t)kMaxMulti * 32 * kWideCap))) return rc;
+    if ((rc = dev_alloc(&L.wbuf, (size_t)vs::kSlotStride * vs::kScanWaves * kWideWaveCap))) return rc;
+    if ((rc = dev_alloc(&L.wcount, (size_t)vs::kSlotStride * vs::kScanWaves + 1))) return rc;
     return VS_OK;
 }
 
@@ -569,9 +581,12 @@ int bf_launch(vs_index* h, vs_index::Lane& L, const float* q_dev, int nb, int B,
     const bool exchange = !seeded && grid >= 16 && tp >= (u8_path ? 16 : 6) * vs::kScanWaves && g_xchg_first_it >= 0;
     const bool use_u8 = u8_path;
     if (use_u8) HIPCHK(hipMemsetAsync(h->d_invalid, 0, (size_t)nb * sizeof(int32_t), s));
-    // several batches per pass over the rows (exact int8 rows, bounds known up front): the wide scan
-    const bool wide = use_u8 && seeded && g_i8_wide > 0 && h->metric == VS_METRIC_L2 && g_seed_i8;
-    if (wide) {
+    // With the bounds known up front the batches need nothing from each other: the streaming scans (fp32: one batch per
+    // pass; exact int8 rows: several batches per pass over the rows) hand out the tiles of ALL batches through one
+    // ticket per workgroup and write survivors to candidate lists -- no barrier, no workgroup merge, no per-batch prologue.
+    const bool i8_seed = h->d_vecs_u8 && h->metric == VS_METRIC_L2 && g_seed_i8;
+    const bool stream = seeded && g_stream && (use_u8 ? (g_i8_wide > 0 && i8_seed) : true);
+    if (stream) {
         int rc = ensure_wide(L);
         if (rc) return rc;
     }
@@ -579,7 +594,7 @@ int bf_launch(vs_index* h, vs_index::Lane& L, const float* q_dev, int nb, int B,
         vs::SeedParams sp{};
         sp.base = h->d_vecs;
         sp.bnorm = h->d_norm;
-        if (h->d_vecs_u8 && h->metric == VS_METRIC_L2 && g_seed_i8) {  // exact int8 copy of the rows: 16x cheaper seed
+        if (i8_seed) {  // exact int8 copy of the rows: 16x cheaper seed
             sp.base_u8 = h->d_vecs_u8;
             sp.rterm = h->d_rterm;
         }
@@ -593,7 +608,7 @@ int bf_launch(vs_index* h, vs_index::Lane& L, const float* q_dev, int nb, int B,
         sp.qnorm = L.seed_qnorm;
         sp.wmin = L.seed_wmin;
         sp.tau0 = L.tau0;
-        if (wide) {
+        if (stream && use_u8) {
             sp.q8 = L.q8;
             sp.qterm = L.qterm;
             sp.invalid = h->d_invalid;
@@ -614,37 +629,71 @@ int bf_launch(vs_index* h, vs_index::Lane& L, const float* q_dev, int nb, int B,
     m.q_group_out = B;
     m.q_group_in = vs::kMaxBatch;
     m.invalid = use_u8 ? h->d_invalid : nullptr;
-    if (wide) {
+    int32_t* overflow = nullptr;
+    if (stream) {
+        overflow = L.wcount + vs::kSlotStride * vs::kScanWaves;
         HIPCHK(hipMemsetAsync(L.wcnt, 0, (size_t)nb * 32 * sizeof(int32_t), s));
-        vs::WideParams wp{};
-        wp.base_u8 = h->d_vecs_u8;
-        wp.rterm = h->d_rterm;
-        wp.n_rows = h->n_rows;
-        wp.q8 = L.q8;
-        wp.qterm = L.qterm;
-        wp.tau0 = L.tau0;
-        wp.invalid = h->d_invalid;
-        wp.n_batches = nb;
-        wp.nq_valid = B;
-        wp.bpb = nqh;
-        wp.id_offset = (int32_t)h->id_offset;
-        wp.cnt = L.wcnt;
-        wp.cand_d = L.wcand_d;
-        wp.cand_i = L.wcand_i;
-        wp.cap = kWideCap;
-        const int64_t tiles64 = (h->n_rows + 63) / 64;
-        const int wgrid = (int)std::max<int64_t>(1, std::min<int64_t>(h->num_cus, tiles64));
+        HIPCHK(hipMemsetAsync(overflow, 0, sizeof(int32_t), s));
+        vs::CandSink sink{};
+        sink.wbuf = L.wbuf;
+        sink.wcount = L.wcount;
+        sink.wcap = kWideWaveCap;
+        sink.overflow = overflow;
+        sink.cnt = L.wcnt;
+        sink.cand_d = L.wcand_d;
+        sink.cand_i = L.wcand_i;
+        sink.cap = kWideCap;
         prof_begin(h, 0, s);
-        HIPCHK(vs::launch_scan_i8_wide(wp, wgrid, g_i8_wide, s));
+        if (use_u8) {
+            vs::WideParams wp{};
+            wp.base_u8 = h->d_vecs_u8;
+            wp.rterm = h->d_rterm;
+            wp.n_rows = h->n_rows;
+            wp.q8 = L.q8;
+            wp.qterm = L.qterm;
+            wp.tau0 = L.tau0;
+            wp.invalid = h->d_invalid;
+            wp.n_batches = nb;
+            wp.nq_valid = B;
+            wp.bpb = nqh;
+            wp.id_offset = (int32_t)h->id_offset;
+            wp.sink = sink;
+            const int64_t tiles64 = (h->n_rows + 63) / 64;
+            const int wgrid = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(h->num_cus, vs::kSlotStride), tiles64));
+            HIPCHK(vs::launch_scan_i8_wide(wp, wgrid, g_i8_wide, s));
+        } else {
+            vs::StreamParams sp{};
+            sp.base = h->d_vecs;
+            sp.bnorm = h->d_norm;
+            sp.n_rows = h->n_rows;
+            sp.q = q_dev;
+            sp.q_batch_stride = (int64_t)B * vs::kDim;
+            sp.qnorm = L.seed_qnorm;
+            sp.tau0 = L.tau0;
+            sp.n_batches = nb;
+            sp.nq_valid = B;
+            sp.metric = h->metric;
+            sp.id_offset = (int32_t)h->id_offset;
+            sp.sink = sink;
+            const int sgrid = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(h->num_cus, vs::kSlotStride), tiles_total));
+            HIPCHK(vs::launch_scan_f32_stream(sp, sgrid, s));
+        }
         prof_end(h, 0, s);
         // every query's candidate list (unsorted, a few hundred entries) -> k1 best by (dist, id), tie flags
-        m.part_d = L.wcand_d;
-        m.part_i = L.wcand_i;
-        m.G = 1;
-        m.kin = kWideCap;
-        m.flat_len = L.wcnt;
-        HIPCHK(vs::launch_merge_layout(m, 0, kWideCap, s));
-        return VS_OK;
+        vs::MergeParams mf = m;
+        mf.part_d = L.wcand_d;
+        mf.part_i = L.wcand_i;
+        mf.G = 1;
+        mf.kin = kWideCap;
+        mf.flat_len = L.wcnt;
+        mf.run_if = overflow;
+        mf.run_mode = 2;
+        HIPCHK(vs::launch_merge_layout(mf, 0, kWideCap, s));
+        // Fallback, enqueued behind and idle unless a candidate buffer overflowed (thousands of rows under one query's
+        // bound: masses of duplicates): the per-batch scan with lane lists, which copes with any data.
+        p.run_if = overflow;
+        m.run_if = overflow;
+        m.run_mode = 1;
     }
     p.row_begin = 0;
     p.row_end = h->n_rows;
@@ -656,9 +705,9 @@ int bf_launch(vs_index* h, vs_index::Lane& L, const float* q_dev, int nb, int B,
         p.rterm = h->d_rterm;
         p.invalid = h->d_invalid;
     }
-    prof_begin(h, 0, s);
+    if (!stream) prof_begin(h, 0, s);
     HIPCHK(vs::launch_scan(p, grid, kcap, nqh, vs::kModeTopK, s));
-    prof_end(h, 0, s);
+    if (!stream) prof_end(h, 0, s);
     // one merge launch ranks every (batch, query): lists are [batch*32 + q][workgroup][kcap]
     m.part_d = L.part_d;
     m.part_i = L.part_i;

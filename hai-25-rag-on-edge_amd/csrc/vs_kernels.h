@@ -28,6 +28,7 @@ struct ScanParams {
     const float* tau0;       // [n_batches][32] bounds computed beforehand by launch_seed (then no exchange, no warm-up), or nullptr
     int k1;                  // the exchange bounds the k1-th best distance; also entries kept per partial list
     int* dbg;                // optional debug counters [grid][16]
+    const int32_t* run_if;   // optional [1]: the launch does nothing unless *run_if != 0 (fallback behind a streaming scan)
     int64_t row_begin;       // multiple of 16
     int64_t row_end;         // exclusive
     int tiles_per_wg;
@@ -90,6 +91,21 @@ hipError_t launch_seed(const SeedParams& p, hipStream_t s);
 // global memory (a few hundred per query per million rows); launch_merge_flat ranks the lists.  Waves are independent:
 // tiles of ALL passes are handed out through one monotonic ticket counter per workgroup, so nothing synchronises
 // between batches.
+// Where the streaming scans put what they find: wave-private buffers filled with plain stores (positions from a wave
+// ballot -- a returning atomic in the tile loop would have to be waited for with vmcnt(0), i.e. drain the tile queue on
+// every hit), binned into per-query lists by a small launch after the scan.
+struct CandSink {
+    int4* wbuf;              // [grid * 8][wcap] x (query = batch * 32 + q, dist bits, id, 0)
+    int32_t* wcount;         // [grid * 8] fill of every wave buffer (may exceed wcap)
+    int wcap;
+    int32_t* overflow;       // [1] (pre-set to 0): a wave buffer or a query list overflowed -> the launch's fallback kernels
+                             //     (the per-batch scan + its merge, enqueued behind with run_if = overflow) produce the result
+    int32_t* cnt;            // [n_batches][32] candidates per query (pre-set to 0)
+    float* cand_d;           // [n_batches][32][cap]
+    int32_t* cand_i;
+    int cap;
+};
+
 struct WideParams {
     const int8_t* base_u8;   // [n_rows (+64)][128] bytes (x - 128)
     const int32_t* rterm;    // [n_rows + 64]
@@ -100,12 +116,27 @@ struct WideParams {
     const int32_t* invalid;  // [n_batches]
     int n_batches, nq_valid, bpb;
     int32_t id_offset;
-    int32_t* cnt;            // [n_batches][32] candidates appended per query (pre-set to 0; may exceed cap)
-    float* cand_d;           // [n_batches][32][cap]
-    int32_t* cand_i;
-    int cap;
+    CandSink sink;
 };
 hipError_t launch_scan_i8_wide(const WideParams& p, int grid, int nqh, hipStream_t s);  // nqh in {4, 8}
+
+// Streaming fp32 scan: the arithmetic of scan_kernel (v_mfma_f32_16x16x4_f32 chain in k order, fma(-2, dot, qn + bn)
+// epilogue: bit-identical distances), one batch per pass, but organised like the wide int8 scan: bounds from
+// launch_seed, queries and their norms straight from global memory, survivors to the CandSink, tiles of all batches
+// handed out through one monotonic ticket per workgroup -- no barrier, no workgroup merge, no per-batch prologue.
+struct StreamParams {
+    const float* base;       // [n_rows (+64)][128]
+    const float* bnorm;      // [n_rows + 64]
+    int64_t n_rows;
+    const float* q;          // [n_batches][nq_valid][128] raw queries
+    int64_t q_batch_stride;
+    const float* qnorm;      // [n_batches][32] from launch_seed
+    const float* tau0;       // [n_batches][32]
+    int n_batches, nq_valid, metric;
+    int32_t id_offset;
+    CandSink sink;
+};
+hipError_t launch_scan_f32_stream(const StreamParams& p, int grid, hipStream_t s);
 
 // Cross-workgroup merge of sorted partial lists -> [nq][kout] + tie flags (+ seed thresholds).
 struct MergeParams {
@@ -124,6 +155,8 @@ struct MergeParams {
     int q_group_out, q_group_in;  // output query q reads input query (q / out) * in + q % out (0 = identity)
     const int32_t* invalid;  // optional [nq / q_group_out]: batches skipped by the int8 scan -> flags = 2
     int flag_empty;          // flags = 2 for a query with no finite entry at all (cross-GPU merge: every shard skipped its batch)
+    const int32_t* run_if;   // optional [1] with run_mode: 1 = run only if *run_if != 0, 2 = only if *run_if == 0 (the other
+    int run_mode;            //   launch of the pair writes the outputs)
     const int32_t* flat_len; // optional [queries]: the query's row holds min(flat_len, kin) UNSORTED candidates (G = 1);
                              // flat_len > kin = the list overflowed -> flags = 2
 };

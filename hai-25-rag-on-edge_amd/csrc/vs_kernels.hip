@@ -236,6 +236,7 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams 
     const int lane0 = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably wave-uniform
     VS_STAMP(0);
+    if (p.run_if && !p.run_if[0]) return;  // fallback launch behind a streaming scan that did not overflow
 
     const int64_t n_rows = p.row_end - p.row_begin;
     const int tiles_total = (int)((n_rows + TR - 1) / TR);
@@ -1006,9 +1007,10 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_i8w_kernel(const WidePar
         return (int)blockIdx.x + (tk - dec_base) * G;
     };
 
-    // per-pass state: B operands of the NQH column blocks, the queries' constant terms and integer bounds
+    // per-pass state: B operands of the NQH column blocks, the queries' constant terms and integer bounds.
+    // d = qt + rt - 2 acc < tau  <=>  2 acc - rt > qt - tau =: thr  (the hot loop never forms d)
     i32x4 qb[NQH][2];
-    int qt[NQH], tau[NQH], qglob[NQH];
+    int qt[NQH], thr[NQH], qglob[NQH];
     auto load_pass = [&](int pass) __attribute__((always_inline)) {
 #pragma unroll
         for (int h = 0; h < NQH; ++h) {
@@ -1022,12 +1024,16 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_i8w_kernel(const WidePar
             qt[h] = p.qterm[bq];
             const float t0 = p.tau0[bq];
             const bool dead = !live || p.invalid[live ? batch : 0] != 0;
-            // d < tau0 for integer d  <=>  d < ceil(tau0)  (tau0 is next_up of an integer-valued float, or +inf)
-            tau[h] = dead ? (int)0x80000000 : (t0 < 2147483520.f ? (int)ceilf(t0) : 0x7fffffff);
+            // d < tau0 for integer d  <=>  d < ceil(tau0)  (tau0 is next_up of an integer-valued float, or +inf; distances
+            // are below 2^24, so any bound from 2^26 on admits everything)
+            const int ti = (int)ceilf(fminf(fmaxf(t0, -67108864.f), 67108864.f));
+            thr[h] = dead ? 0x7fffffff : qt[h] - ti;
             qglob[h] = bq;
         }
     };
 
+    int4* wbuf = p.sink.wbuf + ((int64_t)blockIdx.x * kScanWaves + wave) * p.sink.wcap;
+    int wbase = 0;  // wave-uniform fill of the private candidate buffer
     int tk_cur = wave, tk_nxt = wave + kScanWaves, pass_cur, pass_nxt;
     int tile_cur = tile_of(tk_cur, pass_cur);
     int tile_nxt = tile_of(tk_nxt, pass_nxt);
@@ -1056,28 +1062,58 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_i8w_kernel(const WidePar
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         issue_tile(tile_new, sl);  // the slot is refilled as soon as its fragments sit in registers
         const int row_t = tile_cur * TR + 4 * g;
+        // hot loop, branch free: per column block 8 MFMAs and e = 2 acc - rt folded to its maximum; a block whose maximum
+        // exceeds the query's threshold holds a candidate (a few per tile) and is recomputed below
+        i32x4 nrt[4];
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) nrt[rg] = -rtv[rg];
+        unsigned hit = 0;
 #pragma unroll
         for (int h = 0; h < NQH; ++h) {
+            i32x4 acc[4];
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
-                i32x4 acc = (i32x4){0, 0, 0, 0};
-                acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0[rg], qb[h][0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1[rg], qb[h][1], acc, 0, 0, 0);
-                // the integer the fp32 path computes exactly: ||q||^2 + ||b||^2 - 2 q.b  (|acc| < 2^23: 24-bit multiply)
-                int d[4];
+                acc[rg] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0[rg], qb[h][0], (i32x4){0, 0, 0, 0}, 0, 0, 0);
+                acc[rg] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1[rg], qb[h][1], acc[rg], 0, 0, 0);
+            }
+            int emax = (int)0x80000000;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) d[j] = __mul24(acc[j], -2) + (qt[h] + rtv[rg][j]);
-                const int dmin = min(min(d[0], d[1]), min(d[2], d[3]));
-                if (dmin < tau[h]) {  // rare: a few hundred rows per query per million
+            for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) emax = max(emax, 2 * acc[rg][j] + nrt[rg][j]);
+            hit |= emax > thr[h] ? (1u << h) : 0u;
+        }
+        // wave-uniform union of the hit bits (DPP or-reduction)
+        unsigned um = hit;
+        um |= (unsigned)dpp_mov_i<0xB1>((int)um);
+        um |= (unsigned)dpp_mov_i<0x4E>((int)um);
+        um |= (unsigned)dpp_mov_i<0x141>((int)um);
+        um |= (unsigned)dpp_mov_i<0x140>((int)um);
+        um = (unsigned)(__builtin_amdgcn_readlane((int)um, 0) | __builtin_amdgcn_readlane((int)um, 16) |
+                        __builtin_amdgcn_readlane((int)um, 32) | __builtin_amdgcn_readlane((int)um, 48));
+        if (um) {
+#pragma unroll
+            for (int h = 0; h < NQH; ++h) {
+                if (!(um & (1u << h))) continue;  // scalar branch
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    i32x4 acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0[rg], qb[h][0], (i32x4){0, 0, 0, 0}, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1[rg], qb[h][1], acc, 0, 0, 0);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int row = row_t + 16 * rg + j;
-                        if (d[j] < tau[h] && row < (int)p.n_rows) {
-                            const int pos = atomicAdd(p.cnt + qglob[h], 1);
-                            if (pos < p.cap) {
-                                p.cand_d[(int64_t)qglob[h] * p.cap + pos] = (float)d[j];
-                                p.cand_i[(int64_t)qglob[h] * p.cap + pos] = row + p.id_offset;
+                        const bool pass = 2 * acc[j] + nrt[rg][j] > thr[h] && row < (int)p.n_rows;
+                        const unsigned long long mask = __ballot(pass);
+                        if (mask) {  // wave-uniform
+                            // This wave's private candidate buffer, positions from the ballot: plain stores, no atomics -- a
+                            // returning atomic would have to be waited for with vmcnt(0), i.e. drain the tile queue per hit.
+                            const int pos = wbase + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+                            if (pass && pos < p.sink.wcap) {
+                                // the integer the fp32 path computes exactly: ||q||^2 + ||b||^2 - 2 q.b
+                                const int d = qt[h] + rtv[rg][j] - 2 * acc[j];
+                                wbuf[pos] = make_int4(qglob[h], __builtin_bit_cast(int, (float)d), row + p.id_offset, 0);
                             }
+                            wbase += __popcll(mask);
                         }
                     }
                 }
@@ -1096,6 +1132,207 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_i8w_kernel(const WidePar
         step(1);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // retire the tail prefetches before the wave ends
+    if (lane == 0) p.sink.wcount[(int)blockIdx.x * kScanWaves + wave] = wbase;  // may exceed wcap: overflow, seen by the binning kernel
+}
+
+// Candidates of a streaming scan, wave buffers -> per-query lists (the only atomics of the path, massively parallel here).
+__global__ __launch_bounds__(256) void cand_bin_kernel(const CandSink p) {
+    const int wb = blockIdx.x;
+    const int n = p.wcount[wb];
+    if (n > p.wcap) {
+        if (threadIdx.x == 0) p.overflow[0] = 1;  // entries were dropped: the fallback kernels behind take over
+        return;
+    }
+    const int4* src = p.wbuf + (int64_t)wb * p.wcap;
+    for (int e = threadIdx.x; e < n; e += 256) {
+        const int4 c = src[e];
+        const int pos = atomicAdd(p.cnt + c.x, 1);
+        if (pos < p.cap) {
+            p.cand_d[(int64_t)c.x * p.cap + pos] = __builtin_bit_cast(float, c.y);
+            p.cand_i[(int64_t)c.x * p.cap + pos] = c.z;
+        } else {
+            p.overflow[0] = 1;  // more rows under a query's bound than its list holds
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Streaming fp32 scan (see StreamParams): scan_kernel's fp32 data path and arithmetic, the wide int8 scan's organisation.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kScanThreads, 2) void scan_f32s_kernel(const StreamParams p) {
+    constexpr int TR = kTileRows;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* lds_ticket = reinterpret_cast<int*>(smem + kRingBytes);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    const int tiles_total = (int)((p.n_rows + TR - 1) / TR);
+    const int G = (int)gridDim.x;
+    const int T = (tiles_total - (int)blockIdx.x + G - 1) / G;  // tiles of this workgroup per batch (grid <= tiles_total)
+    const int total = T * p.n_batches;                            // tickets of this workgroup
+    if (threadIdx.x == 0) lds_ticket[0] = 2 * kScanWaves;
+    __syncthreads();  // the only barrier of the kernel
+
+    char* ring = smem + wave * (kDepth * kSlotBytes);
+    unsigned voff[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int row_in = 2 * j + (lane >> 5);
+        voff[j] = (unsigned)(row_in * 512 + 16 * ((lane & 31) ^ row_in));
+    }
+    const unsigned voff_n = (unsigned)lane * 4u;
+    auto issue_tile = [&](int tile, int slot) __attribute__((always_inline)) {
+        const int64_t row0 = (int64_t)tile * TR;
+        char* dst = ring + slot * kSlotBytes;
+        const char* tb = reinterpret_cast<const char*>(p.base) + row0 * (kDim * 4);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            unsigned vo = voff[j];
+            asm volatile("" : "+v"(vo));
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tb + vo),
+                                             (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, 0, VS_ROW_CPOL);
+        }
+        const char* nb = reinterpret_cast<const char*>(p.bnorm + row0);
+        unsigned vn = voff_n;
+        asm volatile("" : "+v"(vn));
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(nb + vn),
+                                         (__attribute__((address_space(3))) void*)(dst + 8192), 4, 0, 0);
+    };
+    unsigned fa[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) fa[c] = (unsigned)(wave * (kDepth * kSlotBytes) + r * 512 + (((4 * c + g) ^ r) << 4));
+    const unsigned fa_n = (unsigned)(wave * (kDepth * kSlotBytes) + 8192 + 16 * g);
+    const unsigned ticket_addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) int*)lds_ticket;
+    auto next_ticket = [&]() -> int {
+        int tk = 0;
+        if (lane == 0)
+            asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(tk) : "v"(ticket_addr), "v"(1) : "memory");
+        return __builtin_amdgcn_readfirstlane(tk);
+    };
+    int dec_pass = 0, dec_base = 0;
+    auto tile_of = [&](int tk, int& pass_out) __attribute__((always_inline)) -> int {
+        if (tk >= total) {
+            pass_out = p.n_batches;
+            return (int)blockIdx.x;  // past the end: the DMA still goes out (queue accounting), to a tile nobody uses
+        }
+        while (tk - dec_base >= T) {
+            dec_base += T;
+            ++dec_pass;
+        }
+        pass_out = dec_pass;
+        return (int)blockIdx.x + (tk - dec_base) * G;
+    };
+
+    // per-batch state: the 32 queries as B operands (qf[h][c][i] = Q[16 h + r][16 c + 4 g + i]), their norms and bounds
+    f32x4 qf[2][8];
+    float qn[2], tau[2];
+    int qglob[2];
+    auto load_pass = [&](int batch) __attribute__((always_inline)) {
+        const float* qb = p.q + (int64_t)batch * p.q_batch_stride;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int qrow = 16 * h + r;
+            const bool live = qrow < p.nq_valid;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                qf[h][c] = *reinterpret_cast<const f32x4*>(qb + (live ? qrow : 0) * kDim + 16 * c + 4 * g);
+                if (!live) qf[h][c] = (f32x4){0.f, 0.f, 0.f, 0.f};  // zero padding (main.cpp:206-211)
+            }
+            qglob[h] = batch * kMaxBatch + (live ? qrow : 0);
+            qn[h] = p.qnorm[qglob[h]];
+            tau[h] = live ? p.tau0[qglob[h]] : -VS_INF;  // padding queries never produce a candidate
+        }
+    };
+
+    int4* wbuf = p.sink.wbuf + ((int64_t)blockIdx.x * kScanWaves + wave) * p.sink.wcap;
+    int wbase = 0;  // wave-uniform fill of the private candidate buffer
+    int tk_cur = wave, tk_nxt = wave + kScanWaves, pass_cur, pass_nxt;
+    int tile_cur = tile_of(tk_cur, pass_cur);
+    int tile_nxt = tile_of(tk_nxt, pass_nxt);
+    issue_tile(tile_cur, 0);
+    issue_tile(tile_nxt, 1);
+    int have_pass = -1;
+
+    auto step = [&](const int sl) __attribute__((always_inline)) {
+        if (pass_cur != have_pass) {  // wave-uniform: this wave enters the next batch
+            load_pass(pass_cur);
+            have_pass = pass_cur;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // operands are here (and so are both staged tiles)
+        }
+        const int tk_new = next_ticket();
+        int pass_new;
+        const int tile_new = tile_of(tk_new, pass_new);
+        asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        const char* src = smem + sl * kSlotBytes;
+        f32x4 a[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) a[c] = *reinterpret_cast<const f32x4*>(src + fa[c]);
+        const f32x4 bn = *reinterpret_cast<const f32x4*>(src + fa_n);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        issue_tile(tile_new, sl);  // the slot is refilled as soon as its fragments sit in registers
+        f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][i], qf[h][c][i], acc[h], 0, 0, 0);
+        float d[2][4];
+        bool any = false;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                // cpu_baseline.cpp:241  dist = qn + bn - 2*dot  (gcc contracts to fnmadd(2, dot, qn+bn))
+                const float l2 = fmaf(-2.0f, acc[h][j], qn[h] + bn[j]);
+                d[h][j] = p.metric ? -acc[h][j] : l2;
+                any = any || d[h][j] < tau[h];
+            }
+        if (__ballot(any)) {  // rare: a few hundred rows per query per million
+            const int row_t = tile_cur * TR + 4 * g;
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int row = row_t + j;
+                    const bool pass = d[h][j] < tau[h] && row < (int)p.n_rows;
+                    const unsigned long long mask = __ballot(pass);
+                    if (mask) {
+                        const int pos = wbase + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+                        if (pass && pos < p.sink.wcap)
+                            wbuf[pos] = make_int4(qglob[h], __builtin_bit_cast(int, d[h][j]), row + p.id_offset, 0);
+                        wbase += __popcll(mask);
+                    }
+                }
+        }
+        tk_cur = tk_nxt;
+        tile_cur = tile_nxt;
+        pass_cur = pass_nxt;
+        tk_nxt = tk_new;
+        tile_nxt = tile_new;
+        pass_nxt = pass_new;
+    };
+    while (tk_cur < total) {
+        step(0);
+        if (tk_cur >= total) break;
+        step(1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // retire the tail prefetches before the wave ends
+    if (lane == 0) p.sink.wcount[(int)blockIdx.x * kScanWaves + wave] = wbase;
+}
+
+hipError_t launch_scan_f32_stream(const StreamParams& p, int grid, hipStream_t s) {
+    static bool attr_set[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!attr_set[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(scan_f32s_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kWideLds);
+        if (e != hipSuccess) return e;
+        attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL(scan_f32s_kernel, dim3(grid), dim3(kScanThreads), kWideLds, s, p);
+    hipLaunchKernelGGL(cand_bin_kernel, dim3(grid * kScanWaves), dim3(256), 0, s, p.sink);
+    return hipGetLastError();
 }
 
 hipError_t launch_scan_i8_wide(const WideParams& p, int grid, int nqh, hipStream_t s) {
@@ -1114,6 +1351,7 @@ hipError_t launch_scan_i8_wide(const WideParams& p, int grid, int nqh, hipStream
     }
     if (which) hipLaunchKernelGGL(k8, dim3(grid), dim3(kScanThreads), kWideLds, s, p);
     else hipLaunchKernelGGL(k4, dim3(grid), dim3(kScanThreads), kWideLds, s, p);
+    hipLaunchKernelGGL(cand_bin_kernel, dim3(grid * kScanWaves), dim3(256), 0, s, p.sink);
     return hipGetLastError();
 }
 
@@ -1532,6 +1770,7 @@ __global__ __launch_bounds__(256) void merge_compact_kernel(const MergeParams p,
     const int q_in = p.q_group_out > 0 ? (q / p.q_group_out) * p.q_group_in + (q % p.q_group_out) : q;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
+    if (p.run_if && ((p.run_mode == 1 && !p.run_if[0]) || (p.run_mode == 2 && p.run_if[0]))) return;
     if (p.invalid && p.q_group_out > 0 && p.invalid[q / p.q_group_out]) {
         // the int8 scan skipped this batch (a query was not an integer in [0, 255]): tell the caller to rerun it
         for (int t = tid; t < p.kout; t += 256) {

@@ -474,11 +474,11 @@ def test_wide_int8_scan_equals_fp32_path(gpu_pkg):
         assert out[1][2].max() <= 1
 
 
-def test_wide_int8_scan_overflow_reruns_in_fp32(gpu_pkg):
-    """More rows under a query's bound than its candidate list holds (here: tens of thousands of identical rows): the
-    device API says so (flags = 2) and the host API reruns the batch on the fp32 path -- results stay exact."""
+def test_streaming_scan_overflow_falls_back_on_the_device(gpu_pkg):
+    """More rows under a query's bound than the candidate buffers hold (here: tens of thousands of identical rows): the
+    binning launch raises the overflow word and the per-batch scan + merge enqueued behind the streaming scan produce
+    the result instead -- same outputs as ever, on both data paths, with no host round trip and no special flag."""
     import torch
-    rng = np.random.default_rng(73)
     base = gpu_pkg.synth_sift(100000, seed=74)
     base[20000:60000] = base[7]           # 40 000 copies of one row
     q = gpu_pkg.synth_sift(5 * 32, seed=75)
@@ -486,16 +486,21 @@ def test_wide_int8_scan_overflow_reruns_in_fp32(gpu_pkg):
     q[33] = base[7] + 1
     dev = torch.device("cuda", 0)
     qd = torch.from_numpy(q).to(dev)
-    with gpu_pkg.BruteForceIndex(base) as idx:
-        idx.set_precision(2)
-        o_d = torch.zeros((160, 6), dtype=torch.float32, device=dev)
-        o_i = torch.zeros((160, 6), dtype=torch.int32, device=dev)
-        fl = torch.zeros((160,), dtype=torch.int32, device=dev)
-        idx.search_dev_multi(qd.data_ptr(), 5, 32, 5, o_i.data_ptr(), o_d.data_ptr(), fl.data_ptr(), torch.cuda.current_stream().cuda_stream)
-        torch.cuda.synchronize()
-        f = fl.cpu().numpy()
-        assert f[0] == 2 and f[33] == 2
-        idx.set_precision(0)
-        ids, d = idx.search(q, 5)
     oi, od = oracle.search_bf(base, q, 5)
-    assert np.array_equal(ids, oi) and np.array_equal(d, od)
+    ex = oracle.exact_int_dists(q, base)
+    with gpu_pkg.BruteForceIndex(base) as idx:
+        for precision in (1, 2):
+            idx.set_precision(precision)
+            o_d = torch.zeros((160, 6), dtype=torch.float32, device=dev)
+            o_i = torch.zeros((160, 6), dtype=torch.int32, device=dev)
+            fl = torch.zeros((160,), dtype=torch.int32, device=dev)
+            idx.search_dev_multi(qd.data_ptr(), 5, 32, 5, o_i.data_ptr(), o_d.data_ptr(), fl.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            f, gi, gd = fl.cpu().numpy(), o_i.cpu().numpy(), o_d.cpu().numpy()
+            assert f.max() <= 1 and f[0] == 1 and f[33] == 1          # ties among the copies, nothing skipped
+            assert np.array_equal(gd, np.sort(ex, axis=1)[:, :6].astype(np.float32))
+            assert np.array_equal(np.take_along_axis(ex, gi.astype(np.int64), 1).astype(np.float32), gd)
+            keep = f == 0
+            assert np.array_equal(gi[keep, :5], oi[keep])
+            ids, d = idx.search(q, 5)
+            assert np.array_equal(ids, oi) and np.array_equal(d, od)
