@@ -86,7 +86,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=40)
-    ap.add_argument("--repeats", type=int, default=5, help="the timed region of K steps is repeated R times; the median is reported")
+    ap.add_argument("--repeats", type=int, default=0,
+                    help="the timed region of K steps is repeated R times and the median is reported; 0 = as many as fit "
+                         "a quarter of a second (at least 5, at most 200): a short region (K = 20 is under 2 ms) is at the mercy of "
+                         "clock ramps and launch jitter, many of them back to back are not")
     ap.add_argument("--coll-every", type=int, default=32,
                     help="batches per multi-batch call (and per all-gather + merge when N > 1)")
     ap.add_argument("--rows", type=int, default=N_BASE, help="base rows (default SIFT-1M)")
@@ -132,7 +135,7 @@ def main():
 
     n_rows = args.rows
     steps, warmup, S = max(1, args.steps), max(1, args.warmup), max(1, min(32, args.coll_every))
-    R = max(1, args.repeats)
+    R = args.repeats  # 0 = chosen from the first region's length (the same on every rank: the time is the max over ranks)
     K1 = K + 1
 
     # ---------------------------------------------------------------- data (synthetic, deterministic)
@@ -231,13 +234,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(step_fn, nsteps, nwarm, repeats=R):
-        """W warm-up steps, then `repeats` regions of exactly `nsteps` steps, each bracketed by barrier + synchronize,
-        max over ranks per region; returns the list of region times."""
+    def timed(step_fn, nsteps, nwarm, repeats=None):
+        """W warm-up steps, then R regions of exactly `nsteps` steps, each bracketed by barrier + synchronize, max over
+        ranks per region; returns the list of region times."""
         for i in range(nwarm):
             step_fn(i, nwarm)
         out = []
-        for _ in range(repeats):
+        want = repeats if repeats is not None else R
+        while True:
             barrier()
             t = time.perf_counter()
             for i in range(nsteps):
@@ -249,7 +253,10 @@ def main():
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 el = float(tt.item())
             out.append(el)
-        return out
+            if want <= 0:
+                want = int(min(200, max(5, 0.25 / max(el, 1e-6))))
+            if len(out) >= want:
+                return out
 
     # ---------------------------------------------------------------- brute force fp32 (the headline)
     bf.prof_enable(not args.no_prof)
@@ -261,7 +268,8 @@ def main():
     ms_per_step = elapsed / steps * 1e3
     # the prof window covers every launch of the warm-up and of the R regions = warmup + R * steps batches (the last
     # launch of a run may hold fewer than S batches): time per batch, scaled to a launch of S batches
-    n_batches_prof = warmup + R * steps
+    R_used = len(regions)
+    n_batches_prof = warmup + R_used * steps
     kern_per_batch_s = (kern_ms * 1e-3) / n_batches_prof if kern_n else 0.0
     kern_avg_s = kern_per_batch_s * S
     rows_local = r1 - r0
@@ -275,8 +283,8 @@ def main():
             traffic = json.load(open(tpath)).get("hbm_bytes_per_batch") * S
         except Exception:
             traffic = None
-    log(f"brute force: {qps:.0f} QPS, {ms_per_step * 1e3:.1f} us/step (median of {R}: "
-        f"{', '.join(f'{e / steps * 1e6:.1f}' for e in regions)}), scan kernel {kern_per_batch_s * 1e6:.1f} us/batch "
+    log(f"brute force: {qps:.0f} QPS, {ms_per_step * 1e3:.1f} us/step (median of {R_used} regions, min "
+        f"{min(regions) / steps * 1e6:.1f} max {max(regions) / steps * 1e6:.1f}), scan kernel {kern_per_batch_s * 1e6:.1f} us/batch "
         f"({achieved:.0f} GB/s algorithmic)")
 
     # exactness guard on what was just timed: ascending, finite, ids in range
@@ -302,7 +310,7 @@ def main():
             assert np.array_equal(out_d.cpu().numpy(), fp32_d) and np.array_equal(out_i.cpu().numpy(), fp32_i), \
                 "int8 path differs from the fp32 path"
             el8 = median(reg8)
-            k8_s = (k8_ms * 1e-3) / n_batches_prof * S if k8_n else 0.0
+            k8_s = (k8_ms * 1e-3) / (warmup + len(reg8) * steps) * S if k8_n else 0.0
             # the wide scan serves VSEARCH_I8_WIDE / 2 batches of 32 queries per pass over the rows (default 4): its
             # algorithmic bytes per launch are one pass of u8 rows + i32 row terms per GROUP of batches
             bpp = max(1, int(os.environ.get("VSEARCH_I8_WIDE", "8")) // 2)
@@ -331,7 +339,7 @@ def main():
         tm = pkg.Timing()
         bf.search(queries[:nq_h], K)  # pinned staging + tie scratch allocated here, not in the timed calls
         th = []
-        for _ in range(R):
+        for _ in range(5):
             t = time.perf_counter()
             hid, hdd = bf.search(queries[:nq_h], K, tm)
             th.append(time.perf_counter() - t)
@@ -448,7 +456,7 @@ def main():
                 ib = row_bytes * uniq_rows + 4 * info["avg_candidates"] * BATCH   # per batch
                 # kernel time per batch: every launch of the prof window (warm-up + R regions), divided by the batches
                 # they held -- launches of different sizes are never averaged as if they were equal
-                ks_batch = (okern_ms * 1e-3) / n_batches_prof if okern_n else 0.0
+                ks_batch = (okern_ms * 1e-3) / (warmup + len(ireg) * steps) if okern_n else 0.0
                 ach = ib / ks_batch / 1e9 if ks_batch > 0 else None
                 itraffic = None
                 ipath = os.path.join(ROOT, "profiles", "traffic_ivf_list_scan.json")
@@ -478,7 +486,7 @@ def main():
             tm = pkg.Timing()
             ivf.searchBatch(queries, n_queries, K, NPROBE)
             th = []
-            for _ in range(R):
+            for _ in range(5):
                 t = time.perf_counter()
                 ivf.searchBatch(queries, n_queries, K, NPROBE, tm)
                 th.append(time.perf_counter() - t)
@@ -533,8 +541,8 @@ def main():
             "config": {"workload": f"SIFT-1M-shaped synthetic {n_rows}x{DIM} fp32 base, brute force, batch={BATCH}, k={K}",
                        "parallelism": f"row-shard x{world}" if world > 1 else "single GPU",
                        "collective_every_steps": S if world > 1 else None, "collective": coll_kind},
-            "repeats": R,
-            "ms_per_step_regions": [round(e / steps * 1e3, 5) for e in regions],
+            "repeats": R_used,
+            "ms_per_step_min_max": [round(min(regions) / steps * 1e3, 5), round(max(regions) / steps * 1e3, 5)],
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": "vs::scan_kernel<2,8,0,0>", "kernel_us": round(kern_avg_s * 1e6, 2),

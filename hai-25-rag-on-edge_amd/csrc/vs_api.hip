@@ -41,7 +41,8 @@ constexpr int kSlotWords = 32 * vs::kIvfSlots;  // per-batch slot minima of the 
 constexpr int kMaxLanes = 4;
 constexpr int kMaxMulti = 32;  // batches per persistent scan launch
 constexpr int kWideWaveCap = 1024;  // entries per wave buffer of the wide int8 scan (expected fill: about 100 per launch)
-constexpr int kWideCap = 2048;    // candidate slots per query of the wide int8 scan (more: the batch is rerun in fp32)
+constexpr int kWideSub = 16;      // sub-lists per query of the streaming scans' candidate lists
+constexpr int kWideCap = 128;     // entries per sub-list (2048 per query; more: the per-batch scan behind takes over)
 constexpr int kTieDense = 4096;   // rows whose distances the tie resolver takes densely
 constexpr int kTieCap = 8192;     // candidate slots per flagged query (more: full-row fallback)
 
@@ -537,9 +538,9 @@ int ensure_wide(vs_index::Lane& L) {
     int rc;
     if ((rc = dev_alloc(&L.q8, (size_t)kMaxMulti * 32 * vs::kDim))) return rc;
     if ((rc = dev_alloc(&L.qterm, (size_t)kMaxMulti * 32))) return rc;
-    if ((rc = dev_alloc(&L.wcnt, (size_t)kMaxMulti * 32))) return rc;
-    if ((rc = dev_alloc(&L.wcand_d, (size_t)kMaxMulti * 32 * kWideCap))) return rc;
-    if ((rc = dev_alloc(&L.wcand_i, (size_t)kMaxMulti * 32 * kWideCap))) return rc;
+    if ((rc = dev_alloc(&L.wcnt, (size_t)kMaxMulti * 32 * kWideSub))) return rc;
+    if ((rc = dev_alloc(&L.wcand_d, (size_t)kMaxMulti * 32 * kWideSub * kWideCap))) return rc;
+    if ((rc = dev_alloc(&L.wcand_i, (size_t)kMaxMulti * 32 * kWideSub * kWideCap))) return rc;
     if ((rc = dev_alloc(&L.wbuf, (size_t)vs::kSlotStride * vs::kScanWaves * kWideWaveCap))) return rc;
     if ((rc = dev_alloc(&L.wcount, (size_t)vs::kSlotStride * vs::kScanWaves + 1))) return rc;
     return VS_OK;
@@ -632,7 +633,7 @@ int bf_launch(vs_index* h, vs_index::Lane& L, const float* q_dev, int nb, int B,
     int32_t* overflow = nullptr;
     if (stream) {
         overflow = L.wcount + vs::kSlotStride * vs::kScanWaves;
-        HIPCHK(hipMemsetAsync(L.wcnt, 0, (size_t)nb * 32 * sizeof(int32_t), s));
+        HIPCHK(hipMemsetAsync(L.wcnt, 0, (size_t)nb * 32 * kWideSub * sizeof(int32_t), s));
         HIPCHK(hipMemsetAsync(overflow, 0, sizeof(int32_t), s));
         vs::CandSink sink{};
         sink.wbuf = L.wbuf;
@@ -643,6 +644,7 @@ int bf_launch(vs_index* h, vs_index::Lane& L, const float* q_dev, int nb, int B,
         sink.cand_d = L.wcand_d;
         sink.cand_i = L.wcand_i;
         sink.cap = kWideCap;
+        sink.nsub = kWideSub;
         prof_begin(h, 0, s);
         if (use_u8) {
             vs::WideParams wp{};
@@ -683,12 +685,12 @@ int bf_launch(vs_index* h, vs_index::Lane& L, const float* q_dev, int nb, int B,
         vs::MergeParams mf = m;
         mf.part_d = L.wcand_d;
         mf.part_i = L.wcand_i;
-        mf.G = 1;
+        mf.G = kWideSub;
         mf.kin = kWideCap;
         mf.flat_len = L.wcnt;
         mf.run_if = overflow;
         mf.run_mode = 2;
-        HIPCHK(vs::launch_merge_layout(mf, 0, kWideCap, s));
+        HIPCHK(vs::launch_merge_layout(mf, kWideCap, (int64_t)kWideSub * kWideCap, s));
         // Fallback, enqueued behind and idle unless a candidate buffer overflowed (thousands of rows under one query's
         // bound: masses of duplicates): the per-batch scan with lane lists, which copes with any data.
         p.run_if = overflow;

@@ -100,10 +100,13 @@ struct CandSink {
     int wcap;
     int32_t* overflow;       // [1] (pre-set to 0): a wave buffer or a query list overflowed -> the launch's fallback kernels
                              //     (the per-batch scan + its merge, enqueued behind with run_if = overflow) produce the result
-    int32_t* cnt;            // [n_batches][32] candidates per query (pre-set to 0)
-    float* cand_d;           // [n_batches][32][cap]
+    // per-query lists, split into nsub sub-lists (wave buffer w appends to sub-list w % nsub) so that the appending
+    // atomics of one query spread over nsub counters
+    int32_t* cnt;            // [n_batches][32][nsub] entries per sub-list (pre-set to 0)
+    float* cand_d;           // [n_batches][32][nsub][cap]
     int32_t* cand_i;
-    int cap;
+    int cap;                 // per sub-list
+    int nsub;
 };
 
 struct WideParams {
@@ -157,8 +160,7 @@ struct MergeParams {
     int flag_empty;          // flags = 2 for a query with no finite entry at all (cross-GPU merge: every shard skipped its batch)
     const int32_t* run_if;   // optional [1] with run_mode: 1 = run only if *run_if != 0, 2 = only if *run_if == 0 (the other
     int run_mode;            //   launch of the pair writes the outputs)
-    const int32_t* flat_len; // optional [queries]: the query's row holds min(flat_len, kin) UNSORTED candidates (G = 1);
-                             // flat_len > kin = the list overflowed -> flags = 2
+    const int32_t* flat_len; // optional [queries][G]: list (q, g) holds flat_len[q * G + g] <= kin UNSORTED candidates
 };
 hipError_t launch_merge(const MergeParams& p, hipStream_t s);  // scan-partial layout [G][nq_stride][kin]
 // general layout: entry (g, q, j) at g*stride_g + q*stride_q + j

@@ -1144,14 +1144,16 @@ __global__ __launch_bounds__(256) void cand_bin_kernel(const CandSink p) {
         return;
     }
     const int4* src = p.wbuf + (int64_t)wb * p.wcap;
+    const int sub = wb % p.nsub;
     for (int e = threadIdx.x; e < n; e += 256) {
         const int4 c = src[e];
-        const int pos = atomicAdd(p.cnt + c.x, 1);
+        const int64_t lst = (int64_t)c.x * p.nsub + sub;
+        const int pos = atomicAdd(p.cnt + lst, 1);
         if (pos < p.cap) {
-            p.cand_d[(int64_t)c.x * p.cap + pos] = __builtin_bit_cast(float, c.y);
-            p.cand_i[(int64_t)c.x * p.cap + pos] = c.z;
+            p.cand_d[lst * p.cap + pos] = __builtin_bit_cast(float, c.y);
+            p.cand_i[lst * p.cap + pos] = c.z;
         } else {
-            p.overflow[0] = 1;  // more rows under a query's bound than its list holds
+            p.overflow[0] = 1;  // more rows under a query's bound than its lists hold
         }
     }
 }
@@ -1444,25 +1446,36 @@ __global__ __launch_bounds__(256) void seed_kernel(const SeedParams p) {
         qn[h] = p.qnorm[batch * kMaxBatch + qrow];
     }
     float m[2] = {VS_INF, VS_INF};
-    for (int t = 0; t < kSeedTilesPerWave; ++t) {
-        const int64_t tile = seed_tile(tiles_total, chunk * kSeedTilesPerWave + t);
-        if (tile >= tiles_total) break;  // wave-uniform
-        const int64_t row0 = tile * kTileRows;
-        f32x4 a[8];
+    // two tiles per step: their loads go out together (see seed_kernel_i8)
+    constexpr int U = 2;
+    for (int t0 = 0; t0 < kSeedTilesPerWave; t0 += U) {
+        f32x4 a[U][8], bn[U];
+        int64_t row0[U];
+        bool ok[U];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) a[c] = *reinterpret_cast<const f32x4*>(p.base + (row0 + r) * kDim + 16 * c + 4 * g);
-        const f32x4 bn = *reinterpret_cast<const f32x4*>(p.bnorm + row0 + 4 * g);  // padded by 64
+        for (int u = 0; u < U; ++u) {
+            const int64_t tile = seed_tile(tiles_total, chunk * kSeedTilesPerWave + t0 + u);
+            ok[u] = tile < tiles_total;  // wave-uniform
+            row0[u] = (ok[u] ? tile : 0) * kTileRows;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int c = 0; c < 8; ++c) a[u][c] = *reinterpret_cast<const f32x4*>(p.base + (row0[u] + r) * kDim + 16 * c + 4 * g);
+            bn[u] = *reinterpret_cast<const f32x4*>(p.bnorm + row0[u] + 4 * g);  // padded by 64
+        }
 #pragma unroll
-            for (int c = 0; c < 8; ++c)
+        for (int u = 0; u < U; ++u) {
+            if (!ok[u]) continue;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][i], qf[h][c][i], acc, 0, 0, 0);
+            for (int h = 0; h < 2; ++h) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float d = p.metric ? -acc[j] : fmaf(-2.0f, acc[j], qn[h] + bn[j]);  // the scan's own expression
-                if (row0 + 4 * g + j < p.n_rows) m[h] = fminf(m[h], d);
+                for (int c = 0; c < 8; ++c)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][c][i], qf[h][c][i], acc, 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float d = p.metric ? -acc[j] : fmaf(-2.0f, acc[j], qn[h] + bn[u][j]);  // the scan's own expression
+                    if (row0[u] + 4 * g + j < p.n_rows) m[h] = fminf(m[h], d);
+                }
             }
         }
     }
@@ -1518,22 +1531,35 @@ __global__ __launch_bounds__(256) void seed_kernel_i8(const SeedParams p) {
         qterm[h] = (int)p.qnorm[batch * kMaxBatch + qrow] - 256 * part - 4194304;
     }
     float m[2] = {VS_INF, VS_INF};
-    for (int t = 0; t < kSeedTilesPerWave; ++t) {
-        const int64_t tile = seed_tile(tiles_total, chunk * kSeedTilesPerWave + t);
-        if (tile >= tiles_total) break;
-        const int64_t row0 = tile * kTileRows;
-        // A fragments: bytes k = 16 g .. 16 g + 15 and 64 + 16 g .. of row row0 + r
-        const i32x4 a0 = *reinterpret_cast<const i32x4*>(p.base_u8 + (row0 + r) * kDim + 16 * g);
-        const i32x4 a1 = *reinterpret_cast<const i32x4*>(p.base_u8 + (row0 + r) * kDim + 64 + 16 * g);
-        const i32x4 rt = *reinterpret_cast<const i32x4*>(p.rterm + row0 + 4 * g);  // padded by 64
+    // four tiles per step: their loads go out together (the tiles are L2 / Infinity Cache hits; one at a time the loop
+    // would pay that latency 32 times in a row)
+    constexpr int U = 4;
+    for (int t0 = 0; t0 < kSeedTilesPerWave; t0 += U) {
+        i32x4 a0[U], a1[U], rt[U];
+        int64_t row0[U];
+        bool ok[U];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            i32x4 acc = {0, 0, 0, 0};
-            acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, qi[h][0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, qi[h][1], acc, 0, 0, 0);
+        for (int u = 0; u < U; ++u) {
+            const int64_t tile = seed_tile(tiles_total, chunk * kSeedTilesPerWave + t0 + u);
+            ok[u] = tile < tiles_total;  // wave-uniform
+            row0[u] = (ok[u] ? tile : 0) * kTileRows;
+            // A fragments: bytes k = 16 g .. 16 g + 15 and 64 + 16 g .. of row row0 + r
+            a0[u] = *reinterpret_cast<const i32x4*>(p.base_u8 + (row0[u] + r) * kDim + 16 * g);
+            a1[u] = *reinterpret_cast<const i32x4*>(p.base_u8 + (row0[u] + r) * kDim + 64 + 16 * g);
+            rt[u] = *reinterpret_cast<const i32x4*>(p.rterm + row0[u] + 4 * g);  // padded by 64
+        }
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (row0 + 4 * g + j < p.n_rows) m[h] = fminf(m[h], (float)(qterm[h] + rt[j] - 2 * acc[j]));
+        for (int u = 0; u < U; ++u) {
+            if (!ok[u]) continue;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                i32x4 acc = {0, 0, 0, 0};
+                acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0[u], qi[h][0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1[u], qi[h][1], acc, 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (row0[u] + 4 * g + j < p.n_rows) m[h] = fminf(m[h], (float)(qterm[h] + rt[u][j] - 2 * acc[j]));
+            }
         }
     }
 #pragma unroll
@@ -1783,21 +1809,18 @@ __global__ __launch_bounds__(256) void merge_compact_kernel(const MergeParams p,
     if (tid == 0) cnt = 0;
     __syncthreads();
     if (p.flat_len) {
-        // one unsorted candidate list per query (wide int8 scan): the first min(len, kin) entries of the query's row
-        const int len = p.flat_len[q_in];
-        if (len > p.kin) {  // the list overflowed: the caller reruns the batch on another path
-            for (int t = tid; t < p.kout; t += 256) {
-                if (p.out_d) p.out_d[(int64_t)q * p.kout + t] = VS_INF;
-                if (p.out_i) p.out_i[(int64_t)q * p.kout + t] = -1;
+        // G unsorted candidate lists per query (streaming scans): list g holds flat_len[q_in * G + g] <= kin entries
+        int off = 0;
+        for (int g = 0; g < p.G; ++g) {
+            const int len = min(p.flat_len[(int64_t)q_in * p.G + g], p.kin);
+            const int64_t src = ((int64_t)q_in * p.G + g) * p.kin;
+            for (int e = tid; e < len; e += 256) {
+                cd[off + e] = p.part_d[src + e];
+                ci[off + e] = p.part_i[src + e];
             }
-            if (tid == 0 && p.flags) p.flags[q] = 2;
-            return;
+            off += len;
         }
-        for (int e = tid; e < len; e += 256) {
-            cd[e] = p.part_d[(int64_t)q_in * L.stride_q + e];
-            ci[e] = p.part_i[(int64_t)q_in * L.stride_q + e];
-        }
-        if (tid == 0) cnt = len;
+        if (tid == 0) cnt = off;
     } else
     for (int g = tid; g < p.G; g += 256) {
         const int64_t off = (int64_t)g * L.stride_g + (int64_t)q_in * L.stride_q;
