@@ -1010,7 +1010,7 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_i8w_kernel(const WidePar
     // per-pass state: B operands of the NQH column blocks, the queries' constant terms and integer bounds.
     // d = qt + rt - 2 acc < tau  <=>  2 acc - rt > qt - tau =: thr  (the hot loop never forms d)
     i32x4 qb[NQH][2];
-    int qt[NQH], thr[NQH], qglob[NQH];
+    int qt[NQH], thr[NQH], thr2[NQH], qglob[NQH];
     auto load_pass = [&](int pass) __attribute__((always_inline)) {
 #pragma unroll
         for (int h = 0; h < NQH; ++h) {
@@ -1028,6 +1028,7 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_i8w_kernel(const WidePar
             // are below 2^24, so any bound from 2^26 on admits everything)
             const int ti = (int)ceilf(fminf(fmaxf(t0, -67108864.f), 67108864.f));
             thr[h] = dead ? 0x7fffffff : qt[h] - ti;
+            thr2[h] = dead ? 0x7fffffff : (thr[h] >> 1);  // floor: an odd thr is lowered by one (see the hot loop)
             qglob[h] = bq;
         }
     };
@@ -1062,26 +1063,27 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_i8w_kernel(const WidePar
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         issue_tile(tile_new, sl);  // the slot is refilled as soon as its fragments sit in registers
         const int row_t = tile_cur * TR + 4 * g;
-        // hot loop, branch free: per column block 8 MFMAs and e = 2 acc - rt folded to its maximum; a block whose maximum
-        // exceeds the query's threshold holds a candidate (a few per tile) and is recomputed below
-        i32x4 nrt[4];
+        // hot loop, branch free: d < tau  <=>  2 dot - rt > thr.  With rt = 2 rh + ro (ro = 0 / 1) that is
+        // 2 (dot - rh) - ro > thr, which for an EVEN thr means dot - rh > thr / 2 whatever ro is -- and an odd thr may be
+        // lowered by one here, because a block that passes is recomputed and tested exactly below.  -rh goes in as the C
+        // operand of the first MFMA, so the accumulators come out as dot - rh and the only vector work per column block
+        // is the maximum of its 16 values.
+        i32x4 nrh[4];
 #pragma unroll
-        for (int rg = 0; rg < 4; ++rg) nrt[rg] = -rtv[rg];
+        for (int rg = 0; rg < 4; ++rg) nrh[rg] = -(rtv[rg] >> 1);
         unsigned hit = 0;
 #pragma unroll
         for (int h = 0; h < NQH; ++h) {
             i32x4 acc[4];
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
-                acc[rg] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0[rg], qb[h][0], (i32x4){0, 0, 0, 0}, 0, 0, 0);
+                acc[rg] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0[rg], qb[h][0], nrh[rg], 0, 0, 0);
                 acc[rg] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1[rg], qb[h][1], acc[rg], 0, 0, 0);
             }
-            int emax = (int)0x80000000;
+            int emax = max(max(acc[0][0], acc[0][1]), max(acc[0][2], acc[0][3]));
 #pragma unroll
-            for (int rg = 0; rg < 4; ++rg)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) emax = max(emax, 2 * acc[rg][j] + nrt[rg][j]);
-            hit |= emax > thr[h] ? (1u << h) : 0u;
+            for (int rg = 1; rg < 4; ++rg) emax = max(max(emax, acc[rg][0]), max(max(acc[rg][1], acc[rg][2]), acc[rg][3]));
+            hit |= emax > thr2[h] ? (1u << h) : 0u;
         }
         // wave-uniform union of the hit bits (DPP or-reduction)
         unsigned um = hit;
@@ -1102,7 +1104,7 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_i8w_kernel(const WidePar
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int row = row_t + 16 * rg + j;
-                        const bool pass = 2 * acc[j] + nrt[rg][j] > thr[h] && row < (int)p.n_rows;
+                        const bool pass = 2 * acc[j] - rtv[rg][j] > thr[h] && row < (int)p.n_rows;
                         const unsigned long long mask = __ballot(pass);
                         if (mask) {  // wave-uniform
                             // This wave's private candidate buffer, positions from the ballot: plain stores, no atomics -- a
