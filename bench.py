@@ -545,7 +545,7 @@ def main():
             "ms_per_step_min_max": [round(min(regions) / steps * 1e3, 5), round(max(regions) / steps * 1e3, 5)],
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "vs::scan_kernel<2,8,0,0>", "kernel_us": round(kern_avg_s * 1e6, 2),
+                         "kernel": "vs::scan_f32s_kernel", "kernel_us": round(kern_avg_s * 1e6, 2),
                          "kernel_us_per_batch": round(kern_per_batch_s * 1e6, 2),
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "batches_per_launch": S,

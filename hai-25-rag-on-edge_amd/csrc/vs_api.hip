@@ -663,6 +663,8 @@ int bf_launch(vs_index* h, vs_index::Lane& L, const float* q_dev, int nb, int B,
             const int64_t tiles64 = (h->n_rows + 63) / 64;
             const int wgrid = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(h->num_cus, vs::kSlotStride), tiles64));
             HIPCHK(vs::launch_scan_i8_wide(wp, wgrid, g_i8_wide, s));
+            prof_end(h, 0, s);
+            HIPCHK(vs::launch_cand_bin(sink, wgrid, s));
         } else {
             vs::StreamParams sp{};
             sp.base = h->d_vecs;
@@ -679,8 +681,9 @@ int bf_launch(vs_index* h, vs_index::Lane& L, const float* q_dev, int nb, int B,
             sp.sink = sink;
             const int sgrid = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(h->num_cus, vs::kSlotStride), tiles_total));
             HIPCHK(vs::launch_scan_f32_stream(sp, sgrid, s));
+            prof_end(h, 0, s);
+            HIPCHK(vs::launch_cand_bin(sink, sgrid, s));
         }
-        prof_end(h, 0, s);
         // every query's candidate list (unsorted, a few hundred entries) -> k1 best by (dist, id), tie flags
         vs::MergeParams mf = m;
         mf.part_d = L.wcand_d;

@@ -140,6 +140,7 @@ struct StreamParams {
     CandSink sink;
 };
 hipError_t launch_scan_f32_stream(const StreamParams& p, int grid, hipStream_t s);
+hipError_t launch_cand_bin(const CandSink& sink, int grid, hipStream_t s);  // after either streaming scan, same grid
 
 // Cross-workgroup merge of sorted partial lists -> [nq][kout] + tie flags (+ seed thresholds).
 struct MergeParams {

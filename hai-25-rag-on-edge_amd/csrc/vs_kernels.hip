@@ -1043,7 +1043,7 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_i8w_kernel(const WidePar
     int have_pass = -1;
 
     auto step = [&](const int sl) __attribute__((always_inline)) {
-        if (pass_cur != have_pass) {  // wave-uniform: this wave enters a new pass
+        if (pass_cur != have_pass) {  // wave-uniform; only a wave's very first tile comes through here (see below)
             load_pass(pass_cur);
             have_pass = pass_cur;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // operands are here (and so are both staged tiles)
@@ -1061,7 +1061,11 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_i8w_kernel(const WidePar
             rtv[rg] = *reinterpret_cast<const i32x4*>(src + fa_n + 64 * rg);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        issue_tile(tile_new, sl);  // the slot is refilled as soon as its fragments sit in registers
+        const bool same_pass = pass_nxt == pass_cur;  // wave-uniform
+        // the slot is refilled as soon as its fragments sit in registers -- except on the wave's last tile of a pass:
+        // there the next pass's operands are fetched first (after this tile's arithmetic, into the same registers), so
+        // that the refill is the younger request and the next step's counted wait covers both
+        if (same_pass) issue_tile(tile_new, sl);
         const int row_t = tile_cur * TR + 4 * g;
         // hot loop, branch free: d < tau  <=>  2 dot - rt > thr.  With rt = 2 rh + ro (ro = 0 / 1) that is
         // 2 (dot - rh) - ro > thr, which for an EVEN thr means dot - rh > thr / 2 whatever ro is -- and an odd thr may be
@@ -1120,6 +1124,13 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_i8w_kernel(const WidePar
                     }
                 }
             }
+        }
+        if (!same_pass) {
+            if (pass_nxt < n_pass) {
+                load_pass(pass_nxt);
+                have_pass = pass_nxt;
+            }
+            issue_tile(tile_new, sl);
         }
         tk_cur = tk_nxt;
         tile_cur = tile_nxt;
@@ -1258,7 +1269,7 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_f32s_kernel(const Stream
     int have_pass = -1;
 
     auto step = [&](const int sl) __attribute__((always_inline)) {
-        if (pass_cur != have_pass) {  // wave-uniform: this wave enters the next batch
+        if (pass_cur != have_pass) {  // wave-uniform; only a wave's very first tile comes through here (see below)
             load_pass(pass_cur);
             have_pass = pass_cur;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // operands are here (and so are both staged tiles)
@@ -1273,7 +1284,11 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_f32s_kernel(const Stream
         for (int c = 0; c < 8; ++c) a[c] = *reinterpret_cast<const f32x4*>(src + fa[c]);
         const f32x4 bn = *reinterpret_cast<const f32x4*>(src + fa_n);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        issue_tile(tile_new, sl);  // the slot is refilled as soon as its fragments sit in registers
+        const bool same_pass = pass_nxt == pass_cur;  // wave-uniform
+        // the slot is refilled as soon as its fragments sit in registers -- except on the wave's last tile of a batch:
+        // there the next batch's queries are fetched first (after this tile's arithmetic, into the same registers), so
+        // that the refill is the younger request and the next step's counted wait covers both
+        if (same_pass) issue_tile(tile_new, sl);
         f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
         for (int c = 0; c < 8; ++c)
@@ -1309,6 +1324,13 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_f32s_kernel(const Stream
                     }
                 }
         }
+        if (!same_pass) {
+            if (pass_nxt < p.n_batches) {
+                load_pass(pass_nxt);
+                have_pass = pass_nxt;
+            }
+            issue_tile(tile_new, sl);
+        }
         tk_cur = tk_nxt;
         tile_cur = tile_nxt;
         pass_cur = pass_nxt;
@@ -1335,7 +1357,12 @@ hipError_t launch_scan_f32_stream(const StreamParams& p, int grid, hipStream_t s
         attr_set[dev] = true;
     }
     hipLaunchKernelGGL(scan_f32s_kernel, dim3(grid), dim3(kScanThreads), kWideLds, s, p);
-    hipLaunchKernelGGL(cand_bin_kernel, dim3(grid * kScanWaves), dim3(256), 0, s, p.sink);
+    return hipGetLastError();
+}
+
+// wave buffers -> per-query lists (after either streaming scan; `grid` = that scan's grid)
+hipError_t launch_cand_bin(const CandSink& sink, int grid, hipStream_t s) {
+    hipLaunchKernelGGL(cand_bin_kernel, dim3(grid * kScanWaves), dim3(256), 0, s, sink);
     return hipGetLastError();
 }
 
@@ -1355,7 +1382,6 @@ hipError_t launch_scan_i8_wide(const WideParams& p, int grid, int nqh, hipStream
     }
     if (which) hipLaunchKernelGGL(k8, dim3(grid), dim3(kScanThreads), kWideLds, s, p);
     else hipLaunchKernelGGL(k4, dim3(grid), dim3(kScanThreads), kWideLds, s, p);
-    hipLaunchKernelGGL(cand_bin_kernel, dim3(grid * kScanWaves), dim3(256), 0, s, p.sink);
     return hipGetLastError();
 }
 
