@@ -1043,7 +1043,7 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_i8w_kernel(const WidePar
     int have_pass = -1;
 
     auto step = [&](const int sl) __attribute__((always_inline)) {
-        if (pass_cur != have_pass) {  // wave-uniform; only a wave's very first tile comes through here (see below)
+        if (pass_cur != have_pass) {  // wave-uniform: this wave enters a new pass (four batches: the drain is amortised)
             load_pass(pass_cur);
             have_pass = pass_cur;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // operands are here (and so are both staged tiles)
@@ -1061,11 +1061,7 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_i8w_kernel(const WidePar
             rtv[rg] = *reinterpret_cast<const i32x4*>(src + fa_n + 64 * rg);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const bool same_pass = pass_nxt == pass_cur;  // wave-uniform
-        // the slot is refilled as soon as its fragments sit in registers -- except on the wave's last tile of a pass:
-        // there the next pass's operands are fetched first (after this tile's arithmetic, into the same registers), so
-        // that the refill is the younger request and the next step's counted wait covers both
-        if (same_pass) issue_tile(tile_new, sl);
+        issue_tile(tile_new, sl);  // the slot is refilled as soon as its fragments sit in registers
         const int row_t = tile_cur * TR + 4 * g;
         // hot loop, branch free: d < tau  <=>  2 dot - rt > thr.  With rt = 2 rh + ro (ro = 0 / 1) that is
         // 2 (dot - rh) - ro > thr, which for an EVEN thr means dot - rh > thr / 2 whatever ro is -- and an odd thr may be
@@ -1124,13 +1120,6 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_i8w_kernel(const WidePar
                     }
                 }
             }
-        }
-        if (!same_pass) {
-            if (pass_nxt < n_pass) {
-                load_pass(pass_nxt);
-                have_pass = pass_nxt;
-            }
-            issue_tile(tile_new, sl);
         }
         tk_cur = tk_nxt;
         tile_cur = tile_nxt;
@@ -1238,24 +1227,32 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_f32s_kernel(const Stream
         return (int)blockIdx.x + (tk - dec_base) * G;
     };
 
-    // per-batch state: the 32 queries as B operands (qf[h][c][i] = Q[16 h + r][16 c + 4 g + i]), their norms and bounds
+    // per-batch state: the 32 queries as B operands (qf[h][c][i] = Q[16 h + r][16 c + 4 g + i]), their norms and bounds.
+    // The loads are inline asm on purpose: the compiler does not know them as memory operations, so it puts no
+    // s_waitcnt of its own in front of their first use (it would be vmcnt(0): a drain of the tile queue in every
+    // step); the hand-counted waits of the tile loop cover them.  A padding query (main.cpp:206-211) reads row 0 and
+    // is masked where candidates are taken: its MFMA column influences nothing else.
     f32x4 qf[2][8];
     float qn[2], tau[2];
     int qglob[2];
+    bool live[2];
     auto load_pass = [&](int batch) __attribute__((always_inline)) {
         const float* qb = p.q + (int64_t)batch * p.q_batch_stride;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int qrow = 16 * h + r;
-            const bool live = qrow < p.nq_valid;
+            live[h] = qrow < p.nq_valid;
+            qglob[h] = batch * kMaxBatch + (live[h] ? qrow : 0);
+            const float* src = qb + (live[h] ? qrow : 0) * kDim + 4 * g;
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
-                qf[h][c] = *reinterpret_cast<const f32x4*>(qb + (live ? qrow : 0) * kDim + 16 * c + 4 * g);
-                if (!live) qf[h][c] = (f32x4){0.f, 0.f, 0.f, 0.f};  // zero padding (main.cpp:206-211)
+                const float* pc = src + 16 * c;
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(qf[h][c]) : "v"(pc) : "memory");
             }
-            qglob[h] = batch * kMaxBatch + (live ? qrow : 0);
-            qn[h] = p.qnorm[qglob[h]];
-            tau[h] = live ? p.tau0[qglob[h]] : -VS_INF;  // padding queries never produce a candidate
+            const float* pn = p.qnorm + qglob[h];
+            const float* pt = p.tau0 + qglob[h];
+            asm volatile("global_load_dword %0, %1, off" : "=v"(qn[h]) : "v"(pn) : "memory");
+            asm volatile("global_load_dword %0, %1, off" : "=v"(tau[h]) : "v"(pt) : "memory");
         }
     };
 
@@ -1305,7 +1302,7 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_f32s_kernel(const Stream
                 // cpu_baseline.cpp:241  dist = qn + bn - 2*dot  (gcc contracts to fnmadd(2, dot, qn+bn))
                 const float l2 = fmaf(-2.0f, acc[h][j], qn[h] + bn[j]);
                 d[h][j] = p.metric ? -acc[h][j] : l2;
-                any = any || d[h][j] < tau[h];
+                any = any || (live[h] && d[h][j] < tau[h]);
             }
         if (__ballot(any)) {  // rare: a few hundred rows per query per million
             const int row_t = tile_cur * TR + 4 * g;
@@ -1314,7 +1311,7 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_f32s_kernel(const Stream
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int row = row_t + j;
-                    const bool pass = d[h][j] < tau[h] && row < (int)p.n_rows;
+                    const bool pass = live[h] && d[h][j] < tau[h] && row < (int)p.n_rows;
                     const unsigned long long mask = __ballot(pass);
                     if (mask) {
                         const int pos = wbase + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
