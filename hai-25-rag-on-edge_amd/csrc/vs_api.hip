@@ -105,11 +105,11 @@ struct vs_index {
         // wide int8 scan (several batches per pass over the rows): prepared queries + per-query candidate lists
         int8_t* q8 = nullptr;        // [kMaxMulti][32][128]
         int32_t* qterm = nullptr;    // [kMaxMulti][32]
-        int32_t* wcnt = nullptr;     // [kMaxMulti][32]
+        int32_t* wcnt = nullptr;     // [16] (word 0: overflow) + [kMaxMulti][32][kWideSub]
         float* wcand_d = nullptr;    // [kMaxMulti][32][kWideCap]
         int32_t* wcand_i = nullptr;
         int4* wbuf = nullptr;        // [256 * 8][kWideWaveCap] wave-private candidate buffers of the scan
-        int32_t* wcount = nullptr;   // [256 * 8] + [1] overflow word
+        int32_t* wcount = nullptr;   // [256 * 8]
     };
     Lane lane[kMaxLanes];
     int n_lanes = 1;
@@ -538,11 +538,11 @@ int ensure_wide(vs_index::Lane& L) {
     int rc;
     if ((rc = dev_alloc(&L.q8, (size_t)kMaxMulti * 32 * vs::kDim))) return rc;
     if ((rc = dev_alloc(&L.qterm, (size_t)kMaxMulti * 32))) return rc;
-    if ((rc = dev_alloc(&L.wcnt, (size_t)kMaxMulti * 32 * kWideSub))) return rc;
+    if ((rc = dev_alloc(&L.wcnt, (size_t)kMaxMulti * 32 * kWideSub + 16))) return rc;  // [0] = overflow word, lists' counters from [16]
     if ((rc = dev_alloc(&L.wcand_d, (size_t)kMaxMulti * 32 * kWideSub * kWideCap))) return rc;
     if ((rc = dev_alloc(&L.wcand_i, (size_t)kMaxMulti * 32 * kWideSub * kWideCap))) return rc;
     if ((rc = dev_alloc(&L.wbuf, (size_t)vs::kSlotStride * vs::kScanWaves * kWideWaveCap))) return rc;
-    if ((rc = dev_alloc(&L.wcount, (size_t)vs::kSlotStride * vs::kScanWaves + 1))) return rc;
+    if ((rc = dev_alloc(&L.wcount, (size_t)vs::kSlotStride * vs::kScanWaves))) return rc;
     return VS_OK;
 }
 
@@ -632,15 +632,14 @@ int bf_launch(vs_index* h, vs_index::Lane& L, const float* q_dev, int nb, int B,
     m.invalid = use_u8 ? h->d_invalid : nullptr;
     int32_t* overflow = nullptr;
     if (stream) {
-        overflow = L.wcount + vs::kSlotStride * vs::kScanWaves;
-        HIPCHK(hipMemsetAsync(L.wcnt, 0, (size_t)nb * 32 * kWideSub * sizeof(int32_t), s));
-        HIPCHK(hipMemsetAsync(overflow, 0, sizeof(int32_t), s));
+        overflow = L.wcnt;  // one memset clears the overflow word and the lists' counters behind it
+        HIPCHK(hipMemsetAsync(L.wcnt, 0, ((size_t)nb * 32 * kWideSub + 16) * sizeof(int32_t), s));
         vs::CandSink sink{};
         sink.wbuf = L.wbuf;
         sink.wcount = L.wcount;
         sink.wcap = kWideWaveCap;
         sink.overflow = overflow;
-        sink.cnt = L.wcnt;
+        sink.cnt = L.wcnt + 16;
         sink.cand_d = L.wcand_d;
         sink.cand_i = L.wcand_i;
         sink.cap = kWideCap;
@@ -690,7 +689,7 @@ int bf_launch(vs_index* h, vs_index::Lane& L, const float* q_dev, int nb, int B,
         mf.part_i = L.wcand_i;
         mf.G = kWideSub;
         mf.kin = kWideCap;
-        mf.flat_len = L.wcnt;
+        mf.flat_len = L.wcnt + 16;
         mf.run_if = overflow;
         mf.run_mode = 2;
         HIPCHK(vs::launch_merge_layout(mf, kWideCap, (int64_t)kWideSub * kWideCap, s));

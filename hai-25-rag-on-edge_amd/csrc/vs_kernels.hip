@@ -1442,9 +1442,11 @@ __device__ __forceinline__ int64_t seed_tile(int64_t tiles_total, int s) {  // s
 
 __global__ __launch_bounds__(256) void seed_kernel(const SeedParams p) {
     const int lane = threadIdx.x & 63;
-    const int wid = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
-    const int batch = wid / kSeedChunks, chunk = wid % kSeedChunks;
-    if (batch >= p.n_batches) return;
+    // one workgroup per (batch, group of 32 sample tiles); its four waves take 8 tiles each (a quarter of the serial
+    // chain of one wave per group) and fold their minima through LDS
+    __shared__ float wm[4][kMaxBatch];
+    const int wv = (int)(threadIdx.x >> 6);
+    const int batch = (int)blockIdx.x / kSeedChunks, chunk = (int)blockIdx.x % kSeedChunks;
     const int r = lane & 15, g = lane >> 4;
     const int64_t tiles_total = (p.n_rows + kTileRows - 1) / kTileRows;
     const float* qb = p.q + (int64_t)batch * p.q_batch_stride;
@@ -1464,7 +1466,7 @@ __global__ __launch_bounds__(256) void seed_kernel(const SeedParams p) {
     float m[2] = {VS_INF, VS_INF};
     // two tiles per step: their loads go out together (see seed_kernel_i8)
     constexpr int U = 2;
-    for (int t0 = 0; t0 < kSeedTilesPerWave; t0 += U) {
+    for (int t0 = wv * (kSeedTilesPerWave / 4); t0 < (wv + 1) * (kSeedTilesPerWave / 4); t0 += U) {
         f32x4 a[U][8], bn[U];
         int64_t row0[U];
         bool ok[U];
@@ -1500,10 +1502,14 @@ __global__ __launch_bounds__(256) void seed_kernel(const SeedParams p) {
         m[h] = fminf(m[h], __shfl_xor(m[h], 16));
         m[h] = fminf(m[h], __shfl_xor(m[h], 32));
     }
-    float* dst = p.wmin + ((int64_t)batch * kSeedChunks + chunk) * kMaxBatch;  // 128 contiguous bytes per wave
     if (g == 0) {
-        dst[r] = m[0];
-        dst[16 + r] = m[1];
+        wm[wv][r] = m[0];
+        wm[wv][16 + r] = m[1];
+    }
+    __syncthreads();
+    if (threadIdx.x < kMaxBatch) {  // fminf keeps a -inf ("no bound from this kernel") if any wave wrote one
+        float* dst = p.wmin + ((int64_t)batch * kSeedChunks + chunk) * kMaxBatch;  // 128 contiguous bytes per group
+        dst[threadIdx.x] = fminf(fminf(wm[0][threadIdx.x], wm[1][threadIdx.x]), fminf(wm[2][threadIdx.x], wm[3][threadIdx.x]));
     }
 }
 
@@ -1511,9 +1517,11 @@ __global__ __launch_bounds__(256) void seed_kernel(const SeedParams p) {
 __global__ __launch_bounds__(256) void seed_kernel_i8(const SeedParams p) {
     typedef int i32x4 __attribute__((ext_vector_type(4)));
     const int lane = threadIdx.x & 63;
-    const int wid = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
-    const int batch = wid / kSeedChunks, chunk = wid % kSeedChunks;
-    if (batch >= p.n_batches) return;
+    // one workgroup per (batch, group of 32 sample tiles); its four waves take 8 tiles each (a quarter of the serial
+    // chain of one wave per group) and fold their minima through LDS
+    __shared__ float wm[4][kMaxBatch];
+    const int wv = (int)(threadIdx.x >> 6);
+    const int batch = (int)blockIdx.x / kSeedChunks, chunk = (int)blockIdx.x % kSeedChunks;
     const int r = lane & 15, g = lane >> 4;
     const int64_t tiles_total = (p.n_rows + kTileRows - 1) / kTileRows;
     const float* qb = p.q + (int64_t)batch * p.q_batch_stride;
@@ -1550,7 +1558,7 @@ __global__ __launch_bounds__(256) void seed_kernel_i8(const SeedParams p) {
     // four tiles per step: their loads go out together (the tiles are L2 / Infinity Cache hits; one at a time the loop
     // would pay that latency 32 times in a row)
     constexpr int U = 4;
-    for (int t0 = 0; t0 < kSeedTilesPerWave; t0 += U) {
+    for (int t0 = wv * (kSeedTilesPerWave / 4); t0 < (wv + 1) * (kSeedTilesPerWave / 4); t0 += U) {
         i32x4 a0[U], a1[U], rt[U];
         int64_t row0[U];
         bool ok[U];
@@ -1584,10 +1592,14 @@ __global__ __launch_bounds__(256) void seed_kernel_i8(const SeedParams p) {
         m[h] = fminf(m[h], __shfl_xor(m[h], 32));
         if (!__all(q_ok)) m[h] = -VS_INF;  // not an int8 batch: no bound from this kernel (-inf survives the minima below)
     }
-    float* dst = p.wmin + ((int64_t)batch * kSeedChunks + chunk) * kMaxBatch;
     if (g == 0) {
-        dst[r] = m[0];
-        dst[16 + r] = m[1];
+        wm[wv][r] = m[0];
+        wm[wv][16 + r] = m[1];
+    }
+    __syncthreads();
+    if (threadIdx.x < kMaxBatch) {  // fminf keeps a -inf ("no bound from this kernel") if any wave wrote one
+        float* dst = p.wmin + ((int64_t)batch * kSeedChunks + chunk) * kMaxBatch;  // 128 contiguous bytes per group
+        dst[threadIdx.x] = fminf(fminf(wm[0][threadIdx.x], wm[1][threadIdx.x]), fminf(wm[2][threadIdx.x], wm[3][threadIdx.x]));
     }
 }
 
@@ -1612,7 +1624,7 @@ __global__ __launch_bounds__(1024) void seed_tau_kernel(const SeedParams p) {
 
 hipError_t launch_seed(const SeedParams& p, hipStream_t s) {
     hipLaunchKernelGGL(seed_qnorm_kernel, dim3(p.n_batches), dim3(256), 0, s, p);
-    const int wgs = (p.n_batches * kSeedChunks + 3) / 4;  // one wave per (batch, chunk)
+    const int wgs = p.n_batches * kSeedChunks;  // one workgroup per (batch, group of sample tiles)
     if (p.base_u8) hipLaunchKernelGGL(seed_kernel_i8, dim3(wgs), dim3(256), 0, s, p);
     else hipLaunchKernelGGL(seed_kernel, dim3(wgs), dim3(256), 0, s, p);
     hipLaunchKernelGGL(seed_tau_kernel, dim3(p.n_batches), dim3(1024), 0, s, p);
