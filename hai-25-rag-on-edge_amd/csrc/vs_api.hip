@@ -538,7 +538,7 @@ int ensure_wide(vs_index::Lane& L) {
     int rc;
     if ((rc = dev_alloc(&L.q8, (size_t)kMaxMulti * 32 * vs::kDim))) return rc;
     if ((rc = dev_alloc(&L.qterm, (size_t)kMaxMulti * 32))) return rc;
-    if ((rc = dev_alloc(&L.wcnt, (size_t)kMaxMulti * 32 * kWideSub + 16))) return rc;  // [0] = overflow word, lists' counters from [16]
+    if ((rc = dev_alloc(&L.wcnt, (size_t)kMaxMulti * 32 * kWideSub + 64))) return rc;  // overflow word | skipped batches | list counters
     if ((rc = dev_alloc(&L.wcand_d, (size_t)kMaxMulti * 32 * kWideSub * kWideCap))) return rc;
     if ((rc = dev_alloc(&L.wcand_i, (size_t)kMaxMulti * 32 * kWideSub * kWideCap))) return rc;
     if ((rc = dev_alloc(&L.wbuf, (size_t)vs::kSlotStride * vs::kScanWaves * kWideWaveCap))) return rc;
@@ -581,16 +581,19 @@ int bf_launch(vs_index* h, vs_index::Lane& L, const float* q_dev, int nb, int B,
     scan_geometry(h->n_rows, h->num_cus, grid, tp, seeded ? 0 : (u8_path ? 16 : 6) * vs::kScanWaves);
     const bool exchange = !seeded && grid >= 16 && tp >= (u8_path ? 16 : 6) * vs::kScanWaves && g_xchg_first_it >= 0;
     const bool use_u8 = u8_path;
-    if (use_u8) HIPCHK(hipMemsetAsync(h->d_invalid, 0, (size_t)nb * sizeof(int32_t), s));
     // With the bounds known up front the batches need nothing from each other: the streaming scans (fp32: one batch per
     // pass; exact int8 rows: several batches per pass over the rows) hand out the tiles of ALL batches through one
     // ticket per workgroup and write survivors to candidate lists -- no barrier, no workgroup merge, no per-batch prologue.
     const bool i8_seed = h->d_vecs_u8 && h->metric == VS_METRIC_L2 && g_seed_i8;
     const bool stream = seeded && g_stream && (use_u8 ? (g_i8_wide > 0 && i8_seed) : true);
-    if (stream) {
+    if (seeded || use_u8) {
         int rc = ensure_wide(L);
         if (rc) return rc;
     }
+    // one zeroed block per launch: [0] overflow word | [16, 48) batches the int8 path has to skip | [64, ...) list counters
+    int32_t* const overflow = L.wcnt;
+    int32_t* const invalid = L.wcnt ? L.wcnt + 16 : nullptr;
+    if (L.wcnt) HIPCHK(hipMemsetAsync(L.wcnt, 0, (64 + (stream ? (size_t)nb * 32 * kWideSub : 0)) * sizeof(int32_t), s));
     if (seeded) {
         vs::SeedParams sp{};
         sp.base = h->d_vecs;
@@ -609,10 +612,10 @@ int bf_launch(vs_index* h, vs_index::Lane& L, const float* q_dev, int nb, int B,
         sp.qnorm = L.seed_qnorm;
         sp.wmin = L.seed_wmin;
         sp.tau0 = L.tau0;
-        if (stream && use_u8) {
+        if (i8_seed) {  // queries as bytes + constant terms + the "not byte valued" verdict: int8 seed and wide int8 scan
             sp.q8 = L.q8;
             sp.qterm = L.qterm;
-            sp.invalid = h->d_invalid;
+            sp.invalid = invalid;
         }
         HIPCHK(vs::launch_seed(sp, s));
         p.tau0 = L.tau0;
@@ -629,17 +632,14 @@ int bf_launch(vs_index* h, vs_index::Lane& L, const float* q_dev, int nb, int B,
     m.flags = flags;
     m.q_group_out = B;
     m.q_group_in = vs::kMaxBatch;
-    m.invalid = use_u8 ? h->d_invalid : nullptr;
-    int32_t* overflow = nullptr;
+    m.invalid = use_u8 ? invalid : nullptr;
     if (stream) {
-        overflow = L.wcnt;  // one memset clears the overflow word and the lists' counters behind it
-        HIPCHK(hipMemsetAsync(L.wcnt, 0, ((size_t)nb * 32 * kWideSub + 16) * sizeof(int32_t), s));
         vs::CandSink sink{};
         sink.wbuf = L.wbuf;
         sink.wcount = L.wcount;
         sink.wcap = kWideWaveCap;
         sink.overflow = overflow;
-        sink.cnt = L.wcnt + 16;
+        sink.cnt = L.wcnt + 64;
         sink.cand_d = L.wcand_d;
         sink.cand_i = L.wcand_i;
         sink.cap = kWideCap;
@@ -653,7 +653,7 @@ int bf_launch(vs_index* h, vs_index::Lane& L, const float* q_dev, int nb, int B,
             wp.q8 = L.q8;
             wp.qterm = L.qterm;
             wp.tau0 = L.tau0;
-            wp.invalid = h->d_invalid;
+            wp.invalid = invalid;
             wp.n_batches = nb;
             wp.nq_valid = B;
             wp.bpb = nqh;
@@ -689,7 +689,7 @@ int bf_launch(vs_index* h, vs_index::Lane& L, const float* q_dev, int nb, int B,
         mf.part_i = L.wcand_i;
         mf.G = kWideSub;
         mf.kin = kWideCap;
-        mf.flat_len = L.wcnt + 16;
+        mf.flat_len = L.wcnt + 64;
         mf.run_if = overflow;
         mf.run_mode = 2;
         HIPCHK(vs::launch_merge_layout(mf, kWideCap, (int64_t)kWideSub * kWideCap, s));
@@ -707,7 +707,7 @@ int bf_launch(vs_index* h, vs_index::Lane& L, const float* q_dev, int nb, int B,
     if (use_u8) {
         p.base_u8 = h->d_vecs_u8;
         p.rterm = h->d_rterm;
-        p.invalid = h->d_invalid;
+        p.invalid = invalid;
     }
     if (!stream) prof_begin(h, 0, s);
     HIPCHK(vs::launch_scan(p, grid, kcap, nqh, vs::kModeTopK, s));

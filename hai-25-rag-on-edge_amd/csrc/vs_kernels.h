@@ -65,7 +65,7 @@ struct SeedParams {
     const float* base;       // [n_rows (+pad)][128]
     const float* bnorm;
     const int8_t* base_u8;   // optional exact int8 copy (x - 128) + row terms: the seed then runs on v_mfma_i32_16x16x64_i8
-    const int32_t* rterm;    //   (16x fewer MFMA cycles); a batch with a non-integer query gets tau0 = +inf
+    const int32_t* rterm;    //   (16x fewer MFMA cycles) for batches whose queries are byte valued too (q8 / qterm / invalid below are then required)
     int64_t n_rows;
     const float* q;          // [n_batches][nq_valid][128]
     int n_batches;

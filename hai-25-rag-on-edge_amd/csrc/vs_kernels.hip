@@ -1391,9 +1391,9 @@ static hipError_t launch_scan_t(const ScanParams& p, int grid, hipStream_t s) {
 
 
 // ------------------------------------------------------------------------------------------------
-// Seed bounds (see SeedParams).  seed_qnorm_kernel: ||q||^2 in the reference's order; seed_kernel: one wave per
-// sample tile, A fragments and row norms in registers for the whole launch, the queries of every batch straight
-// from global memory (L2) as the B operand; seed_tau_kernel: 32 group minima per query -> k1-th smallest.
+// Seed bounds (see SeedParams).  seed_qnorm_kernel: ||q||^2 in the reference's order (+ the queries as bytes for the
+// int8 paths); seed_kernel: minima of 64 groups of 32 sample tiles per (batch, query); seed_tau_kernel: k1-th smallest
+// of a query's 64 group minima.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void seed_qnorm_kernel(const SeedParams p) {
     const int batch = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
@@ -1440,14 +1440,8 @@ __device__ __forceinline__ int64_t seed_tile(int64_t tiles_total, int s) {  // s
     return tiles_total >= kSeedWaves ? (int64_t)s * (tiles_total / kSeedWaves) : s;
 }
 
-__global__ __launch_bounds__(256) void seed_kernel(const SeedParams p) {
-    const int lane = threadIdx.x & 63;
-    // one workgroup per (batch, group of 32 sample tiles); its four waves take 8 tiles each (a quarter of the serial
-    // chain of one wave per group) and fold their minima through LDS
-    __shared__ float wm[4][kMaxBatch];
-    const int wv = (int)(threadIdx.x >> 6);
-    const int batch = (int)blockIdx.x / kSeedChunks, chunk = (int)blockIdx.x % kSeedChunks;
-    const int r = lane & 15, g = lane >> 4;
+// this wave's share (8 of the group's 32 sample tiles) on the fp32 rows -> per-query minima m[h] of column 16 h + r
+__device__ __forceinline__ void seed_body_f32(const SeedParams& p, int batch, int chunk, int wv, int r, int g, float (&m)[2]) {
     const int64_t tiles_total = (p.n_rows + kTileRows - 1) / kTileRows;
     const float* qb = p.q + (int64_t)batch * p.q_batch_stride;
     f32x4 qf[2][8];
@@ -1463,8 +1457,7 @@ __global__ __launch_bounds__(256) void seed_kernel(const SeedParams p) {
         }
         qn[h] = p.qnorm[batch * kMaxBatch + qrow];
     }
-    float m[2] = {VS_INF, VS_INF};
-    // two tiles per step: their loads go out together (see seed_kernel_i8)
+    // two tiles per step: their loads go out together (one at a time the loop would pay the cache latency per tile)
     constexpr int U = 2;
     for (int t0 = wv * (kSeedTilesPerWave / 4); t0 < (wv + 1) * (kSeedTilesPerWave / 4); t0 += U) {
         f32x4 a[U][8], bn[U];
@@ -1497,67 +1490,24 @@ __global__ __launch_bounds__(256) void seed_kernel(const SeedParams p) {
             }
         }
     }
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        m[h] = fminf(m[h], __shfl_xor(m[h], 16));
-        m[h] = fminf(m[h], __shfl_xor(m[h], 32));
-    }
-    if (g == 0) {
-        wm[wv][r] = m[0];
-        wm[wv][16 + r] = m[1];
-    }
-    __syncthreads();
-    if (threadIdx.x < kMaxBatch) {  // fminf keeps a -inf ("no bound from this kernel") if any wave wrote one
-        float* dst = p.wmin + ((int64_t)batch * kSeedChunks + chunk) * kMaxBatch;  // 128 contiguous bytes per group
-        dst[threadIdx.x] = fminf(fminf(wm[0][threadIdx.x], wm[1][threadIdx.x]), fminf(wm[2][threadIdx.x], wm[3][threadIdx.x]));
-    }
 }
 
-// int8 variant (rows and queries integers in [0, 255]): the same distances as exact integers, see scan_kernel PREC = 1
-__global__ __launch_bounds__(256) void seed_kernel_i8(const SeedParams p) {
+// the same on the exact int8 copy (rows and queries integers in [0, 255]): the same distances as exact integers, see
+// scan_kernel PREC = 1; the queries as bytes and their constant terms come from seed_qnorm_kernel
+__device__ __forceinline__ void seed_body_i8(const SeedParams& p, int batch, int chunk, int wv, int r, int g, float (&m)[2]) {
     typedef int i32x4 __attribute__((ext_vector_type(4)));
-    const int lane = threadIdx.x & 63;
-    // one workgroup per (batch, group of 32 sample tiles); its four waves take 8 tiles each (a quarter of the serial
-    // chain of one wave per group) and fold their minima through LDS
-    __shared__ float wm[4][kMaxBatch];
-    const int wv = (int)(threadIdx.x >> 6);
-    const int batch = (int)blockIdx.x / kSeedChunks, chunk = (int)blockIdx.x % kSeedChunks;
-    const int r = lane & 15, g = lane >> 4;
     const int64_t tiles_total = (p.n_rows + kTileRows - 1) / kTileRows;
-    const float* qb = p.q + (int64_t)batch * p.q_batch_stride;
     i32x4 qi[2][2];
     int qterm[2];
-    bool q_ok = true;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int qrow = h * 16 + r;
-        const bool qv = qrow < p.nq_valid;
-        int part = 0;
-#pragma unroll
-        for (int half = 0; half < 2; ++half)
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(qb + (qv ? qrow : 0) * kDim + half * 64 + 16 * g + 4 * w);
-                unsigned word = 0;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float x = qv ? v[e] : 128.f;
-                    const int xi = (int)x;
-                    q_ok = q_ok && ((float)xi == x) && xi >= 0 && xi <= 255;
-                    const int sb = xi - 128;
-                    part += sb;
-                    word |= ((unsigned)(sb & 0xff)) << (8 * e);
-                }
-                qi[h][half][w] = (int)word;
-            }
-        part += __shfl_xor(part, 16);
-        part += __shfl_xor(part, 32);
-        qterm[h] = (int)p.qnorm[batch * kMaxBatch + qrow] - 256 * part - 4194304;
+        const int8_t* src = p.q8 + ((int64_t)batch * kMaxBatch + qrow) * kDim;  // padding queries are all-zero rows
+        qi[h][0] = *reinterpret_cast<const i32x4*>(src + 16 * g);
+        qi[h][1] = *reinterpret_cast<const i32x4*>(src + 64 + 16 * g);
+        qterm[h] = p.qterm[batch * kMaxBatch + qrow];
     }
-    float m[2] = {VS_INF, VS_INF};
-    // four tiles per step: their loads go out together (the tiles are L2 / Infinity Cache hits; one at a time the loop
-    // would pay that latency 32 times in a row)
-    constexpr int U = 4;
+    constexpr int U = 4;  // four tiles per step
     for (int t0 = wv * (kSeedTilesPerWave / 4); t0 < (wv + 1) * (kSeedTilesPerWave / 4); t0 += U) {
         i32x4 a0[U], a1[U], rt[U];
         int64_t row0[U];
@@ -1586,18 +1536,31 @@ __global__ __launch_bounds__(256) void seed_kernel_i8(const SeedParams p) {
             }
         }
     }
+}
+
+// One workgroup per (batch, group of 32 sample tiles); its four waves take 8 tiles each (a quarter of the serial chain
+// of one wave per group) and fold their minima through LDS.  A batch whose queries are byte valued uses the exact int8
+// copy of the rows when there is one; any other batch (workgroup-uniform choice) the fp32 rows.
+__global__ __launch_bounds__(256) void seed_kernel(const SeedParams p) {
+    __shared__ float wm[4][kMaxBatch];
+    const int lane = threadIdx.x & 63;
+    const int wv = (int)(threadIdx.x >> 6);
+    const int batch = (int)blockIdx.x / kSeedChunks, chunk = (int)blockIdx.x % kSeedChunks;
+    const int r = lane & 15, g = lane >> 4;
+    float m[2] = {VS_INF, VS_INF};
+    if (p.base_u8 && p.invalid[batch] == 0) seed_body_i8(p, batch, chunk, wv, r, g, m);
+    else seed_body_f32(p, batch, chunk, wv, r, g, m);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         m[h] = fminf(m[h], __shfl_xor(m[h], 16));
         m[h] = fminf(m[h], __shfl_xor(m[h], 32));
-        if (!__all(q_ok)) m[h] = -VS_INF;  // not an int8 batch: no bound from this kernel (-inf survives the minima below)
     }
     if (g == 0) {
         wm[wv][r] = m[0];
         wm[wv][16 + r] = m[1];
     }
     __syncthreads();
-    if (threadIdx.x < kMaxBatch) {  // fminf keeps a -inf ("no bound from this kernel") if any wave wrote one
+    if (threadIdx.x < kMaxBatch) {
         float* dst = p.wmin + ((int64_t)batch * kSeedChunks + chunk) * kMaxBatch;  // 128 contiguous bytes per group
         dst[threadIdx.x] = fminf(fminf(wm[0][threadIdx.x], wm[1][threadIdx.x]), fminf(wm[2][threadIdx.x], wm[3][threadIdx.x]));
     }
@@ -1617,16 +1580,14 @@ __global__ __launch_bounds__(1024) void seed_tau_kernel(const SeedParams p) {
             const unsigned long long msk = __ballot(v == kth);
             if (msk != 0ull && lane == __builtin_ctzll(msk)) v = VS_INF;  // drop exactly one instance
         }
-        // (-inf = the int8 seed met a non-integer query: no bound for this batch)
-        if (lane == 0) p.tau0[batch * kMaxBatch + q] = (kth < VS_INF && kth > -VS_INF) ? next_up(kth) : VS_INF;
+        if (lane == 0) p.tau0[batch * kMaxBatch + q] = kth < VS_INF ? next_up(kth) : VS_INF;
     }
 }
 
 hipError_t launch_seed(const SeedParams& p, hipStream_t s) {
     hipLaunchKernelGGL(seed_qnorm_kernel, dim3(p.n_batches), dim3(256), 0, s, p);
     const int wgs = p.n_batches * kSeedChunks;  // one workgroup per (batch, group of sample tiles)
-    if (p.base_u8) hipLaunchKernelGGL(seed_kernel_i8, dim3(wgs), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(seed_kernel, dim3(wgs), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(seed_kernel, dim3(wgs), dim3(256), 0, s, p);
     hipLaunchKernelGGL(seed_tau_kernel, dim3(p.n_batches), dim3(1024), 0, s, p);
     return hipGetLastError();
 }
@@ -1838,9 +1799,13 @@ __global__ __launch_bounds__(256) void merge_compact_kernel(const MergeParams p,
     __syncthreads();
     if (p.flat_len) {
         // G unsorted candidate lists per query (streaming scans): list g holds flat_len[q_in * G + g] <= kin entries
+        // (the lengths are fetched together: one after the other they would cost G cache round trips)
+        __shared__ int s_len[64];
+        if (tid < p.G && tid < 64) s_len[tid] = min(p.flat_len[(int64_t)q_in * p.G + tid], p.kin);
+        __syncthreads();
         int off = 0;
-        for (int g = 0; g < p.G; ++g) {
-            const int len = min(p.flat_len[(int64_t)q_in * p.G + g], p.kin);
+        for (int g = 0; g < p.G && g < 64; ++g) {
+            const int len = s_len[g];
             const int64_t src = ((int64_t)q_in * p.G + g) * p.kin;
             for (int e = tid; e < len; e += 256) {
                 cd[off + e] = p.part_d[src + e];
