@@ -467,3 +467,51 @@ def test_native_index_builder_end_to_end(gpu_pkg, tmp_path):
     with gpu_pkg.IVFIndex(d) as ivf2:
         ids2, dd2, total2 = ivf2.searchBatch(q, 64, 5, 8)
     assert np.array_equal(ids2, ids) and np.array_equal(dd2, dd) and total2 == total
+
+
+def test_c5_shape_eight_list_shards(gpu_pkg):
+    """BASELINE.json config 5 in shape: nlist = 1024, nprobe = 32, k = 5, batch 32, lists dealt to 8 ranks (longest
+    first, round robin).  Eight shard indexes on one GPU stand in for the ranks; each runs the multi-batch device call the
+    ranks run, the per-shard top-k lists are merged exactly as the all-gather + merge of vs_ivf_search_dev_sharded does
+    (vs_topk_merge_dev over [world][n][k]) and must equal the unsharded result; every list is owned exactly once and the
+    rows per rank are balanced within 5 %."""
+    import torch
+    n, nlist, k, nprobe, world, nb = 150_000, 1024, 5, 32, 8, 6
+    key = ("built", n, nlist)
+    if key not in _INDEX_CACHE:
+        base = gpu_pkg.synth_sift(n, seed=41)
+        _INDEX_CACHE[key] = (base,) + tuple(gpu_pkg.ivf_build(base, nlist, max_iter=8, seed=42))
+    base, vr, off, r2o, cents, _ = _INDEX_CACHE[key]
+    owners = gpu_pkg.ivf_list_owners(off, world)
+    sizes = np.diff(off)
+    rows_per_rank = np.array([sizes[owners == r].sum() for r in range(world)])
+    assert rows_per_rank.sum() == n and rows_per_rank.max() <= 1.05 * rows_per_rank.mean()
+    dev = torch.device("cuda:0")
+    q = gpu_pkg.synth_sift(nb * 32, seed=44)
+    qd = torch.from_numpy(q).to(dev)
+    s = torch.cuda.current_stream().cuda_stream
+
+    def run(rank, w):
+        with gpu_pkg.IVFIndex(vectors_reordered=vr, centroids=cents, cluster_offsets=off, reorder_to_original=r2o,
+                              rank=rank, world=w) as ivf:
+            ids = torch.zeros((nb * 32, k), dtype=torch.int32, device=dev)
+            d = torch.zeros((nb * 32, k), dtype=torch.float32, device=dev)
+            ivf.search_dev_multi(qd.data_ptr(), nb, 32, k, nprobe, ids.data_ptr(), d.data_ptr(), s)
+            torch.cuda.synchronize()
+            return d, ids
+    d_all, i_all = run(0, 1)
+    parts = [run(r, world) for r in range(world)]
+    gd = torch.stack([p[0] for p in parts]).contiguous()
+    gi = torch.stack([p[1] for p in parts]).contiguous()
+    od = torch.zeros((nb * 32, k), dtype=torch.float32, device=dev)
+    oi = torch.zeros((nb * 32, k), dtype=torch.int32, device=dev)
+    gpu_pkg.topk_merge_dev(gd.data_ptr(), gi.data_ptr(), world, nb * 32, k, k, od.data_ptr(), oi.data_ptr(), 0, s)
+    torch.cuda.synchronize()
+    assert torch.equal(od, d_all)
+    a, b = i_all.cpu().numpy(), oi.cpu().numpy()
+    ex = oracle.exact_int_dists(q, base)
+    assert np.array_equal(np.take_along_axis(ex, b.astype(np.int64), 1).astype(np.float32), od.cpu().numpy())
+    for i in range(nb * 32):
+        assert sorted(a[i].tolist()) == sorted(b[i].tolist())
+    gt, _ = oracle.search_bf(base, q, k)
+    assert oracle.recall(b[:, :1], gt[:, :1], 1) >= 0.91
