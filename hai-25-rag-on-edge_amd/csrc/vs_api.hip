@@ -43,6 +43,8 @@ constexpr int kMaxMulti = 32;  // batches per persistent scan launch
 constexpr int kWideWaveCap = 1024;  // entries per wave buffer of the wide int8 scan (expected fill: about 100 per launch)
 constexpr int kWideSub = 16;      // sub-lists per query of the streaming scans' candidate lists
 constexpr int kWideCap = 128;     // entries per sub-list (2048 per query; more: the per-batch scan behind takes over)
+constexpr int kIvfWideWaveCap = 512;  // entries per wave buffer of the wide IVF scan (expected fill: a few dozen per group)
+constexpr int kIvfWideSubCap = 64;    // entries per candidate sub-list (16 per query)
 constexpr int kTieDense = 4096;   // rows whose distances the tie resolver takes densely
 constexpr int kTieCap = 8192;     // candidate slots per flagged query (more: full-row fallback)
 
@@ -157,6 +159,23 @@ struct vs_index {
     int mb_nbk = 0;  // per-query score-block minima (32 scores per block) of the list scan
     long long mb_off_lq = 0, mb_off_lbase = 0, mb_off_qoff = 0, mb_off_probes = 0, mb_off_gd = 0, mb_off_gp = 0, mb_off_units = 0,
               mb_off_cand = 0, mb_off_scores = 0;
+    // wide IVF pipeline (super-batches of 8 batches share one list-major pass): slot tables, zeroed counters, plans,
+    // bounds, prepared queries, candidate sink
+    struct IvfWide {
+        int32_t* lq = nullptr;      // [4][nlist][256]
+        int32_t* zero = nullptr;    // one zeroed block per launch group: [4][nlist + 16] | slow [1024] | overflow (16) | list counters [1024][16]
+        size_t zero_words = 0;
+        int32_t* units = nullptr;   // [4][n_units_max][4]
+        float* tau = nullptr;       // [1024]
+        float* qnorm = nullptr;     // [1024]
+        int8_t* q8 = nullptr;       // [1024][128]
+        int32_t* qterm = nullptr;   // [1024]
+        int4* wbuf = nullptr;       // [waves][kIvfWideWaveCap]
+        int32_t* wcount = nullptr;
+        int n_waves = 0;
+        float* cand_d = nullptr;    // [1024][16][kIvfWideSubCap]
+        int32_t* cand_i = nullptr;
+    } wide;
     hipStream_t ivf_stream[8] = {};
     hipEvent_t ivf_fork = nullptr, ivf_join[8] = {};
     int64_t n_units_max = 0;
@@ -257,6 +276,10 @@ void free_all(vs_index* h) {
         if (h->ivf_fork) (void)hipEventDestroy(h->ivf_fork);
         if (h->mb_slab) (void)hipFree(h->mb_slab);
         if (h->mb_zslab) (void)hipFree(h->mb_zslab);
+        void* wd[] = {h->wide.lq, h->wide.zero, h->wide.units, h->wide.tau, h->wide.qnorm, h->wide.q8, h->wide.qterm, h->wide.wbuf,
+                      h->wide.wcount, h->wide.cand_d, h->wide.cand_i};
+        for (void* w : wd)
+            if (w) (void)hipFree(w);
     }
     for (auto& ps : h->prof_slot)
         for (auto e : ps.ev) (void)hipEventDestroy(e);
@@ -663,7 +686,7 @@ int bf_launch(vs_index* h, vs_index::Lane& L, const float* q_dev, int nb, int B,
             const int wgrid = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(h->num_cus, vs::kSlotStride), tiles64));
             HIPCHK(vs::launch_scan_i8_wide(wp, wgrid, g_i8_wide, s));
             prof_end(h, 0, s);
-            HIPCHK(vs::launch_cand_bin(sink, wgrid, s));
+            HIPCHK(vs::launch_cand_bin(sink, wgrid * vs::kScanWaves, s));
         } else {
             vs::StreamParams sp{};
             sp.base = h->d_vecs;
@@ -681,7 +704,7 @@ int bf_launch(vs_index* h, vs_index::Lane& L, const float* q_dev, int nb, int B,
             const int sgrid = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(h->num_cus, vs::kSlotStride), tiles_total));
             HIPCHK(vs::launch_scan_f32_stream(sp, sgrid, s));
             prof_end(h, 0, s);
-            HIPCHK(vs::launch_cand_bin(sink, sgrid, s));
+            HIPCHK(vs::launch_cand_bin(sink, sgrid * vs::kScanWaves, s));
         }
         // every query's candidate list (unsorted, a few hundred entries) -> k1 best by (dist, id), tie flags
         vs::MergeParams mf = m;
@@ -922,6 +945,151 @@ int g_ivf_multi = [] {
     return e ? atoi(e) : 1;
 }();
 
+int ensure_ivf_mb(vs_index* h, int nprobe, hipStream_t s);
+// tuning knob (VSEARCH_IVF_WIDE=0): launch groups use the per-batch list-major pipeline instead of the wide one
+int g_ivf_wide = [] {
+    const char* e = getenv("VSEARCH_IVF_WIDE");
+    return e ? atoi(e) : 1;
+}();
+
+int ensure_ivf_wide(vs_index* h) {
+    vs_index::IvfWide& W = h->wide;
+    if (W.lq) return VS_OK;
+    int rc;
+    const size_t nq = (size_t)kMaxMulti * 32;
+    const int n_sb_max = (kMaxMulti + vs::kIvfWideBatches - 1) / vs::kIvfWideBatches;
+    W.n_waves = vs::ivf_wide_grid_x(h->num_cus, 1) * 4;  // n_sb * grid.x(n_sb) * 4 <= this (grid.x shrinks with n_sb)
+    W.n_waves = std::max(W.n_waves, n_sb_max * vs::ivf_wide_grid_x(h->num_cus, n_sb_max) * 4);
+    W.zero_words = (size_t)n_sb_max * (h->nlist + 16) + nq + 16 + nq * kWideSub;
+    if ((rc = dev_alloc(&W.lq, (size_t)n_sb_max * h->nlist * vs::kIvfWideQ))) return rc;
+    if ((rc = dev_alloc(&W.zero, W.zero_words))) return rc;
+    if ((rc = dev_alloc(&W.units, (size_t)n_sb_max * std::max<int64_t>(h->n_units_max, 1) * 4))) return rc;
+    if ((rc = dev_alloc(&W.tau, nq))) return rc;
+    if ((rc = dev_alloc(&W.qnorm, nq))) return rc;
+    if ((rc = dev_alloc(&W.q8, nq * vs::kDim))) return rc;
+    if ((rc = dev_alloc(&W.qterm, nq))) return rc;
+    if ((rc = dev_alloc(&W.wbuf, (size_t)W.n_waves * kIvfWideWaveCap))) return rc;
+    if ((rc = dev_alloc(&W.wcount, (size_t)W.n_waves))) return rc;
+    if ((rc = dev_alloc(&W.cand_d, nq * kWideSub * kIvfWideSubCap))) return rc;
+    if ((rc = dev_alloc(&W.cand_i, nq * kWideSub * kIvfWideSubCap))) return rc;
+    return VS_OK;
+}
+
+// nb <= kMaxMulti independent batches through the wide pipeline: query preparation, coarse (MFMA) + pick per batch,
+// bounds, then per super-batch of 8 batches ONE list-major pass with candidates to the sink; binning, ranking, and the
+// exact slow path for queries without a bound (or for everybody if a candidate buffer overflowed).
+int ivf_group_wide_dev(vs_index* h, const float* q_dev, int nb, int B, int k, int nprobe, float* out_d, int32_t* out_i, hipStream_t s) {
+    int rc = ensure_ivf_mb(h, nprobe, s);
+    if (rc) return rc;
+    if ((rc = ensure_ivf_wide(h))) return rc;
+    vs_index::IvfWide& W = h->wide;
+    const int n_sb = (nb + vs::kIvfWideBatches - 1) / vs::kIvfWideBatches;
+    const size_t nq = (size_t)kMaxMulti * 32;
+    int32_t* const z_plan = W.zero;                                   // [n_sb_max][nlist + 16]
+    const int n_sb_max = (kMaxMulti + vs::kIvfWideBatches - 1) / vs::kIvfWideBatches;
+    int32_t* const z_slow = z_plan + (size_t)n_sb_max * (h->nlist + 16);  // [1024]
+    int32_t* const z_ovf = z_slow + nq;                               // [16]: word 0 = overflow
+    int32_t* const z_cnt = z_ovf + 16;                                // [1024][16]
+    HIPCHK(hipMemsetAsync(W.zero, 0, W.zero_words * sizeof(int32_t), s));
+    int32_t* const invalid = h->mb_zslab;  // [nb] (first words of the per-batch zero block: cleared here)
+    HIPCHK(hipMemsetAsync(h->mb_zslab, 0, (size_t)kMaxMulti * sizeof(int32_t), s));
+    vs::IvfMulti mb{};
+    mb.slab = h->mb_slab_stride;
+    mb.zslab = h->mb_zslab_stride * (long long)sizeof(int32_t);
+    mb.q = (long long)B * vs::kDim * sizeof(float);
+    char* sl = h->mb_slab;
+    int32_t* probes = reinterpret_cast<int32_t*>(sl + h->mb_off_probes);
+    stage_mark(h, 0, s);
+    {   // ||q||^2 (reference order), queries as bytes, constant terms, per-batch "byte valued" verdict
+        vs::SeedParams sp{};
+        sp.q = q_dev;
+        sp.n_batches = nb;
+        sp.q_batch_stride = (int64_t)B * vs::kDim;
+        sp.nq_valid = B;
+        sp.qnorm = W.qnorm;
+        sp.q8 = W.q8;
+        sp.qterm = W.qterm;
+        sp.invalid = invalid;
+        HIPCHK(vs::launch_query_prep(sp, s));
+    }
+    vs::IvfGroup grp{};
+    grp.offsets = h->d_offsets;
+    grp.lcnt = z_plan;  // non-null: the pick kernel also writes the window offsets and adds up the candidate count
+    grp.qoff = reinterpret_cast<int32_t*>(sl + h->mb_off_qoff);
+    grp.cand_count = h->d_cand;
+    grp.mb = mb;
+    HIPCHK(vs::launch_ivf_coarse_pick(q_dev, B, h->d_centroids, h->d_cnorm, h->nlist, nprobe, h->metric,
+                                      reinterpret_cast<float*>(sl + h->mb_off_scores), (h->nlist + 63) & ~63, probes, grp, s, nb));
+    stage_mark(h, 1, s);
+    vs::IvfWideParams wp{};
+    wp.vecs = h->d_vecs;
+    wp.vnorm = h->d_norm;
+    if (h->d_vecs_u8 && g_ivf_i8) {
+        wp.vecs_u8 = h->d_vecs_u8;
+        wp.rterm = h->d_rterm;
+    }
+    wp.offsets = h->d_offsets;
+    wp.chunk_list = h->d_chunk_list;
+    wp.chunk_row0 = h->d_chunk_row0;
+    wp.chunk_rows = h->d_chunk_rows;
+    wp.n_chunks = h->n_chunks;
+    wp.nlist = h->nlist;
+    wp.nprobe = nprobe;
+    wp.k = k;
+    wp.metric = h->metric;
+    wp.q = q_dev;
+    wp.q_batch_bytes = mb.q;
+    wp.n_batches = nb;
+    wp.B = B;
+    wp.qnorm = W.qnorm;
+    wp.q8 = W.q8;
+    wp.qterm = W.qterm;
+    wp.invalid = invalid;
+    wp.probes = probes;
+    wp.probes_batch_bytes = mb.slab;
+    wp.lq = W.lq;
+    wp.zero = z_plan;
+    wp.units = W.units;
+    wp.units_sb_stride = std::max<int64_t>(h->n_units_max, 1) * 4;
+    wp.tau = W.tau;
+    wp.slow = z_slow;
+    wp.sink.wbuf = W.wbuf;
+    wp.sink.wcount = W.wcount;
+    wp.sink.wcap = kIvfWideWaveCap;
+    wp.sink.overflow = z_ovf;
+    wp.sink.cnt = z_cnt;
+    wp.sink.cand_d = W.cand_d;
+    wp.sink.cand_i = W.cand_i;
+    wp.sink.cap = kIvfWideSubCap;
+    wp.sink.nsub = kWideSub;
+    wp.out_d = out_d;
+    wp.out_i = out_i;
+    wp.id_map = h->d_r2o;
+    stage_mark(h, 2, s);  // (grouping is part of the wide launch sequence below: it is charged to the fine search)
+    prof_begin(h, 1, s);
+    HIPCHK(vs::launch_ivf_wide(wp, h->num_cus, s));
+    prof_end(h, 1, s);
+    const int waves = vs::ivf_wide_grid_x(h->num_cus, n_sb) * n_sb * 4;
+    HIPCHK(vs::launch_cand_bin(wp.sink, waves, s));
+    vs::MergeParams m{};
+    m.part_d = W.cand_d;
+    m.part_i = W.cand_i;
+    m.G = kWideSub;
+    m.kin = kIvfWideSubCap;
+    m.nq = nb * B;
+    m.kout = k;
+    m.out_d = out_d;
+    m.out_i = out_i;
+    m.q_group_out = B;
+    m.q_group_in = vs::kMaxBatch;
+    m.flat_len = z_cnt;
+    m.id_map = h->d_r2o;
+    HIPCHK(vs::launch_merge_layout(m, kIvfWideSubCap, (int64_t)kWideSub * kIvfWideSubCap, s));
+    HIPCHK(vs::launch_ivf_wide_slow(wp, s));
+    stage_mark(h, 3, s);
+    return VS_OK;
+}
+
 bool ivf_multi_ok(const vs_index* h, int k) {
     return g_ivf_multi && g_ivf_grouped && g_ivf_plan && h->nlist <= vs::kIvfFastNlist && h->n_chunks > 0 && h->d_units && pick_kcap(k);
 }
@@ -956,7 +1124,9 @@ int ensure_ivf_mb(vs_index* h, int nprobe, hipStream_t s) {
 }
 
 // nb <= kMaxMulti independent batches, every kernel launched once for all of them (blockIdx.y = batch)
+int ivf_group_wide_dev(vs_index* h, const float* q_dev, int nb, int B, int k, int nprobe, float* out_d, int32_t* out_i, hipStream_t s);
 int ivf_group_dev(vs_index* h, const float* q_dev, int nb, int B, int k, int nprobe, float* out_d, int32_t* out_i, hipStream_t s) {
+    if (g_ivf_wide) return ivf_group_wide_dev(h, q_dev, nb, B, k, nprobe, out_d, out_i, s);
     int rc = ensure_ivf_mb(h, nprobe, s);
     if (rc) return rc;
     HIPCHK(hipMemsetAsync(h->mb_zslab, 0, (size_t)h->mb_zslab_stride * nb * sizeof(int32_t), s));

@@ -140,7 +140,7 @@ struct StreamParams {
     CandSink sink;
 };
 hipError_t launch_scan_f32_stream(const StreamParams& p, int grid, hipStream_t s);
-hipError_t launch_cand_bin(const CandSink& sink, int grid, hipStream_t s);  // after either streaming scan, same grid
+hipError_t launch_cand_bin(const CandSink& sink, int n_buffers, hipStream_t s);  // after a streaming scan: its wave buffers
 
 // Cross-workgroup merge of sorted partial lists -> [nq][kout] + tie flags (+ seed thresholds).
 struct MergeParams {
@@ -279,6 +279,48 @@ struct IvfSelectParams {
     IvfMulti mb;
 };
 hipError_t launch_ivf_select(const IvfSelectParams& p, int B, hipStream_t s, int n_batches = 1);
+
+// ---- wide IVF pipeline: launch groups are cut into super-batches of kIvfWideBatches batches (<= 256 queries) that
+// share ONE list-major pass: a list probed by any of them is read once and scored against all its queries (MFMA
+// column blocks of 16).  Bounds first (ivf_tau_kernel: k-th best of the first rows of the query's nearest resident
+// list), survivors to a CandSink, ranking by merge_compact_kernel -- no candidate-score arrays, no selection kernel.
+constexpr int kIvfWideBatches = 8;
+constexpr int kIvfWideQ = kIvfWideBatches * kMaxBatch;  // query slots per super-batch
+constexpr int kIvfTauRows = 256;                         // rows of the nearest list that seed a query's bound
+struct IvfWideParams {
+    const float* vecs;        // [n_rows (+64)][128] cluster-reordered
+    const float* vnorm;       // [n_rows + 64]
+    const int8_t* vecs_u8;    // optional exact int8 copy (x - 128) + row terms
+    const int32_t* rterm;
+    const int32_t* offsets;   // [nlist+1] local list offsets (lists not resident here are empty)
+    const int32_t* chunk_list;
+    const int32_t* chunk_row0;
+    const int32_t* chunk_rows;
+    int n_chunks, nlist, nprobe, k, metric;
+    const float* q;           // batch b's [B][128] at (char*)q + b * q_batch_bytes
+    long long q_batch_bytes;
+    int n_batches, B;
+    const float* qnorm;       // [n_batches][32]   | from seed_qnorm_kernel (launch_query_prep)
+    const int8_t* q8;         // [n_batches][32][128]
+    const int32_t* qterm;     // [n_batches][32]
+    const int32_t* invalid;   // [n_batches] (pre-set to 0) a query of the batch is not byte valued
+    const int32_t* probes;    // batch b's [B][nprobe] at (char*)probes + b * probes_batch_bytes
+    long long probes_batch_bytes;
+    int32_t* lq;              // [n_sb][nlist][kIvfWideQ] query slots (batch * 32 + q) probing each list
+    int32_t* zero;            // [n_sb][nlist + 16] (pre-set to 0): word nlist = units in the super-batch's plan
+    int32_t* units;           // [n_sb][units_sb_stride / 4][4] unit records (first row, chunk end, list | queries << 16, 0)
+    long long units_sb_stride;  // in int32
+    float* tau;               // [n_batches][32] bounds
+    int32_t* slow;            // [n_batches][32] (pre-set to 0): no bound could be had -> exact slow path
+    CandSink sink;
+    float* out_d;             // [n_batches][B][k]   (slow path writes here directly)
+    int32_t* out_i;
+    const int32_t* id_map;    // reorder_to_original (local)
+};
+hipError_t launch_query_prep(const SeedParams& p, hipStream_t s);  // ||q||^2, queries as bytes, constant terms, validity
+hipError_t launch_ivf_wide(const IvfWideParams& p, int num_cus, hipStream_t s);       // tau, plan, scan
+int ivf_wide_grid_x(int num_cus, int n_sb);  // grid.x of the scan (its wave buffers: grid.x * n_sb * 4)
+hipError_t launch_ivf_wide_slow(const IvfWideParams& p, hipStream_t s);               // after bin + merge
 
 struct IvfScanParams {
     const float* vecs;        // [n_rows][128] cluster-reordered (vectors_reordered.npy)

@@ -1348,9 +1348,9 @@ hipError_t launch_scan_f32_stream(const StreamParams& p, int grid, hipStream_t s
     return hipGetLastError();
 }
 
-// wave buffers -> per-query lists (after either streaming scan; `grid` = that scan's grid)
-hipError_t launch_cand_bin(const CandSink& sink, int grid, hipStream_t s) {
-    hipLaunchKernelGGL(cand_bin_kernel, dim3(grid * kScanWaves), dim3(256), 0, s, sink);
+// wave buffers -> per-query lists (after a streaming scan that filled `n_buffers` of them)
+hipError_t launch_cand_bin(const CandSink& sink, int n_buffers, hipStream_t s) {
+    hipLaunchKernelGGL(cand_bin_kernel, dim3(n_buffers), dim3(256), 0, s, sink);
     return hipGetLastError();
 }
 
@@ -3351,6 +3351,450 @@ __global__ __launch_bounds__(256) void ivf_select_kernel(IvfSelectParams p) {
             __syncthreads();
         }
     }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Wide IVF pipeline (see IvfWideParams).
+// ------------------------------------------------------------------------------------------------
+hipError_t launch_query_prep(const SeedParams& p, hipStream_t s) {
+    hipLaunchKernelGGL(seed_qnorm_kernel, dim3(p.n_batches), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+// Bound of a query = k-th smallest distance among the first kIvfTauRows rows of its nearest resident list holding at
+// least k rows (those rows are candidates, so k of them at most that far bound the k-th best of all candidates).  One
+// wave per query: 16-row MFMA tiles with the query in column 0 of the B operand, distances through LDS, k rounds of a
+// wave minimum.  No such list: tau = +inf and the query is marked for the exact slow path.
+__global__ __launch_bounds__(256) void ivf_tau_kernel(const IvfWideParams p) {
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    typedef int i32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+    typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+    __shared__ __attribute__((aligned(16))) float dist[4][kIvfTauRows];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int qg = (int)blockIdx.x * 4 + wave;
+    const int batch = qg >> 5, qi = qg & 31;
+    if (batch >= p.n_batches || qi >= p.B) return;  // wave-uniform
+    const int r = lane & 15, g = lane >> 4;
+    const int32_t* pr = reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(p.probes) + (long long)batch * p.probes_batch_bytes) + qi * p.nprobe;
+    int start = 0, rows = 0;
+    for (int pp = 0; pp < p.nprobe; ++pp) {
+        const int c = pr[pp];
+        if (c < 0) continue;
+        const int len = p.offsets[c + 1] - p.offsets[c];
+        if (len >= p.k) {
+            start = p.offsets[c];
+            rows = min(len, kIvfTauRows);
+            break;
+        }
+    }
+    if (rows == 0) {
+        if (lane == 0) {
+            p.tau[qg] = VS_INF;
+            p.slow[qg] = 1;
+        }
+        return;
+    }
+    for (int i = lane; i < kIvfTauRows; i += 64) dist[wave][i] = VS_INF;
+    const bool i8 = p.vecs_u8 && p.metric == 0 && p.invalid[batch] == 0;
+    const int tiles = (rows + 15) >> 4;
+    if (i8) {
+        i32x4 b0 = {0, 0, 0, 0}, b1 = {0, 0, 0, 0};
+        if (r == 0) {
+            b0 = *reinterpret_cast<const i32x4*>(p.q8 + (int64_t)qg * kDim + 16 * g);
+            b1 = *reinterpret_cast<const i32x4*>(p.q8 + (int64_t)qg * kDim + 64 + 16 * g);
+        }
+        const int qt = p.qterm[qg];
+        for (int t = 0; t < tiles; ++t) {
+            const int row = min(start + 16 * t + r, start + rows - 1);
+            const i32x4 a0 = *reinterpret_cast<const i32x4*>(p.vecs_u8 + (int64_t)row * kDim + 16 * g);
+            const i32x4 a1 = *reinterpret_cast<const i32x4*>(p.vecs_u8 + (int64_t)row * kDim + 64 + 16 * g);
+            const i32x4 rt = *reinterpret_cast<const i32x4_u*>(p.rterm + start + 16 * t + 4 * g);  // padded by 64
+            i32x4 acc = {0, 0, 0, 0};
+            acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b1, acc, 0, 0, 0);
+            if (r == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (16 * t + 4 * g + j < rows) dist[wave][16 * t + 4 * g + j] = (float)(qt + rt[j] - 2 * acc[j]);
+            }
+        }
+    } else {
+        const float* qsrc = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.q) + (long long)batch * p.q_batch_bytes) + qi * kDim;
+        f32x4 qf[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            qf[c] = *reinterpret_cast<const f32x4*>(qsrc + 16 * c + 4 * g);
+            if (r != 0) qf[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        const float qn = p.qnorm[qg];
+        for (int t = 0; t < tiles; ++t) {
+            const int row = min(start + 16 * t + r, start + rows - 1);
+            f32x4 a[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) a[c] = *reinterpret_cast<const f32x4*>(p.vecs + (int64_t)row * kDim + 16 * c + 4 * g);
+            const f32x4 bn = *reinterpret_cast<const f32x4_u*>(p.vnorm + start + 16 * t + 4 * g);  // padded by 64
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][i], qf[c][i], acc, 0, 0, 0);
+            if (r == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (16 * t + 4 * g + j < rows) dist[wave][16 * t + 4 * g + j] = p.metric ? -acc[j] : fmaf(-2.0f, acc[j], qn + bn[j]);
+            }
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0);  // this wave's LDS writes (a wave reads only what it wrote)
+    __builtin_amdgcn_wave_barrier();
+    const f32x4 v = *reinterpret_cast<const f32x4*>(&dist[wave][4 * lane]);
+    const float kth = wave_kth_smallest(v[0], v[1], v[2], v[3], p.k, lane);
+    if (lane == 0) {
+        // integer distances (int8 path) are exact: the bound may sit right above the k-th value; fp32 rows are scored
+        // with the same MFMA chain as the scan here, but leave slack anyway (the bound only filters)
+        const float t = i8 ? next_up(kth) : kth + 1e-4f * fabsf(kth) + 1e-30f;
+        p.tau[qg] = kth < VS_INF ? t : VS_INF;
+        if (!(kth < VS_INF)) p.slow[qg] = 1;
+    }
+}
+
+// Grouping + work plan of one super-batch (blockIdx.y), kPlanSplit workgroups each (see ivf_group_plan_kernel): the
+// query slots probing every list, and the 32-row units of every chunk whose list is probed.
+__global__ __launch_bounds__(1024) void ivf_plan_wide_kernel(const IvfWideParams p) {
+    __shared__ int cnt_s[kIvfFastNlist];
+    __shared__ int s_carry;
+    __shared__ int s_wtot[16];
+    const int tid = threadIdx.x;
+    const int sb = blockIdx.y;
+    const int b0 = sb * kIvfWideBatches, b1 = min(p.n_batches, b0 + kIvfWideBatches);
+    const bool first = blockIdx.x == 0;
+    int32_t* lq = p.lq + (int64_t)sb * p.nlist * kIvfWideQ;
+    int32_t* units = p.units + (int64_t)sb * p.units_sb_stride;
+    for (int c = tid; c < p.nlist; c += 1024) cnt_s[c] = 0;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    const int per_batch = p.B * p.nprobe;
+    for (int e = tid; e < (b1 - b0) * per_batch; e += 1024) {
+        const int bb = e / per_batch, rem = e - bb * per_batch;
+        const int qi = rem / p.nprobe, pp = rem - qi * p.nprobe;
+        const int batch = b0 + bb;
+        const int c = reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(p.probes) + (long long)batch * p.probes_batch_bytes)[qi * p.nprobe + pp];
+        if (c < 0) continue;
+        if (p.offsets[c + 1] == p.offsets[c]) continue;  // empty (or not resident) list
+        const int slot = atomicAdd(&cnt_s[c], 1);        // < kIvfWideQ: a list is probed at most once per query
+        if (first) lq[(int64_t)c * kIvfWideQ + slot] = batch * kMaxBatch + qi;
+    }
+    __syncthreads();
+    const int pl = tid & 63, wv = tid >> 6;
+    const int nsl = (int)gridDim.x;
+    const int c0 = (int)((long long)p.n_chunks * blockIdx.x / nsl), c1 = (int)((long long)p.n_chunks * (blockIdx.x + 1) / nsl);
+    auto units_of = [&](int chunk) { return cnt_s[p.chunk_list[chunk]] > 0 ? (p.chunk_rows[chunk] + 31) >> 5 : 0; };
+    {
+        int pre = 0;
+        for (int chunk = tid; chunk < c0; chunk += 1024) pre += units_of(chunk);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) pre += __shfl_xor(pre, o);
+        if (pl == 0) s_wtot[wv] = pre;
+        __syncthreads();
+        if (tid == 0) {
+            int t = 0;
+            for (int w = 0; w < 16; ++w) t += s_wtot[w];
+            s_carry = t;
+        }
+        __syncthreads();
+    }
+    for (int base = c0; base < c1; base += 1024) {
+        const int chunk = base + tid;
+        const int nu = chunk < c1 ? units_of(chunk) : 0;
+        int incl = nu;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o);
+            if (pl >= o) incl += t;
+        }
+        if (pl == 63) s_wtot[wv] = incl;
+        __syncthreads();
+        int woff = 0, tot = 0;
+        for (int w = 0; w < 16; ++w) {
+            const int t = s_wtot[w];
+            if (w < wv) woff += t;
+            tot += t;
+        }
+        const int pos = s_carry + woff + incl - nu;
+        if (nu > 0) {
+            const int c = p.chunk_list[chunk];
+            const int r0 = p.chunk_row0[chunk];
+            const int r_end = r0 + p.chunk_rows[chunk];
+            const int nq = min(cnt_s[c], kIvfWideQ);
+            for (int i = 0; i < nu; ++i) reinterpret_cast<int4*>(units)[pos + i] = make_int4(r0 + 32 * i, r_end, c | (nq << 16), 0);
+        }
+        __syncthreads();
+        if (tid == 0) s_carry += tot;
+        __syncthreads();
+    }
+    if (tid == 0 && (int)blockIdx.x == nsl - 1) p.zero[(int64_t)sb * (p.nlist + 16) + p.nlist] = s_carry;
+}
+
+// The list-major scan of one super-batch (blockIdx.y).  A workgroup stages the super-batch's queries once (as bytes: 32
+// KB) with their constant terms and thresholds; after that every wave works alone on 32-row units of the plan: the
+// unit's two 16-row tiles are the MFMA A operands, the queries probing the unit's list come 16 at a time as B operands
+// (gathered from the staged bytes through the list's slot table), and a distance under its query's bound goes to the
+// wave's candidate buffer (plain stores, positions from a ballot).  Rows that are not bytes, or a super-batch with a
+// non-byte query: the same on the fp32 rows with queries gathered from global memory.
+constexpr int kIvfWideThreads = 256;
+__global__ __launch_bounds__(kIvfWideThreads) void ivf_scan_wide_kernel(const IvfWideParams p) {
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    typedef int i32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+    typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+    __shared__ __attribute__((aligned(16))) int q8_s[kIvfWideQ * 32];  // [slot][128 bytes]
+    __shared__ int qt_s[kIvfWideQ];
+    __shared__ int thr_s[kIvfWideQ];   // int8 path: 2 dot - rt > thr  <=>  d < tau
+    __shared__ float tau_s[kIvfWideQ];
+    __shared__ float qn_s[kIvfWideQ];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    const int sb = blockIdx.y;
+    const int b0 = sb * kIvfWideBatches, b1 = min(p.n_batches, b0 + kIvfWideBatches);
+    const int nslots = (b1 - b0) * kMaxBatch;
+    const int n_units = p.zero[(int64_t)sb * (p.nlist + 16) + p.nlist];
+    const int wb = ((int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x) * 4 + wave;  // this wave's candidate buffer
+    int wbase = 0;
+    if ((int)blockIdx.x * 4 < n_units) {  // workgroup-uniform
+    bool any_invalid = false;
+    for (int b = b0; b < b1; ++b) any_invalid = any_invalid || p.invalid[b] != 0;
+    const bool i8 = p.vecs_u8 && p.metric == 0 && !any_invalid;
+    for (int s = tid; s < nslots; s += kIvfWideThreads) {
+        const int qg = b0 * kMaxBatch + s;
+        const bool live = (s & 31) < p.B && p.slow[qg] == 0;  // a query without a bound goes through the slow path only
+        const float t0 = live ? p.tau[qg] : -VS_INF;
+        tau_s[s] = t0;
+        qn_s[s] = p.qnorm[qg];
+        const int qt = p.qterm[qg];
+        qt_s[s] = qt;
+        // d < tau for integer d  <=>  d < ceil(tau)  (distances are below 2^24: any bound from 2^26 on admits everything)
+        const int ti = (int)ceilf(fminf(fmaxf(t0, -67108864.f), 67108864.f));
+        thr_s[s] = live ? qt - ti : 0x7fffffff;
+    }
+    if (i8) {
+        const int4* src = reinterpret_cast<const int4*>(p.q8 + (int64_t)b0 * kMaxBatch * kDim);
+        for (int i = tid; i < nslots * 8; i += kIvfWideThreads) reinterpret_cast<int4*>(q8_s)[i] = src[i];
+    }
+    __syncthreads();
+    const int4* recs = reinterpret_cast<const int4*>(p.units + (int64_t)sb * p.units_sb_stride);
+    const int32_t* lq = p.lq + (int64_t)sb * p.nlist * kIvfWideQ;
+    int4* wbuf = p.sink.wbuf + (int64_t)wb * p.sink.wcap;
+    const int nw = (int)gridDim.x * 4;
+    int u = (int)blockIdx.x * 4 + wave;
+    int4 rec = u < n_units ? recs[u] : make_int4(0, 0, 0, 0);
+    for (; u < n_units; u += nw) {
+        const int r0 = __builtin_amdgcn_readfirstlane(rec.x);
+        const int r_end = __builtin_amdgcn_readfirstlane(rec.y);
+        const int c = __builtin_amdgcn_readfirstlane(rec.z) & 0xffff;
+        const int nq = __builtin_amdgcn_readfirstlane(rec.z) >> 16;
+        if (u + nw < n_units) rec = recs[u + nw];  // the next unit's record, in flight during this unit
+        const int32_t* lqc = lq + (int64_t)c * kIvfWideQ;
+        if (i8) {
+            i32x4 a0[2], a1[2], rt[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int row = min(r0 + 16 * t + r, r_end - 1);
+                a0[t] = *reinterpret_cast<const i32x4*>(p.vecs_u8 + (int64_t)row * kDim + 16 * g);
+                a1[t] = *reinterpret_cast<const i32x4*>(p.vecs_u8 + (int64_t)row * kDim + 64 + 16 * g);
+                rt[t] = *reinterpret_cast<const i32x4_u*>(p.rterm + r0 + 16 * t + 4 * g);  // past the chunk: readable, never used
+            }
+            for (int cb = 0; cb < nq; cb += 16) {
+                const int sq = cb + r;
+                const bool live = sq < nq;
+                const int qg = live ? lqc[sq] : b0 * kMaxBatch;
+                const int ql = qg - b0 * kMaxBatch;
+                const i32x4 bq0 = *reinterpret_cast<const i32x4*>(q8_s + ql * 32 + 4 * g);
+                const i32x4 bq1 = *reinterpret_cast<const i32x4*>(q8_s + ql * 32 + 16 + 4 * g);
+                const int th = live ? thr_s[ql] : 0x7fffffff;
+                i32x4 acc[2];
+                bool any = false;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0[t], bq0, (i32x4){0, 0, 0, 0}, 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1[t], bq1, acc[t], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) any = any || (2 * acc[t][j] - rt[t][j] > th);
+                }
+                if (__ballot(any)) {  // rare
+                    const int qt = qt_s[ql];
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int row = r0 + 16 * t + 4 * g + j;
+                            const bool pass = live && 2 * acc[t][j] - rt[t][j] > th && row < r_end;
+                            const unsigned long long mask = __ballot(pass);
+                            if (mask) {
+                                const int pos = wbase + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+                                if (pass && pos < p.sink.wcap)
+                                    wbuf[pos] = make_int4(qg, __builtin_bit_cast(int, (float)(qt + rt[t][j] - 2 * acc[t][j])), row, 0);
+                                wbase += __popcll(mask);
+                            }
+                        }
+                }
+            }
+        } else {
+#pragma unroll 1
+            for (int t = 0; t < 2; ++t) {
+                if (r0 + 16 * t >= r_end) break;  // wave-uniform
+                const int row = min(r0 + 16 * t + r, r_end - 1);
+                f32x4 a[8];
+#pragma unroll
+                for (int c8 = 0; c8 < 8; ++c8) a[c8] = *reinterpret_cast<const f32x4*>(p.vecs + (int64_t)row * kDim + 16 * c8 + 4 * g);
+                const f32x4 bn = *reinterpret_cast<const f32x4_u*>(p.vnorm + r0 + 16 * t + 4 * g);
+                for (int cb = 0; cb < nq; cb += 16) {
+                    const int sq = cb + r;
+                    const bool live = sq < nq;
+                    const int qg = live ? lqc[sq] : b0 * kMaxBatch;
+                    const int ql = qg - b0 * kMaxBatch;
+                    const float* qsrc = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.q) + (long long)(qg >> 5) * p.q_batch_bytes) + (qg & 31) * kDim;
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int c8 = 0; c8 < 8; ++c8) {
+                        const f32x4 qf = *reinterpret_cast<const f32x4*>(qsrc + 16 * c8 + 4 * g);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c8][i], qf[i], acc, 0, 0, 0);
+                    }
+                    const float qn = qn_s[ql];
+                    const float tq = live ? tau_s[ql] : -VS_INF;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float d = p.metric ? -acc[j] : fmaf(-2.0f, acc[j], qn + bn[j]);
+                        const int rowj = r0 + 16 * t + 4 * g + j;
+                        const bool pass = d < tq && rowj < r_end;
+                        const unsigned long long mask = __ballot(pass);
+                        if (mask) {
+                            const int pos = wbase + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+                            if (pass && pos < p.sink.wcap) wbuf[pos] = make_int4(qg, __builtin_bit_cast(int, d), rowj, 0);
+                            wbase += __popcll(mask);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    }
+    if (lane == 0) p.sink.wcount[wb] = wbase;  // every wave of the grid reports (idle ones: 0)
+}
+
+// Exact slow path, one workgroup per query that has no usable bound (or every query when a candidate buffer overflowed:
+// masses of duplicate rows): all rows of the query's probed lists, thread-private sorted lists, ranking through LDS.
+__global__ __launch_bounds__(256) void ivf_wide_slow_kernel(const IvfWideParams p) {
+    const int qg = blockIdx.x;
+    const int batch = qg >> 5, qi = qg & 31;
+    if (batch >= p.n_batches || qi >= p.B) return;
+    if (!p.sink.overflow[0] && !p.slow[qg]) return;
+    constexpr int KM = 16;
+    __shared__ float sd[256 * KM];
+    __shared__ int sp[256 * KM];
+    __shared__ float r_d[4];
+    __shared__ int r_p[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int k = min(p.k, KM);
+    const int32_t* pr = reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(p.probes) + (long long)batch * p.probes_batch_bytes) + qi * p.nprobe;
+    const float* qv = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.q) + (long long)batch * p.q_batch_bytes) + qi * kDim;
+    const bool i8 = p.vecs_u8 && p.metric == 0 && p.invalid[batch] == 0;
+    const float qn = p.qnorm[qg];
+    const int qt = p.qterm[qg];
+    float ld[KM];
+    int lp[KM];
+#pragma unroll
+    for (int j = 0; j < KM; ++j) {
+        ld[j] = VS_INF;
+        lp[j] = 0x7fffffff;
+    }
+    for (int pp = 0; pp < p.nprobe; ++pp) {
+        const int c = pr[pp];
+        if (c < 0) continue;
+        const int s0 = p.offsets[c], s1 = p.offsets[c + 1];
+        for (int row = s0 + tid; row < s1; row += 256) {
+            float d;
+            if (i8) {
+                const int8_t* b = p.vecs_u8 + (int64_t)row * kDim;
+                const int8_t* qq = p.q8 + (int64_t)qg * kDim;
+                int dot = 0;
+                for (int t = 0; t < kDim; ++t) dot += (int)b[t] * (int)qq[t];
+                d = (float)(qt + p.rterm[row] - 2 * dot);
+            } else {
+                const float* b = p.vecs + (int64_t)row * kDim;
+                float dot = 0.f;
+                for (int t = 0; t < kDim; ++t) dot = fmaf(b[t], qv[t], dot);
+                d = p.metric ? -dot : fmaf(-2.0f, dot, qn + p.vnorm[row]);
+            }
+            if (lex_lt(d, row, ld[KM - 1], lp[KM - 1])) list_insert<KM>(ld, lp, d, row);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < KM; ++j) {
+        sd[tid * KM + j] = ld[j];
+        sp[tid * KM + j] = lp[j];
+    }
+    __syncthreads();
+    float last_d = -VS_INF;
+    int last_p = -1;
+    for (int round = 0; round < k; ++round) {
+        float bd = VS_INF;
+        int bp = 0x7fffffff;
+        for (int i = tid; i < 256 * KM; i += 256) {
+            const float d = sd[i];
+            const int ps = sp[i];
+            if (ps == 0x7fffffff) continue;
+            if (d < last_d || (d == last_d && ps <= last_p)) continue;  // already emitted
+            if (lex_lt(d, ps, bd, bp)) {
+                bd = d;
+                bp = ps;
+            }
+        }
+        float wd;
+        int wp;
+        wave_lexmin(bd, bp, wd, wp);
+        if (lane == 0) {
+            r_d[wave] = wd;
+            r_p[wave] = wp;
+        }
+        __syncthreads();
+        bd = r_d[0];
+        bp = r_p[0];
+        for (int w = 1; w < 4; ++w)
+            if (lex_lt(r_d[w], r_p[w], bd, bp)) {
+                bd = r_d[w];
+                bp = r_p[w];
+            }
+        const bool none = bp == 0x7fffffff;
+        if (tid == 0) {
+            p.out_d[((int64_t)batch * p.B + qi) * p.k + round] = none ? VS_INF : bd;
+            p.out_i[((int64_t)batch * p.B + qi) * p.k + round] = none ? -1 : (p.id_map ? p.id_map[bp] : bp);
+        }
+        last_d = none ? VS_INF : bd;
+        last_p = none ? 0x7fffffff : bp;
+        __syncthreads();
+    }
+    for (int round = k + tid; round < p.k; round += 256) {
+        p.out_d[((int64_t)batch * p.B + qi) * p.k + round] = VS_INF;
+        p.out_i[((int64_t)batch * p.B + qi) * p.k + round] = -1;
+    }
+}
+
+int ivf_wide_grid_x(int num_cus, int n_sb) { return std::max(16, 4 * num_cus / n_sb); }
+
+hipError_t launch_ivf_wide(const IvfWideParams& p, int num_cus, hipStream_t s) {
+    if (p.nlist > kIvfFastNlist || p.nprobe > kIvfMaxProbe || p.k > 16) return hipErrorInvalidValue;
+    const int n_sb = (p.n_batches + kIvfWideBatches - 1) / kIvfWideBatches;
+    hipLaunchKernelGGL(ivf_tau_kernel, dim3((p.n_batches * kMaxBatch + 3) / 4), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(ivf_plan_wide_kernel, dim3(kPlanSplit, n_sb), dim3(1024), 0, s, p);
+    hipLaunchKernelGGL(ivf_scan_wide_kernel, dim3(ivf_wide_grid_x(num_cus, n_sb), n_sb), dim3(kIvfWideThreads), 0, s, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_ivf_wide_slow(const IvfWideParams& p, hipStream_t s) {
+    hipLaunchKernelGGL(ivf_wide_slow_kernel, dim3(p.n_batches * kMaxBatch), dim3(256), 0, s, p);
+    return hipGetLastError();
 }
 
 hipError_t launch_ivf_select(const IvfSelectParams& p, int B, hipStream_t s, int n_batches) {
