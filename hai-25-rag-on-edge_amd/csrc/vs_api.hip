@@ -44,7 +44,7 @@ constexpr int kWideWaveCap = 1024;  // entries per wave buffer of the wide int8 
 constexpr int kWideSub = 16;      // sub-lists per query of the streaming scans' candidate lists
 constexpr int kWideCap = 128;     // entries per sub-list (2048 per query; more: the per-batch scan behind takes over)
 constexpr int kIvfWideWaveCap = 512;  // entries per wave buffer of the wide IVF scan (expected fill: a few dozen per group)
-constexpr int kIvfWideSubCap = 64;    // entries per candidate sub-list (16 per query)
+constexpr int kIvfWideSubCap = 256;   // entries per candidate sub-list (16 per query: 4096 candidates)
 constexpr int kTieDense = 4096;   // rows whose distances the tie resolver takes densely
 constexpr int kTieCap = 8192;     // candidate slots per flagged query (more: full-row fallback)
 
@@ -162,7 +162,7 @@ struct vs_index {
     // wide IVF pipeline (super-batches of 8 batches share one list-major pass): slot tables, zeroed counters, plans,
     // bounds, prepared queries, candidate sink
     struct IvfWide {
-        int32_t* lq = nullptr;      // [4][nlist][256]
+        int32_t* lq = nullptr;      // [n_sb][nlist][kIvfWideQ]
         int32_t* zero = nullptr;    // one zeroed block per launch group: [4][nlist + 16] | slow [1024] | overflow (16) | list counters [1024][16]
         size_t zero_words = 0;
         int32_t* units = nullptr;   // [4][n_units_max][4]
@@ -958,8 +958,8 @@ int ensure_ivf_wide(vs_index* h) {
     int rc;
     const size_t nq = (size_t)kMaxMulti * 32;
     const int n_sb_max = (kMaxMulti + vs::kIvfWideBatches - 1) / vs::kIvfWideBatches;
-    W.n_waves = vs::ivf_wide_grid_x(h->num_cus, 1) * 4;  // n_sb * grid.x(n_sb) * 4 <= this (grid.x shrinks with n_sb)
-    W.n_waves = std::max(W.n_waves, n_sb_max * vs::ivf_wide_grid_x(h->num_cus, n_sb_max) * 4);
+    W.n_waves = 0;
+    for (int n = 1; n <= n_sb_max; ++n) W.n_waves = std::max(W.n_waves, vs::ivf_wide_waves(h->num_cus, n));
     W.zero_words = (size_t)n_sb_max * (h->nlist + 16) + nq + 16 + nq * kWideSub;
     if ((rc = dev_alloc(&W.lq, (size_t)n_sb_max * h->nlist * vs::kIvfWideQ))) return rc;
     if ((rc = dev_alloc(&W.zero, W.zero_words))) return rc;
@@ -1062,6 +1062,7 @@ int ivf_group_wide_dev(vs_index* h, const float* q_dev, int nb, int B, int k, in
     wp.sink.cand_i = W.cand_i;
     wp.sink.cap = kIvfWideSubCap;
     wp.sink.nsub = kWideSub;
+    wp.sink.slow = z_slow;
     wp.out_d = out_d;
     wp.out_i = out_i;
     wp.id_map = h->d_r2o;
@@ -1069,7 +1070,7 @@ int ivf_group_wide_dev(vs_index* h, const float* q_dev, int nb, int B, int k, in
     prof_begin(h, 1, s);
     HIPCHK(vs::launch_ivf_wide(wp, h->num_cus, s));
     prof_end(h, 1, s);
-    const int waves = vs::ivf_wide_grid_x(h->num_cus, n_sb) * n_sb * 4;
+    const int waves = vs::ivf_wide_waves(h->num_cus, n_sb);
     HIPCHK(vs::launch_cand_bin(wp.sink, waves, s));
     vs::MergeParams m{};
     m.part_d = W.cand_d;
@@ -2309,6 +2310,47 @@ int vs_ivf_search(vs_index* h, const float* queries_host, int64_t nq, int k, int
         if (timing) *timing = tm;
         return order_end(h, h->stream);
     });
+}
+
+// diagnostic (not part of the ABI header): state of the wide IVF pipeline after the last launch group
+__attribute__((visibility("default"))) int vs_debug_ivf_wide_stats(vs_index* h, int64_t* out /*[8]*/) {
+    if (!h || !h->wide.lq) return VS_ERR_INVALID;
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
+    const size_t nq = (size_t)kMaxMulti * 32;
+    const int n_sb_max = (kMaxMulti + vs::kIvfWideBatches - 1) / vs::kIvfWideBatches;
+    std::vector<int32_t> z(h->wide.zero_words), wc((size_t)h->wide.n_waves);
+    std::vector<float> tau(nq);
+    HIPCHK(hipMemcpy(z.data(), h->wide.zero, z.size() * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(wc.data(), h->wide.wcount, wc.size() * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(tau.data(), h->wide.tau, nq * 4, hipMemcpyDeviceToHost));
+    const int32_t* slow = z.data() + (size_t)n_sb_max * (h->nlist + 16);
+    const int32_t* ovf = slow + nq;
+    const int32_t* cnt = ovf + 16;
+    int64_t nslow = 0, total = 0, maxw = 0, maxsub = 0, ninf = 0;
+    for (size_t i = 0; i < nq; ++i) nslow += slow[i] != 0;
+    for (size_t i = 0; i < nq; ++i) ninf += !(tau[i] < 3e38f);
+    for (int32_t v : wc) {
+        total += v;
+        maxw = std::max<int64_t>(maxw, v);
+    }
+    for (size_t i = 0; i < nq * kWideSub; ++i) maxsub = std::max<int64_t>(maxsub, cnt[i]);
+    out[0] = ovf[0];
+    out[1] = nslow;
+    out[2] = total;
+    out[3] = maxw;
+    out[4] = maxsub;
+    out[5] = ninf;
+    out[6] = z[h->nlist];  // units of super-batch 0
+    int64_t big = 0, maxq = 0;
+    for (size_t i = 0; i < nq; ++i) {
+        int64_t t = 0;
+        for (int g = 0; g < kWideSub; ++g) t += cnt[i * kWideSub + g];
+        big += t > 256;
+        maxq = std::max(maxq, t);
+    }
+    out[7] = big * 100000 + maxq;
+    return VS_OK;
 }
 
 __attribute__((visibility("default"))) int vs_debug_buffer(int* dev_ptr) {

@@ -107,6 +107,7 @@ struct CandSink {
     int32_t* cand_i;
     int cap;                 // per sub-list
     int nsub;
+    int32_t* slow;           // optional [queries]: a query whose lists overflow is marked here instead of raising `overflow`
 };
 
 struct WideParams {
@@ -280,11 +281,11 @@ struct IvfSelectParams {
 };
 hipError_t launch_ivf_select(const IvfSelectParams& p, int B, hipStream_t s, int n_batches = 1);
 
-// ---- wide IVF pipeline: launch groups are cut into super-batches of kIvfWideBatches batches (<= 256 queries) that
+// ---- wide IVF pipeline: launch groups are cut into super-batches of kIvfWideBatches batches (<= 1024 queries) that
 // share ONE list-major pass: a list probed by any of them is read once and scored against all its queries (MFMA
 // column blocks of 16).  Bounds first (ivf_tau_kernel: k-th best of the first rows of the query's nearest resident
 // list), survivors to a CandSink, ranking by merge_compact_kernel -- no candidate-score arrays, no selection kernel.
-constexpr int kIvfWideBatches = 8;
+constexpr int kIvfWideBatches = 32;  // = a whole launch group: every resident list is read once per 1024 queries
 constexpr int kIvfWideQ = kIvfWideBatches * kMaxBatch;  // query slots per super-batch
 constexpr int kIvfTauRows = 256;                         // rows of the nearest list that seed a query's bound
 struct IvfWideParams {
@@ -308,7 +309,7 @@ struct IvfWideParams {
     long long probes_batch_bytes;
     int32_t* lq;              // [n_sb][nlist][kIvfWideQ] query slots (batch * 32 + q) probing each list
     int32_t* zero;            // [n_sb][nlist + 16] (pre-set to 0): word nlist = units in the super-batch's plan
-    int32_t* units;           // [n_sb][units_sb_stride / 4][4] unit records (first row, chunk end, list | queries << 16, 0)
+    int32_t* units;           // [n_sb][units_sb_stride / 4][4] unit records (first row, chunk end, list, queries probing it)
     long long units_sb_stride;  // in int32
     float* tau;               // [n_batches][32] bounds
     int32_t* slow;            // [n_batches][32] (pre-set to 0): no bound could be had -> exact slow path
@@ -319,7 +320,8 @@ struct IvfWideParams {
 };
 hipError_t launch_query_prep(const SeedParams& p, hipStream_t s);  // ||q||^2, queries as bytes, constant terms, validity
 hipError_t launch_ivf_wide(const IvfWideParams& p, int num_cus, hipStream_t s);       // tau, plan, scan
-int ivf_wide_grid_x(int num_cus, int n_sb);  // grid.x of the scan (its wave buffers: grid.x * n_sb * 4)
+int ivf_wide_grid_x(int num_cus, int n_sb);  // grid.x of the scan
+int ivf_wide_waves(int num_cus, int n_sb);   // its waves = candidate buffers
 hipError_t launch_ivf_wide_slow(const IvfWideParams& p, hipStream_t s);               // after bin + merge
 
 struct IvfScanParams {

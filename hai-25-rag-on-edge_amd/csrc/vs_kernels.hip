@@ -1138,24 +1138,29 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_i8w_kernel(const WidePar
 }
 
 // Candidates of a streaming scan, wave buffers -> per-query lists (the only atomics of the path, massively parallel here).
-__global__ __launch_bounds__(256) void cand_bin_kernel(const CandSink p) {
-    const int wb = blockIdx.x;
+__global__ __launch_bounds__(256) void cand_bin_kernel(const CandSink p, int n_buffers) {
+    const int wb = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);  // one wave per wave buffer (a few dozen entries each)
+    if (wb >= n_buffers) return;
+    const int lane = threadIdx.x & 63;
     const int n = p.wcount[wb];
     if (n > p.wcap) {
-        if (threadIdx.x == 0) p.overflow[0] = 1;  // entries were dropped: the fallback kernels behind take over
+        if (lane == 0) p.overflow[0] = 1;  // entries were dropped: the fallback kernels behind take over
         return;
     }
     const int4* src = p.wbuf + (int64_t)wb * p.wcap;
-    const int sub = wb % p.nsub;
-    for (int e = threadIdx.x; e < n; e += 256) {
+    // (a hash: neighbouring buffers hold neighbouring units of one list, whose candidates belong to the same queries)
+    const int sub = (int)((((unsigned)wb * 2654435761u) >> 16) % (unsigned)p.nsub);
+    for (int e = lane; e < n; e += 64) {
         const int4 c = src[e];
         const int64_t lst = (int64_t)c.x * p.nsub + sub;
         const int pos = atomicAdd(p.cnt + lst, 1);
         if (pos < p.cap) {
             p.cand_d[lst * p.cap + pos] = __builtin_bit_cast(float, c.y);
             p.cand_i[lst * p.cap + pos] = c.z;
+        } else if (p.slow) {
+            p.slow[c.x] = 1;    // more rows under this query's bound than its lists hold: the exact slow path takes it
         } else {
-            p.overflow[0] = 1;  // more rows under a query's bound than its lists hold
+            p.overflow[0] = 1;  // ... or, where there is no per-query slow path, the launch's fallback kernels
         }
     }
 }
@@ -1350,7 +1355,7 @@ hipError_t launch_scan_f32_stream(const StreamParams& p, int grid, hipStream_t s
 
 // wave buffers -> per-query lists (after a streaming scan that filled `n_buffers` of them)
 hipError_t launch_cand_bin(const CandSink& sink, int n_buffers, hipStream_t s) {
-    hipLaunchKernelGGL(cand_bin_kernel, dim3(n_buffers), dim3(256), 0, s, sink);
+    hipLaunchKernelGGL(cand_bin_kernel, dim3((n_buffers + 3) / 4), dim3(256), 0, s, sink, n_buffers);
     return hipGetLastError();
 }
 
@@ -3362,94 +3367,151 @@ hipError_t launch_query_prep(const SeedParams& p, hipStream_t s) {
     return hipGetLastError();
 }
 
-// Bound of a query = k-th smallest distance among the first kIvfTauRows rows of its nearest resident list holding at
-// least k rows (those rows are candidates, so k of them at most that far bound the k-th best of all candidates).  One
-// wave per query: 16-row MFMA tiles with the query in column 0 of the B operand, distances through LDS, k rounds of a
-// wave minimum.  No such list: tau = +inf and the query is marked for the exact slow path.
+// Bound of a query = k-th smallest distance among the first kIvfTauRows rows of each of its two nearest resident lists
+// (those rows are candidates, so k of them at most that far bound the k-th best of all candidates; two lists because the
+// query's own neighbourhood is not always in the nearest one).  One wave per query: 16-row MFMA tiles with the query in
+// column 0 of the B operand, distances through LDS, k rounds of a wave minimum.  Fewer than k rows: tau = +inf and the
+// query is marked for the exact slow path.
 __global__ __launch_bounds__(256) void ivf_tau_kernel(const IvfWideParams p) {
     typedef int i32x4 __attribute__((ext_vector_type(4)));
     typedef int i32x4_u __attribute__((ext_vector_type(4), aligned(4)));
     typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
-    __shared__ __attribute__((aligned(16))) float dist[4][kIvfTauRows];
+    constexpr int NSEG = 2;                      // lists sampled per query
+    constexpr int SEGR = kIvfTauRows;            // rows per list
+    constexpr int NR = NSEG * SEGR;              // distance slots per query
+    __shared__ __attribute__((aligned(16))) float dist[4][NR];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int qg = (int)blockIdx.x * 4 + wave;
     const int batch = qg >> 5, qi = qg & 31;
     if (batch >= p.n_batches || qi >= p.B) return;  // wave-uniform
     const int r = lane & 15, g = lane >> 4;
     const int32_t* pr = reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(p.probes) + (long long)batch * p.probes_batch_bytes) + qi * p.nprobe;
-    int start = 0, rows = 0;
-    for (int pp = 0; pp < p.nprobe; ++pp) {
+    // the first NSEG probed lists that are resident here: their first SEGR rows each (k rows in all are needed)
+    int seg_start[NSEG], seg_rows[NSEG];
+    int nseg = 0, total_rows = 0;
+#pragma unroll
+    for (int sgm = 0; sgm < NSEG; ++sgm) seg_start[sgm] = seg_rows[sgm] = 0;
+    for (int pp = 0; pp < p.nprobe && nseg < NSEG; ++pp) {
         const int c = pr[pp];
         if (c < 0) continue;
         const int len = p.offsets[c + 1] - p.offsets[c];
-        if (len >= p.k) {
-            start = p.offsets[c];
-            rows = min(len, kIvfTauRows);
-            break;
+        if (len > 0) {
+            const int take = min(len, SEGR);
+#pragma unroll
+            for (int sgm = 0; sgm < NSEG; ++sgm)
+                if (sgm == nseg) {
+                    seg_start[sgm] = p.offsets[c];
+                    seg_rows[sgm] = take;
+                }
+            ++nseg;
+            total_rows += take;
         }
     }
-    if (rows == 0) {
+    if (total_rows < p.k) {
         if (lane == 0) {
             p.tau[qg] = VS_INF;
             p.slow[qg] = 1;
         }
         return;
     }
-    for (int i = lane; i < kIvfTauRows; i += 64) dist[wave][i] = VS_INF;
+    for (int i = lane; i < NR; i += 64) dist[wave][i] = VS_INF;
     const bool i8 = p.vecs_u8 && p.metric == 0 && p.invalid[batch] == 0;
-    const int tiles = (rows + 15) >> 4;
+    i32x4 b0 = {0, 0, 0, 0}, b1 = {0, 0, 0, 0};
+    f32x4 qf[8];
+    int qt = 0;
+    float qn = 0.f;
     if (i8) {
-        i32x4 b0 = {0, 0, 0, 0}, b1 = {0, 0, 0, 0};
         if (r == 0) {
             b0 = *reinterpret_cast<const i32x4*>(p.q8 + (int64_t)qg * kDim + 16 * g);
             b1 = *reinterpret_cast<const i32x4*>(p.q8 + (int64_t)qg * kDim + 64 + 16 * g);
         }
-        const int qt = p.qterm[qg];
-        for (int t = 0; t < tiles; ++t) {
-            const int row = min(start + 16 * t + r, start + rows - 1);
-            const i32x4 a0 = *reinterpret_cast<const i32x4*>(p.vecs_u8 + (int64_t)row * kDim + 16 * g);
-            const i32x4 a1 = *reinterpret_cast<const i32x4*>(p.vecs_u8 + (int64_t)row * kDim + 64 + 16 * g);
-            const i32x4 rt = *reinterpret_cast<const i32x4_u*>(p.rterm + start + 16 * t + 4 * g);  // padded by 64
-            i32x4 acc = {0, 0, 0, 0};
-            acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b0, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b1, acc, 0, 0, 0);
-            if (r == 0) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (16 * t + 4 * g + j < rows) dist[wave][16 * t + 4 * g + j] = (float)(qt + rt[j] - 2 * acc[j]);
-            }
-        }
+        qt = p.qterm[qg];
     } else {
         const float* qsrc = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.q) + (long long)batch * p.q_batch_bytes) + qi * kDim;
-        f32x4 qf[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             qf[c] = *reinterpret_cast<const f32x4*>(qsrc + 16 * c + 4 * g);
             if (r != 0) qf[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-        const float qn = p.qnorm[qg];
-        for (int t = 0; t < tiles; ++t) {
-            const int row = min(start + 16 * t + r, start + rows - 1);
-            f32x4 a[8];
+        qn = p.qnorm[qg];
+    }
 #pragma unroll
-            for (int c = 0; c < 8; ++c) a[c] = *reinterpret_cast<const f32x4*>(p.vecs + (int64_t)row * kDim + 16 * c + 4 * g);
-            const f32x4 bn = *reinterpret_cast<const f32x4_u*>(p.vnorm + start + 16 * t + 4 * g);  // padded by 64
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int sgm = 0; sgm < NSEG; ++sgm) {
+        const int start = seg_start[sgm], rows = seg_rows[sgm];
+        const int tiles = (rows + 15) >> 4;
+        float* dseg = &dist[wave][sgm * SEGR];
+        if (i8) {
+            constexpr int U = 4;  // tiles whose loads go out together
+            for (int t0 = 0; t0 < tiles; t0 += U) {
+                i32x4 a0[U], a1[U], rt[U];
 #pragma unroll
-            for (int c = 0; c < 8; ++c)
+                for (int u = 0; u < U; ++u) {
+                    const int t = min(t0 + u, tiles - 1);
+                    const int row = min(start + 16 * t + r, start + rows - 1);
+                    a0[u] = *reinterpret_cast<const i32x4*>(p.vecs_u8 + (int64_t)row * kDim + 16 * g);
+                    a1[u] = *reinterpret_cast<const i32x4*>(p.vecs_u8 + (int64_t)row * kDim + 64 + 16 * g);
+                    rt[u] = *reinterpret_cast<const i32x4_u*>(p.rterm + start + 16 * t + 4 * g);  // padded by 64
+                }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][i], qf[c][i], acc, 0, 0, 0);
-            if (r == 0) {
+                for (int u = 0; u < U; ++u) {
+                    const int t = t0 + u;
+                    if (t >= tiles) break;
+                    i32x4 acc = {0, 0, 0, 0};
+                    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0[u], b0, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1[u], b1, acc, 0, 0, 0);
+                    if (r == 0) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (16 * t + 4 * g + j < rows) dist[wave][16 * t + 4 * g + j] = p.metric ? -acc[j] : fmaf(-2.0f, acc[j], qn + bn[j]);
+                        for (int j = 0; j < 4; ++j)
+                            if (16 * t + 4 * g + j < rows) dseg[16 * t + 4 * g + j] = (float)(qt + rt[u][j] - 2 * acc[j]);
+                    }
+                }
+            }
+        } else {
+            for (int t = 0; t < tiles; ++t) {
+                const int row = min(start + 16 * t + r, start + rows - 1);
+                f32x4 a[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) a[c] = *reinterpret_cast<const f32x4*>(p.vecs + (int64_t)row * kDim + 16 * c + 4 * g);
+                const f32x4 bn = *reinterpret_cast<const f32x4_u*>(p.vnorm + start + 16 * t + 4 * g);  // padded by 64
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int c = 0; c < 8; ++c)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][i], qf[c][i], acc, 0, 0, 0);
+                if (r == 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (16 * t + 4 * g + j < rows) dseg[16 * t + 4 * g + j] = p.metric ? -acc[j] : fmaf(-2.0f, acc[j], qn + bn[j]);
+                }
             }
         }
     }
     __builtin_amdgcn_s_waitcnt(0);  // this wave's LDS writes (a wave reads only what it wrote)
     __builtin_amdgcn_wave_barrier();
-    const f32x4 v = *reinterpret_cast<const f32x4*>(&dist[wave][4 * lane]);
-    const float kth = wave_kth_smallest(v[0], v[1], v[2], v[3], p.k, lane);
+    // k-th smallest of the NR slots: every lane folds NR / 64 of them into a sorted pair list? -- simpler: two rounds of the
+    // four-per-lane selection would not compose, so select over per-lane minima first and refill from the lane's values
+    float v[NR / 64];
+#pragma unroll
+    for (int i = 0; i < NR / 64; ++i) v[i] = dist[wave][i * 64 + lane];
+    float kth = VS_INF;
+    for (int round = 0; round < p.k; ++round) {
+        float m = v[0];
+#pragma unroll
+        for (int i = 1; i < NR / 64; ++i) m = fminf(m, v[i]);
+        const float wm = wave_min_f32(m);
+        kth = wm;
+        if (!(wm < VS_INF)) break;
+        const unsigned long long mask = __ballot(m == wm);
+        if (lane == __builtin_ctzll(mask)) {  // drop exactly one instance
+            bool done = false;
+#pragma unroll
+            for (int i = 0; i < NR / 64; ++i)
+                if (!done && v[i] == wm) {
+                    v[i] = VS_INF;
+                    done = true;
+                }
+        }
+    }
     if (lane == 0) {
         // integer distances (int8 path) are exact: the bound may sit right above the k-th value; fp32 rows are scored
         // with the same MFMA chain as the scan here, but leave slack anyway (the bound only filters)
@@ -3459,32 +3521,35 @@ __global__ __launch_bounds__(256) void ivf_tau_kernel(const IvfWideParams p) {
     }
 }
 
-// Grouping + work plan of one super-batch (blockIdx.y), kPlanSplit workgroups each (see ivf_group_plan_kernel): the
-// query slots probing every list, and the 32-row units of every chunk whose list is probed.
+// Grouping of one super-batch (blockIdx.y): every (query, probe) pair takes a slot in its list's query table (one global
+// atomic per pair on the zeroed per-list counters: tens of thousands of pairs over a thousand counters, all in flight).
+__global__ __launch_bounds__(256) void ivf_count_wide_kernel(const IvfWideParams p) {
+    const int sb = blockIdx.y;
+    const int b0 = sb * kIvfWideBatches, b1 = min(p.n_batches, b0 + kIvfWideBatches);
+    const int per_batch = p.B * p.nprobe;
+    const int e = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    if (e >= (b1 - b0) * per_batch) return;
+    const int bb = e / per_batch, rem = e - bb * per_batch;
+    const int qi = rem / p.nprobe, pp = rem - qi * p.nprobe;
+    const int batch = b0 + bb;
+    const int c = reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(p.probes) + (long long)batch * p.probes_batch_bytes)[qi * p.nprobe + pp];
+    if (c < 0) return;
+    if (p.offsets[c + 1] == p.offsets[c]) return;  // empty (or not resident) list
+    const int slot = atomicAdd(p.zero + (int64_t)sb * (p.nlist + 16) + c, 1);  // < kIvfWideQ: a list is probed at most once per query
+    p.lq[((int64_t)sb * p.nlist + c) * kIvfWideQ + slot] = batch * kMaxBatch + qi;
+}
+
+// Work plan of one super-batch (blockIdx.y), several workgroups each (see ivf_group_plan_kernel): the 32-row units of
+// every chunk whose list is probed, as self-contained records.
 __global__ __launch_bounds__(1024) void ivf_plan_wide_kernel(const IvfWideParams p) {
     __shared__ int cnt_s[kIvfFastNlist];
     __shared__ int s_carry;
     __shared__ int s_wtot[16];
     const int tid = threadIdx.x;
     const int sb = blockIdx.y;
-    const int b0 = sb * kIvfWideBatches, b1 = min(p.n_batches, b0 + kIvfWideBatches);
-    const bool first = blockIdx.x == 0;
-    int32_t* lq = p.lq + (int64_t)sb * p.nlist * kIvfWideQ;
     int32_t* units = p.units + (int64_t)sb * p.units_sb_stride;
-    for (int c = tid; c < p.nlist; c += 1024) cnt_s[c] = 0;
+    for (int c = tid; c < p.nlist; c += 1024) cnt_s[c] = p.zero[(int64_t)sb * (p.nlist + 16) + c];
     if (tid == 0) s_carry = 0;
-    __syncthreads();
-    const int per_batch = p.B * p.nprobe;
-    for (int e = tid; e < (b1 - b0) * per_batch; e += 1024) {
-        const int bb = e / per_batch, rem = e - bb * per_batch;
-        const int qi = rem / p.nprobe, pp = rem - qi * p.nprobe;
-        const int batch = b0 + bb;
-        const int c = reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(p.probes) + (long long)batch * p.probes_batch_bytes)[qi * p.nprobe + pp];
-        if (c < 0) continue;
-        if (p.offsets[c + 1] == p.offsets[c]) continue;  // empty (or not resident) list
-        const int slot = atomicAdd(&cnt_s[c], 1);        // < kIvfWideQ: a list is probed at most once per query
-        if (first) lq[(int64_t)c * kIvfWideQ + slot] = batch * kMaxBatch + qi;
-    }
     __syncthreads();
     const int pl = tid & 63, wv = tid >> 6;
     const int nsl = (int)gridDim.x;
@@ -3527,7 +3592,7 @@ __global__ __launch_bounds__(1024) void ivf_plan_wide_kernel(const IvfWideParams
             const int r0 = p.chunk_row0[chunk];
             const int r_end = r0 + p.chunk_rows[chunk];
             const int nq = min(cnt_s[c], kIvfWideQ);
-            for (int i = 0; i < nu; ++i) reinterpret_cast<int4*>(units)[pos + i] = make_int4(r0 + 32 * i, r_end, c | (nq << 16), 0);
+            for (int i = 0; i < nu; ++i) reinterpret_cast<int4*>(units)[pos + i] = make_int4(r0 + 32 * i, r_end, c, nq);
         }
         __syncthreads();
         if (tid == 0) s_carry += tot;
@@ -3542,16 +3607,19 @@ __global__ __launch_bounds__(1024) void ivf_plan_wide_kernel(const IvfWideParams
 // (gathered from the staged bytes through the list's slot table), and a distance under its query's bound goes to the
 // wave's candidate buffer (plain stores, positions from a ballot).  Rows that are not bytes, or a super-batch with a
 // non-byte query: the same on the fp32 rows with queries gathered from global memory.
-constexpr int kIvfWideThreads = 256;
+constexpr int kIvfWideThreads = 1024;  // 16 waves, one workgroup per CU (its LDS holds the super-batch's queries)
+constexpr int kIvfWideWaves = kIvfWideThreads / 64;
+constexpr int kIvfWideLds = kIvfWideQ * kDim + 4 * kIvfWideQ * 4;  // query bytes + four per-query words
 __global__ __launch_bounds__(kIvfWideThreads) void ivf_scan_wide_kernel(const IvfWideParams p) {
     typedef int i32x4 __attribute__((ext_vector_type(4)));
     typedef int i32x4_u __attribute__((ext_vector_type(4), aligned(4)));
     typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
-    __shared__ __attribute__((aligned(16))) int q8_s[kIvfWideQ * 32];  // [slot][128 bytes]
-    __shared__ int qt_s[kIvfWideQ];
-    __shared__ int thr_s[kIvfWideQ];   // int8 path: 2 dot - rt > thr  <=>  d < tau
-    __shared__ float tau_s[kIvfWideQ];
-    __shared__ float qn_s[kIvfWideQ];
+    extern __shared__ __attribute__((aligned(16))) char wide_smem[];
+    int* q8_s = reinterpret_cast<int*>(wide_smem);                       // [slot][128 bytes]
+    int* qt_s = reinterpret_cast<int*>(wide_smem + kIvfWideQ * kDim);    // [slot]
+    int* thr_s = qt_s + kIvfWideQ;                                       // int8 path: 2 dot - rt > thr  <=>  d < tau
+    float* tau_s = reinterpret_cast<float*>(thr_s + kIvfWideQ);
+    float* qn_s = tau_s + kIvfWideQ;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, g = lane >> 4;
@@ -3559,9 +3627,9 @@ __global__ __launch_bounds__(kIvfWideThreads) void ivf_scan_wide_kernel(const Iv
     const int b0 = sb * kIvfWideBatches, b1 = min(p.n_batches, b0 + kIvfWideBatches);
     const int nslots = (b1 - b0) * kMaxBatch;
     const int n_units = p.zero[(int64_t)sb * (p.nlist + 16) + p.nlist];
-    const int wb = ((int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x) * 4 + wave;  // this wave's candidate buffer
+    const int wb = ((int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x) * kIvfWideWaves + wave;  // this wave's candidate buffer
     int wbase = 0;
-    if ((int)blockIdx.x * 4 < n_units) {  // workgroup-uniform
+    if ((int)blockIdx.x < n_units) {  // workgroup-uniform: wave 0's first unit exists
     bool any_invalid = false;
     for (int b = b0; b < b1; ++b) any_invalid = any_invalid || p.invalid[b] != 0;
     const bool i8 = p.vecs_u8 && p.metric == 0 && !any_invalid;
@@ -3585,25 +3653,35 @@ __global__ __launch_bounds__(kIvfWideThreads) void ivf_scan_wide_kernel(const Iv
     const int4* recs = reinterpret_cast<const int4*>(p.units + (int64_t)sb * p.units_sb_stride);
     const int32_t* lq = p.lq + (int64_t)sb * p.nlist * kIvfWideQ;
     int4* wbuf = p.sink.wbuf + (int64_t)wb * p.sink.wcap;
-    const int nw = (int)gridDim.x * 4;
-    int u = (int)blockIdx.x * 4 + wave;
-    int4 rec = u < n_units ? recs[u] : make_int4(0, 0, 0, 0);
-    for (; u < n_units; u += nw) {
-        const int r0 = __builtin_amdgcn_readfirstlane(rec.x);
-        const int r_end = __builtin_amdgcn_readfirstlane(rec.y);
-        const int c = __builtin_amdgcn_readfirstlane(rec.z) & 0xffff;
-        const int nq = __builtin_amdgcn_readfirstlane(rec.z) >> 16;
-        if (u + nw < n_units) rec = recs[u + nw];  // the next unit's record, in flight during this unit
-        const int32_t* lqc = lq + (int64_t)c * kIvfWideQ;
-        if (i8) {
-            i32x4 a0[2], a1[2], rt[2];
+    const int nw = (int)gridDim.x * kIvfWideWaves;
+    // units are dealt so that the waves of a workgroup take neighbouring units (neighbouring rows) at any moment
+    int u = wave * (int)gridDim.x + (int)blockIdx.x;
+    if (i8) {
+        // software pipeline: the next unit's rows are requested before this unit is scored (a wave has a handful of units:
+        // one at a time it would pay the cache latency of its rows per unit)
+        auto load_unit = [&](const int4& rc, i32x4 (&a0)[2], i32x4 (&a1)[2], i32x4 (&rt)[2]) __attribute__((always_inline)) {
+            const int ur0 = rc.x, ur_end = rc.y;
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                const int row = min(r0 + 16 * t + r, r_end - 1);
+                const int row = max(min(ur0 + 16 * t + r, ur_end - 1), 0);
                 a0[t] = *reinterpret_cast<const i32x4*>(p.vecs_u8 + (int64_t)row * kDim + 16 * g);
                 a1[t] = *reinterpret_cast<const i32x4*>(p.vecs_u8 + (int64_t)row * kDim + 64 + 16 * g);
-                rt[t] = *reinterpret_cast<const i32x4_u*>(p.rterm + r0 + 16 * t + 4 * g);  // past the chunk: readable, never used
+                rt[t] = *reinterpret_cast<const i32x4_u*>(p.rterm + ur0 + 16 * t + 4 * g);  // past the chunk: readable, never used
             }
+        };
+        int4 rec = u < n_units ? recs[u] : make_int4(0, 0, 0, 0);
+        int4 rec_n = u + nw < n_units ? recs[u + nw] : make_int4(0, 0, 0, 0);
+        i32x4 a0[2], a1[2], rt[2];
+        if (u < n_units) load_unit(rec, a0, a1, rt);
+        for (; u < n_units; u += nw) {
+            const int r0 = __builtin_amdgcn_readfirstlane(rec.x);
+            const int r_end = __builtin_amdgcn_readfirstlane(rec.y);
+            const int c = __builtin_amdgcn_readfirstlane(rec.z);
+            const int nq = __builtin_amdgcn_readfirstlane(rec.w);
+            const int4 rec_nn = u + 2 * nw < n_units ? recs[u + 2 * nw] : make_int4(0, 0, 0, 0);
+            i32x4 b0n[2], b1n[2], rtn[2];
+            load_unit(rec_n, b0n, b1n, rtn);  // (a zero record past the end reads row 0: harmless)
+            const int32_t* lqc = lq + (int64_t)c * kIvfWideQ;
             for (int cb = 0; cb < nq; cb += 16) {
                 const int sq = cb + r;
                 const bool live = sq < nq;
@@ -3639,7 +3717,25 @@ __global__ __launch_bounds__(kIvfWideThreads) void ivf_scan_wide_kernel(const Iv
                         }
                 }
             }
-        } else {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                a0[t] = b0n[t];
+                a1[t] = b1n[t];
+                rt[t] = rtn[t];
+            }
+            rec = rec_n;
+            rec_n = rec_nn;
+        }
+    } else {
+    int4 rec = u < n_units ? recs[u] : make_int4(0, 0, 0, 0);
+    for (; u < n_units; u += nw) {
+        const int r0 = __builtin_amdgcn_readfirstlane(rec.x);
+        const int r_end = __builtin_amdgcn_readfirstlane(rec.y);
+        const int c = __builtin_amdgcn_readfirstlane(rec.z);
+        const int nq = __builtin_amdgcn_readfirstlane(rec.w);
+        if (u + nw < n_units) rec = recs[u + nw];  // the next unit's record, in flight during this unit
+        const int32_t* lqc = lq + (int64_t)c * kIvfWideQ;
+        {
 #pragma unroll 1
             for (int t = 0; t < 2; ++t) {
                 if (r0 + 16 * t >= r_end) break;  // wave-uniform
@@ -3680,6 +3776,7 @@ __global__ __launch_bounds__(kIvfWideThreads) void ivf_scan_wide_kernel(const Iv
         }
     }
     }
+    }
     if (lane == 0) p.sink.wcount[wb] = wbase;  // every wave of the grid reports (idle ones: 0)
 }
 
@@ -3716,10 +3813,16 @@ __global__ __launch_bounds__(256) void ivf_wide_slow_kernel(const IvfWideParams 
         for (int row = s0 + tid; row < s1; row += 256) {
             float d;
             if (i8) {
-                const int8_t* b = p.vecs_u8 + (int64_t)row * kDim;
-                const int8_t* qq = p.q8 + (int64_t)qg * kDim;
+                typedef int i32x4 __attribute__((ext_vector_type(4)));
+                const i32x4* b = reinterpret_cast<const i32x4*>(p.vecs_u8 + (int64_t)row * kDim);
+                const i32x4* qq = reinterpret_cast<const i32x4*>(p.q8 + (int64_t)qg * kDim);
                 int dot = 0;
-                for (int t = 0; t < kDim; ++t) dot += (int)b[t] * (int)qq[t];
+#pragma unroll
+                for (int t = 0; t < kDim / 16; ++t) {
+                    const i32x4 bv = b[t], qv4 = qq[t];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dot = __builtin_amdgcn_sdot4(bv[e], qv4[e], dot, false);  // four signed bytes at a time
+                }
                 d = (float)(qt + p.rterm[row] - 2 * dot);
             } else {
                 const float* b = p.vecs + (int64_t)row * kDim;
@@ -3781,14 +3884,25 @@ __global__ __launch_bounds__(256) void ivf_wide_slow_kernel(const IvfWideParams 
     }
 }
 
-int ivf_wide_grid_x(int num_cus, int n_sb) { return std::max(16, 4 * num_cus / n_sb); }
+int ivf_wide_grid_x(int num_cus, int n_sb) { return std::max(16, num_cus / n_sb); }
+int ivf_wide_waves(int num_cus, int n_sb) { return ivf_wide_grid_x(num_cus, n_sb) * n_sb * kIvfWideWaves; }
 
 hipError_t launch_ivf_wide(const IvfWideParams& p, int num_cus, hipStream_t s) {
     if (p.nlist > kIvfFastNlist || p.nprobe > kIvfMaxProbe || p.k > 16) return hipErrorInvalidValue;
     const int n_sb = (p.n_batches + kIvfWideBatches - 1) / kIvfWideBatches;
     hipLaunchKernelGGL(ivf_tau_kernel, dim3((p.n_batches * kMaxBatch + 3) / 4), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(ivf_plan_wide_kernel, dim3(kPlanSplit, n_sb), dim3(1024), 0, s, p);
-    hipLaunchKernelGGL(ivf_scan_wide_kernel, dim3(ivf_wide_grid_x(num_cus, n_sb), n_sb), dim3(kIvfWideThreads), 0, s, p);
+    const int pairs = std::min(p.n_batches, kIvfWideBatches) * p.B * p.nprobe;
+    hipLaunchKernelGGL(ivf_count_wide_kernel, dim3((pairs + 255) / 256, n_sb), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(ivf_plan_wide_kernel, dim3(std::max(kPlanSplit, 32 / n_sb), n_sb), dim3(1024), 0, s, p);
+    static bool attr_set[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!attr_set[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ivf_scan_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kIvfWideLds);
+        if (e != hipSuccess) return e;
+        attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL(ivf_scan_wide_kernel, dim3(ivf_wide_grid_x(num_cus, n_sb), n_sb), dim3(kIvfWideThreads), kIvfWideLds, s, p);
     return hipGetLastError();
 }
 
