@@ -3379,42 +3379,41 @@ __global__ __launch_bounds__(256) void ivf_tau_kernel(const IvfWideParams p) {
     constexpr int NSEG = 2;                      // lists sampled per query
     constexpr int SEGR = kIvfTauRows;            // rows per list
     constexpr int NR = NSEG * SEGR;              // distance slots per query
-    __shared__ __attribute__((aligned(16))) float dist[4][NR];
+    // a workgroup = 2 queries x NSEG waves: wave (slot, sgm) scores segment sgm of its query, the segment-0 wave selects
+    __shared__ __attribute__((aligned(16))) float dist[2][NR];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int qg = (int)blockIdx.x * 4 + wave;
+    const int slot = wave >> 1, myseg = wave & 1;
+    const int qg = (int)blockIdx.x * 2 + slot;
     const int batch = qg >> 5, qi = qg & 31;
-    if (batch >= p.n_batches || qi >= p.B) return;  // wave-uniform
+    const bool valid = batch < p.n_batches && qi < p.B;  // wave-uniform
     const int r = lane & 15, g = lane >> 4;
-    const int32_t* pr = reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(p.probes) + (long long)batch * p.probes_batch_bytes) + qi * p.nprobe;
-    // the first NSEG probed lists that are resident here: their first SEGR rows each (k rows in all are needed)
     int seg_start[NSEG], seg_rows[NSEG];
     int nseg = 0, total_rows = 0;
 #pragma unroll
     for (int sgm = 0; sgm < NSEG; ++sgm) seg_start[sgm] = seg_rows[sgm] = 0;
-    for (int pp = 0; pp < p.nprobe && nseg < NSEG; ++pp) {
-        const int c = pr[pp];
-        if (c < 0) continue;
-        const int len = p.offsets[c + 1] - p.offsets[c];
-        if (len > 0) {
-            const int take = min(len, SEGR);
+    if (valid) {
+        const int32_t* pr = reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(p.probes) + (long long)batch * p.probes_batch_bytes) + qi * p.nprobe;
+        // the first NSEG probed lists that are resident here: their first SEGR rows each (k rows in all are needed)
+        for (int pp = 0; pp < p.nprobe && nseg < NSEG; ++pp) {
+            const int c = pr[pp];
+            if (c < 0) continue;
+            const int len = p.offsets[c + 1] - p.offsets[c];
+            if (len > 0) {
+                const int take = min(len, SEGR);
 #pragma unroll
-            for (int sgm = 0; sgm < NSEG; ++sgm)
-                if (sgm == nseg) {
-                    seg_start[sgm] = p.offsets[c];
-                    seg_rows[sgm] = take;
-                }
-            ++nseg;
-            total_rows += take;
+                for (int sgm = 0; sgm < NSEG; ++sgm)
+                    if (sgm == nseg) {
+                        seg_start[sgm] = p.offsets[c];
+                        seg_rows[sgm] = take;
+                    }
+                ++nseg;
+                total_rows += take;
+            }
         }
     }
-    if (total_rows < p.k) {
-        if (lane == 0) {
-            p.tau[qg] = VS_INF;
-            p.slow[qg] = 1;
-        }
-        return;
-    }
-    for (int i = lane; i < NR; i += 64) dist[wave][i] = VS_INF;
+    const bool usable = valid && total_rows >= p.k;
+    for (int i = lane; i < SEGR; i += 64) dist[slot][myseg * SEGR + i] = VS_INF;
+    if (usable) {
     const bool i8 = p.vecs_u8 && p.metric == 0 && p.invalid[batch] == 0;
     i32x4 b0 = {0, 0, 0, 0}, b1 = {0, 0, 0, 0};
     f32x4 qf[8];
@@ -3435,11 +3434,10 @@ __global__ __launch_bounds__(256) void ivf_tau_kernel(const IvfWideParams p) {
         }
         qn = p.qnorm[qg];
     }
-#pragma unroll
-    for (int sgm = 0; sgm < NSEG; ++sgm) {
-        const int start = seg_start[sgm], rows = seg_rows[sgm];
+    {
+        const int start = myseg ? seg_start[1] : seg_start[0], rows = myseg ? seg_rows[1] : seg_rows[0];
         const int tiles = (rows + 15) >> 4;
-        float* dseg = &dist[wave][sgm * SEGR];
+        float* dseg = &dist[slot][myseg * SEGR];
         if (i8) {
             constexpr int U = 4;  // tiles whose loads go out together
             for (int t0 = 0; t0 < tiles; t0 += U) {
@@ -3486,13 +3484,21 @@ __global__ __launch_bounds__(256) void ivf_tau_kernel(const IvfWideParams p) {
             }
         }
     }
-    __builtin_amdgcn_s_waitcnt(0);  // this wave's LDS writes (a wave reads only what it wrote)
-    __builtin_amdgcn_wave_barrier();
-    // k-th smallest of the NR slots: every lane folds NR / 64 of them into a sorted pair list? -- simpler: two rounds of the
-    // four-per-lane selection would not compose, so select over per-lane minima first and refill from the lane's values
+    }
+    __syncthreads();
+    if (!valid || myseg != 0) return;
+    if (!usable) {
+        if (lane == 0) {
+            p.tau[qg] = VS_INF;
+            p.slow[qg] = 1;
+        }
+        return;
+    }
+    const bool i8 = p.vecs_u8 && p.metric == 0 && p.invalid[batch] == 0;
+    // k-th smallest of the NR slots: k rounds of a wave minimum over the lanes' private values
     float v[NR / 64];
 #pragma unroll
-    for (int i = 0; i < NR / 64; ++i) v[i] = dist[wave][i * 64 + lane];
+    for (int i = 0; i < NR / 64; ++i) v[i] = dist[slot][i * 64 + lane];
     float kth = VS_INF;
     for (int round = 0; round < p.k; ++round) {
         float m = v[0];
@@ -3659,7 +3665,8 @@ __global__ __launch_bounds__(kIvfWideThreads) void ivf_scan_wide_kernel(const Iv
     if (i8) {
         // software pipeline: the next unit's rows are requested before this unit is scored (a wave has a handful of units:
         // one at a time it would pay the cache latency of its rows per unit)
-        auto load_unit = [&](const int4& rc, i32x4 (&a0)[2], i32x4 (&a1)[2], i32x4 (&rt)[2]) __attribute__((always_inline)) {
+        constexpr int PF = 4;  // column blocks whose query slots are fetched together with the unit's rows
+        auto load_unit = [&](const int4& rc, i32x4 (&a0)[2], i32x4 (&a1)[2], i32x4 (&rt)[2], int (&qgp)[PF]) __attribute__((always_inline)) {
             const int ur0 = rc.x, ur_end = rc.y;
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
@@ -3668,11 +3675,15 @@ __global__ __launch_bounds__(kIvfWideThreads) void ivf_scan_wide_kernel(const Iv
                 a1[t] = *reinterpret_cast<const i32x4*>(p.vecs_u8 + (int64_t)row * kDim + 64 + 16 * g);
                 rt[t] = *reinterpret_cast<const i32x4_u*>(p.rterm + ur0 + 16 * t + 4 * g);  // past the chunk: readable, never used
             }
+            const int32_t* lqn = lq + (int64_t)rc.z * kIvfWideQ;
+#pragma unroll
+            for (int i = 0; i < PF; ++i) qgp[i] = 16 * i + r < rc.w ? lqn[16 * i + r] : b0 * kMaxBatch;
         };
         int4 rec = u < n_units ? recs[u] : make_int4(0, 0, 0, 0);
         int4 rec_n = u + nw < n_units ? recs[u + nw] : make_int4(0, 0, 0, 0);
         i32x4 a0[2], a1[2], rt[2];
-        if (u < n_units) load_unit(rec, a0, a1, rt);
+        int qgc[PF];
+        if (u < n_units) load_unit(rec, a0, a1, rt, qgc);
         for (; u < n_units; u += nw) {
             const int r0 = __builtin_amdgcn_readfirstlane(rec.x);
             const int r_end = __builtin_amdgcn_readfirstlane(rec.y);
@@ -3680,38 +3691,52 @@ __global__ __launch_bounds__(kIvfWideThreads) void ivf_scan_wide_kernel(const Iv
             const int nq = __builtin_amdgcn_readfirstlane(rec.w);
             const int4 rec_nn = u + 2 * nw < n_units ? recs[u + 2 * nw] : make_int4(0, 0, 0, 0);
             i32x4 b0n[2], b1n[2], rtn[2];
-            load_unit(rec_n, b0n, b1n, rtn);  // (a zero record past the end reads row 0: harmless)
+            int qgn[PF];
+            load_unit(rec_n, b0n, b1n, rtn, qgn);  // (a zero record past the end reads row 0 and no slots: harmless)
             const int32_t* lqc = lq + (int64_t)c * kIvfWideQ;
+            i32x4 nrh[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) nrh[t] = -(rt[t] >> 1);
             for (int cb = 0; cb < nq; cb += 16) {
                 const int sq = cb + r;
                 const bool live = sq < nq;
-                const int qg = live ? lqc[sq] : b0 * kMaxBatch;
+                int qg;
+                if (cb < 16 * PF) {  // wave-uniform: prefetched slots (static indexing)
+                    qg = qgc[0];
+#pragma unroll
+                    for (int i = 1; i < PF; ++i) qg = cb == 16 * i ? qgc[i] : qg;
+                } else {
+                    qg = live ? lqc[sq] : b0 * kMaxBatch;
+                }
                 const int ql = qg - b0 * kMaxBatch;
                 const i32x4 bq0 = *reinterpret_cast<const i32x4*>(q8_s + ql * 32 + 4 * g);
                 const i32x4 bq1 = *reinterpret_cast<const i32x4*>(q8_s + ql * 32 + 16 + 4 * g);
                 const int th = live ? thr_s[ql] : 0x7fffffff;
+                // d < tau  <=>  2 dot - rt > thr; with rt = 2 rh + ro and thr lowered to even that is dot - rh > thr >> 1:
+                // -rh is the C operand of the first MFMA and the hot path only takes the maximum of the 8 results (a block
+                // that passes is tested exactly below) -- see scan_i8w_kernel
                 i32x4 acc[2];
-                bool any = false;
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0[t], bq0, (i32x4){0, 0, 0, 0}, 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0[t], bq0, nrh[t], 0, 0, 0);
                     acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1[t], bq1, acc[t], 0, 0, 0);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) any = any || (2 * acc[t][j] - rt[t][j] > th);
                 }
-                if (__ballot(any)) {  // rare
+                const int emax = max(max(max(acc[0][0], acc[0][1]), max(acc[0][2], acc[0][3])),
+                                     max(max(acc[1][0], acc[1][1]), max(acc[1][2], acc[1][3])));
+                if (__ballot(emax > (th >> 1))) {  // rare
                     const int qt = qt_s[ql];
 #pragma unroll
                     for (int t = 0; t < 2; ++t)
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const int row = r0 + 16 * t + 4 * g + j;
-                            const bool pass = live && 2 * acc[t][j] - rt[t][j] > th && row < r_end;
+                            const int dot = acc[t][j] - nrh[t][j];  // = (x - 128) . (q - 128)
+                            const bool pass = live && 2 * dot - rt[t][j] > th && row < r_end;
                             const unsigned long long mask = __ballot(pass);
                             if (mask) {
                                 const int pos = wbase + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
                                 if (pass && pos < p.sink.wcap)
-                                    wbuf[pos] = make_int4(qg, __builtin_bit_cast(int, (float)(qt + rt[t][j] - 2 * acc[t][j])), row, 0);
+                                    wbuf[pos] = make_int4(qg, __builtin_bit_cast(int, (float)(qt + rt[t][j] - 2 * dot)), row, 0);
                                 wbase += __popcll(mask);
                             }
                         }
@@ -3723,6 +3748,8 @@ __global__ __launch_bounds__(kIvfWideThreads) void ivf_scan_wide_kernel(const Iv
                 a1[t] = b1n[t];
                 rt[t] = rtn[t];
             }
+#pragma unroll
+            for (int i = 0; i < PF; ++i) qgc[i] = qgn[i];
             rec = rec_n;
             rec_n = rec_nn;
         }
@@ -3890,7 +3917,7 @@ int ivf_wide_waves(int num_cus, int n_sb) { return ivf_wide_grid_x(num_cus, n_sb
 hipError_t launch_ivf_wide(const IvfWideParams& p, int num_cus, hipStream_t s) {
     if (p.nlist > kIvfFastNlist || p.nprobe > kIvfMaxProbe || p.k > 16) return hipErrorInvalidValue;
     const int n_sb = (p.n_batches + kIvfWideBatches - 1) / kIvfWideBatches;
-    hipLaunchKernelGGL(ivf_tau_kernel, dim3((p.n_batches * kMaxBatch + 3) / 4), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(ivf_tau_kernel, dim3((p.n_batches * kMaxBatch + 1) / 2), dim3(256), 0, s, p);
     const int pairs = std::min(p.n_batches, kIvfWideBatches) * p.B * p.nprobe;
     hipLaunchKernelGGL(ivf_count_wide_kernel, dim3((pairs + 255) / 256, n_sb), dim3(256), 0, s, p);
     hipLaunchKernelGGL(ivf_plan_wide_kernel, dim3(std::max(kPlanSplit, 32 / n_sb), n_sb), dim3(1024), 0, s, p);
