@@ -686,7 +686,6 @@ int bf_launch(vs_index* h, vs_index::Lane& L, const float* q_dev, int nb, int B,
             const int wgrid = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(h->num_cus, vs::kSlotStride), tiles64));
             HIPCHK(vs::launch_scan_i8_wide(wp, wgrid, g_i8_wide, s));
             prof_end(h, 0, s);
-            HIPCHK(vs::launch_cand_bin(sink, wgrid * vs::kScanWaves, s));
         } else {
             vs::StreamParams sp{};
             sp.base = h->d_vecs;
@@ -704,7 +703,6 @@ int bf_launch(vs_index* h, vs_index::Lane& L, const float* q_dev, int nb, int B,
             const int sgrid = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(h->num_cus, vs::kSlotStride), tiles_total));
             HIPCHK(vs::launch_scan_f32_stream(sp, sgrid, s));
             prof_end(h, 0, s);
-            HIPCHK(vs::launch_cand_bin(sink, sgrid * vs::kScanWaves, s));
         }
         // every query's candidate list (unsorted, a few hundred entries) -> k1 best by (dist, id), tie flags
         vs::MergeParams mf = m;
@@ -960,7 +958,7 @@ int ensure_ivf_wide(vs_index* h) {
     const int n_sb_max = (kMaxMulti + vs::kIvfWideBatches - 1) / vs::kIvfWideBatches;
     W.n_waves = 0;
     for (int n = 1; n <= n_sb_max; ++n) W.n_waves = std::max(W.n_waves, vs::ivf_wide_waves(h->num_cus, n));
-    W.zero_words = (size_t)n_sb_max * (h->nlist + 16) + nq + 16 + nq * kWideSub;
+    W.zero_words = (size_t)n_sb_max * (h->nlist + 16) + nq + 64 + nq * kWideSub;
     if ((rc = dev_alloc(&W.lq, (size_t)n_sb_max * h->nlist * vs::kIvfWideQ))) return rc;
     if ((rc = dev_alloc(&W.zero, W.zero_words))) return rc;
     if ((rc = dev_alloc(&W.units, (size_t)n_sb_max * std::max<int64_t>(h->n_units_max, 1) * 4))) return rc;
@@ -983,16 +981,14 @@ int ivf_group_wide_dev(vs_index* h, const float* q_dev, int nb, int B, int k, in
     if (rc) return rc;
     if ((rc = ensure_ivf_wide(h))) return rc;
     vs_index::IvfWide& W = h->wide;
-    const int n_sb = (nb + vs::kIvfWideBatches - 1) / vs::kIvfWideBatches;
     const size_t nq = (size_t)kMaxMulti * 32;
     int32_t* const z_plan = W.zero;                                   // [n_sb_max][nlist + 16]
     const int n_sb_max = (kMaxMulti + vs::kIvfWideBatches - 1) / vs::kIvfWideBatches;
     int32_t* const z_slow = z_plan + (size_t)n_sb_max * (h->nlist + 16);  // [1024]
     int32_t* const z_ovf = z_slow + nq;                               // [16]: word 0 = overflow
-    int32_t* const z_cnt = z_ovf + 16;                                // [1024][16]
+    int32_t* const invalid = z_ovf + 16;                              // [32] batches with a query that is not byte valued
+    int32_t* const z_cnt = z_ovf + 64;                                // [1024][16]
     HIPCHK(hipMemsetAsync(W.zero, 0, W.zero_words * sizeof(int32_t), s));
-    int32_t* const invalid = h->mb_zslab;  // [nb] (first words of the per-batch zero block: cleared here)
-    HIPCHK(hipMemsetAsync(h->mb_zslab, 0, (size_t)kMaxMulti * sizeof(int32_t), s));
     vs::IvfMulti mb{};
     mb.slab = h->mb_slab_stride;
     mb.zslab = h->mb_zslab_stride * (long long)sizeof(int32_t);
@@ -1070,8 +1066,6 @@ int ivf_group_wide_dev(vs_index* h, const float* q_dev, int nb, int B, int k, in
     prof_begin(h, 1, s);
     HIPCHK(vs::launch_ivf_wide(wp, h->num_cus, s));
     prof_end(h, 1, s);
-    const int waves = vs::ivf_wide_waves(h->num_cus, n_sb);
-    HIPCHK(vs::launch_cand_bin(wp.sink, waves, s));
     vs::MergeParams m{};
     m.part_d = W.cand_d;
     m.part_i = W.cand_i;
@@ -2326,7 +2320,7 @@ __attribute__((visibility("default"))) int vs_debug_ivf_wide_stats(vs_index* h, 
     HIPCHK(hipMemcpy(tau.data(), h->wide.tau, nq * 4, hipMemcpyDeviceToHost));
     const int32_t* slow = z.data() + (size_t)n_sb_max * (h->nlist + 16);
     const int32_t* ovf = slow + nq;
-    const int32_t* cnt = ovf + 16;
+    const int32_t* cnt = ovf + 64;
     int64_t nslow = 0, total = 0, maxw = 0, maxsub = 0, ninf = 0;
     for (size_t i = 0; i < nq; ++i) nslow += slow[i] != 0;
     for (size_t i = 0; i < nq; ++i) ninf += !(tau[i] < 3e38f);

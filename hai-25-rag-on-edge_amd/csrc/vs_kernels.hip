@@ -933,6 +933,34 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams 
 // runs over all passes of the launch (ticket = pass * T + n), so a wave slides from one pass into the next without
 // meeting anybody: the kernel has one barrier (ticket initialisation).
 // ------------------------------------------------------------------------------------------------
+// A wave bins the candidates it has collected (its private buffer `wb`, `n` entries) into the per-query lists.  Called at
+// the very end of a streaming scan, outside the tile loop: the returning atomics cost nothing there.
+__device__ __forceinline__ void sink_bin_wave(const CandSink& p, int wb, int n, int lane) {
+    if (n > p.wcap) {
+        if (lane == 0) p.overflow[0] = 1;  // entries were dropped: the fallback kernels behind take over
+        return;
+    }
+    if (n == 0) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the wave's own stores to the buffer are complete ...
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // ... and its loads below do not come from a stale cache line
+    const int4* src = p.wbuf + (int64_t)wb * p.wcap;
+    // (a hash: neighbouring buffers hold neighbouring units of one list, whose candidates belong to the same queries)
+    const int sub = (int)((((unsigned)wb * 2654435761u) >> 16) % (unsigned)p.nsub);
+    for (int e = lane; e < n; e += 64) {
+        const int4 c = src[e];
+        const int64_t lst = (int64_t)c.x * p.nsub + sub;
+        const int pos = atomicAdd(p.cnt + lst, 1);
+        if (pos < p.cap) {
+            p.cand_d[lst * p.cap + pos] = __builtin_bit_cast(float, c.y);
+            p.cand_i[lst * p.cap + pos] = c.z;
+        } else if (p.slow) {
+            p.slow[c.x] = 1;    // more rows under this query's bound than its lists hold: the exact slow path takes it
+        } else {
+            p.overflow[0] = 1;  // ... or, where there is no per-query slow path, the launch's fallback kernels
+        }
+    }
+}
+
 constexpr int kWideLds = kRingBytes + 64;
 
 template <int NQH>
@@ -1134,7 +1162,7 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_i8w_kernel(const WidePar
         step(1);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // retire the tail prefetches before the wave ends
-    if (lane == 0) p.sink.wcount[(int)blockIdx.x * kScanWaves + wave] = wbase;  // may exceed wcap: overflow, seen by the binning kernel
+    sink_bin_wave(p.sink, (int)blockIdx.x * kScanWaves + wave, wbase, lane);  // no separate binning launch
 }
 
 // Candidates of a streaming scan, wave buffers -> per-query lists (the only atomics of the path, massively parallel here).
@@ -1337,7 +1365,7 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_f32s_kernel(const Stream
         step(1);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // retire the tail prefetches before the wave ends
-    if (lane == 0) p.sink.wcount[(int)blockIdx.x * kScanWaves + wave] = wbase;
+    sink_bin_wave(p.sink, (int)blockIdx.x * kScanWaves + wave, wbase, lane);  // no separate binning launch
 }
 
 hipError_t launch_scan_f32_stream(const StreamParams& p, int grid, hipStream_t s) {
@@ -3804,7 +3832,7 @@ __global__ __launch_bounds__(kIvfWideThreads) void ivf_scan_wide_kernel(const Iv
     }
     }
     }
-    if (lane == 0) p.sink.wcount[wb] = wbase;  // every wave of the grid reports (idle ones: 0)
+    sink_bin_wave(p.sink, wb, wbase, lane);  // the wave's candidates go to the per-query lists here: no binning launch
 }
 
 // Exact slow path, one workgroup per query that has no usable bound (or every query when a candidate buffer overflowed:
