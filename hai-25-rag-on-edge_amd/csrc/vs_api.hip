@@ -996,24 +996,20 @@ int ivf_group_wide_dev(vs_index* h, const float* q_dev, int nb, int B, int k, in
     char* sl = h->mb_slab;
     int32_t* probes = reinterpret_cast<int32_t*>(sl + h->mb_off_probes);
     stage_mark(h, 0, s);
-    {   // ||q||^2 (reference order), queries as bytes, constant terms, per-batch "byte valued" verdict
-        vs::SeedParams sp{};
-        sp.q = q_dev;
-        sp.n_batches = nb;
-        sp.q_batch_stride = (int64_t)B * vs::kDim;
-        sp.nq_valid = B;
-        sp.qnorm = W.qnorm;
-        sp.q8 = W.q8;
-        sp.qterm = W.qterm;
-        sp.invalid = invalid;
-        HIPCHK(vs::launch_query_prep(sp, s));
-    }
     vs::IvfGroup grp{};
     grp.offsets = h->d_offsets;
     grp.lcnt = z_plan;  // non-null: the pick kernel also writes the window offsets and adds up the candidate count
     grp.qoff = reinterpret_cast<int32_t*>(sl + h->mb_off_qoff);
     grp.cand_count = h->d_cand;
     grp.mb = mb;
+    // the coarse kernel also prepares the queries for the int8 paths, the pick kernel also fills the lists' slot tables
+    grp.w_qnorm = W.qnorm;
+    grp.w_q8 = W.q8;
+    grp.w_qterm = W.qterm;
+    grp.w_invalid = invalid;
+    grp.w_cnt = z_plan;
+    grp.w_lq = W.lq;
+    grp.w_q = vs::kIvfWideQ;
     HIPCHK(vs::launch_ivf_coarse_pick(q_dev, B, h->d_centroids, h->d_cnorm, h->nlist, nprobe, h->metric,
                                       reinterpret_cast<float*>(sl + h->mb_off_scores), (h->nlist + 63) & ~63, probes, grp, s, nb));
     stage_mark(h, 1, s);

@@ -216,6 +216,15 @@ struct IvfGroup {
     int32_t* units;                  // [sum ceil(chunk_rows / 32)][4]: first row, chunk end row, list | queries << 16, list start
     int32_t* n_units;                // [1]
     IvfMulti mb;
+    // wide pipeline (one list-major pass per launch group): the coarse kernel also prepares the queries for the int8
+    // paths (block x = 0 of every batch), the pick kernel also enters every (query, probe) pair in its list's slot table
+    float* w_qnorm;                  // [n_batches][32] ||q||^2 (nullptr = not the wide pipeline)
+    int8_t* w_q8;                    // [n_batches][32][128] queries as bytes (x - 128)
+    int32_t* w_qterm;                // [n_batches][32]
+    int32_t* w_invalid;              // [n_batches] (pre-set to 0): a query of the batch is not byte valued
+    int32_t* w_cnt;                  // [nlist] (pre-set to 0) queries of the GROUP probing each list
+    int32_t* w_lq;                   // [nlist][w_q] their slots (batch * 32 + q)
+    int w_q;
 };
 
 // Coarse stage: Q x C^T + L2 epilogue on MFMA into scores [n_batches][32][ld] (ld >= nlist rounded up to 64; batch y's

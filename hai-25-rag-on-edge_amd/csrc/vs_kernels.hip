@@ -1866,7 +1866,72 @@ __global__ __launch_bounds__(256) void merge_compact_kernel(const MergeParams p,
     const int M = cnt;
     const int n_track = p.kout < kMergeTrack ? p.kout : kMergeTrack;
 
-    if (M <= 1024) {
+    // Many candidates (a loose bound on a few queries): the kout-th smallest of the first 1024 bounds the answer; whatever
+    // is not above it (usually a few dozen entries) is copied aside and ranked by one wave like a short list.
+    __shared__ float cd2[1024];
+    __shared__ int ci2[1024];
+    __shared__ float s_thr_d;
+    __shared__ int s_thr_i, s_keep;
+    bool filtered = false;
+    if (M > 1024 && p.kout <= 64) {  // workgroup-uniform
+        if (wave == 0) {
+            float d[16];
+            int id[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                d[e] = cd[e * 64 + lane];
+                id[e] = ci[e * 64 + lane];
+            }
+            float bd = VS_INF;
+            int bi = 0x7fffffff;
+            for (int round = 0; round < p.kout; ++round) {
+                float md = d[0];
+                int mi = id[0];
+#pragma unroll
+                for (int e = 1; e < 16; ++e)
+                    if (lex_lt(d[e], id[e], md, mi)) {
+                        md = d[e];
+                        mi = id[e];
+                    }
+                wave_lexmin(md, mi, bd, bi);
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    if (id[e] == bi && d[e] == bd) {
+                        d[e] = VS_INF;
+                        id[e] = 0x7fffffff;
+                    }
+            }
+            if (lane == 0) {
+                s_thr_d = bd;
+                s_thr_i = bi;
+                s_keep = 0;
+            }
+        }
+        __syncthreads();
+        const float td = s_thr_d;
+        const int ti = s_thr_i;
+        for (int e = tid; e < M; e += 256) {
+            const float d = cd[e];
+            const int id = ci[e];
+            if (!lex_lt(td, ti, d, id)) {  // (d, id) <= (td, ti)
+                const int pos = atomicAdd(&s_keep, 1);
+                if (pos < 1024) {
+                    cd2[pos] = d;
+                    ci2[pos] = id;
+                }
+            }
+        }
+        __syncthreads();
+        filtered = s_keep <= 1024;  // else: masses of ties at the threshold -> the workgroup-wide rounds below
+    }
+    if (filtered) {
+        const int S = s_keep;
+        if (wave == 0) {
+            if (S <= 64) wave_rank_and_emit<1>(p, q, cd2, ci2, S, outd, lane);
+            else if (S <= 256) wave_rank_and_emit<4>(p, q, cd2, ci2, S, outd, lane);
+            else wave_rank_and_emit<16>(p, q, cd2, ci2, S, outd, lane);
+        }
+    } else if (M <= 1024) {
         if (wave == 0) {
             if (M <= 64) wave_rank_and_emit<1>(p, q, cd, ci, M, outd, lane);
             else if (M <= 256) wave_rank_and_emit<4>(p, q, cd, ci, M, outd, lane);
@@ -2158,7 +2223,7 @@ __device__ __forceinline__ T* mb_adv(T* ptr, long long bytes) {
 // would produce.  1024 x 1024 x 128 per group of 32 batches: a few microseconds.
 __global__ __launch_bounds__(256) void ivf_coarse_mfma_kernel(const float* __restrict__ q, int B, const float* __restrict__ cents,
                                                              const float* __restrict__ cnorm, int nlist, int metric,
-                                                             float* __restrict__ scores, int ld, IvfMulti mb) {
+                                                             float* __restrict__ scores, int ld, IvfMulti mb, IvfGroup grp) {
     {
         const long long y = blockIdx.y;
         q = mb_adv(q, y * mb.q);
@@ -2169,19 +2234,44 @@ __global__ __launch_bounds__(256) void ivf_coarse_mfma_kernel(const float* __res
     const int r = lane & 15, g = lane >> 4;
     {   // ||q||^2 in the reference's AVX2 order (cpu_baseline.cpp:95-114): 8 lanes per query
         const int row = tid >> 3, j = tid & 7;
+        // wide pipeline: the first block of every batch also writes the queries as bytes, their constant terms and the
+        // batch's "byte valued" verdict (what seed_qnorm_kernel does for the brute-force scans)
+        const bool prep = grp.w_q8 != nullptr && blockIdx.x == 0;
+        const int64_t qslot = (int64_t)blockIdx.y * kMaxBatch + row;
         float acc = 0.f;
+        int part = 0;
+        bool q_ok = true;
         if (row < B) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const float x = q[row * kDim + 8 * i + j];
                 acc = fmaf(x, x, acc);
+                if (prep) {
+                    const int xi = (int)x;
+                    q_ok = q_ok && ((float)xi == x) && xi >= 0 && xi <= 255;
+                    part += xi - 128;
+                    grp.w_q8[qslot * kDim + 8 * i + j] = (int8_t)(xi - 128);
+                }
             }
+        } else if (prep) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) grp.w_q8[qslot * kDim + 8 * i + j] = 0;  // padding queries
         }
         const int b8 = lane & ~7;
         float sum = __shfl(acc, b8);
 #pragma unroll
         for (int u = 1; u < 8; ++u) sum = sum + __shfl(acc, b8 + u);
         if (j == 0) qn_s[row] = row < B ? sum : 0.f;
+        if (prep) {
+            part += __shfl_xor(part, 1);
+            part += __shfl_xor(part, 2);
+            part += __shfl_xor(part, 4);
+            if (j == 0) {
+                grp.w_qnorm[qslot] = row < B ? sum : 0.f;
+                grp.w_qterm[qslot] = (int)sum - 256 * part - 4194304;
+            }
+            if (!q_ok) grp.w_invalid[blockIdx.y] = 1;
+        }
     }
     const int row0 = ((int)blockIdx.x * 4 + wave) * 16;  // centroid tile (the centroid array has kScanPadRows spare rows)
     f32x4 a[8];
@@ -2336,6 +2426,13 @@ __global__ __launch_bounds__(256) void ivf_pick_kernel(const float* __restrict__
     if (tid == 0) {
         grp.qoff[(int64_t)b * (kIvfMaxProbe + 1) + nprobe] = tot;
         if (grp.cand_count) atomicAdd(grp.cand_count, (unsigned long long)tot);
+    }
+    if (grp.w_cnt && tid < nprobe && sz > 0) {
+        // wide pipeline: this (query, probe) pair takes a slot in its list's table (one global atomic per pair; tens of
+        // thousands of pairs over a thousand zeroed counters)
+        const int c = s_probe[tid];
+        const int slot = atomicAdd(grp.w_cnt + c, 1);  // < w_q: a list is probed at most once per query
+        grp.w_lq[(int64_t)c * grp.w_q + slot] = (int)blockIdx.y * kMaxBatch + b;
     }
 }
 
@@ -2572,7 +2669,7 @@ hipError_t launch_ivf_coarse_pick(const float* q, int B, const float* cents, con
                                   int metric, float* scores, int ld, int32_t* probes, const IvfGroup& grp, hipStream_t s, int n_batches) {
     if (nprobe > 256 || nlist > kIvfFastNlist || ld < ((nlist + 63) & ~63)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(ivf_coarse_mfma_kernel, dim3((nlist + 63) / 64, n_batches), dim3(256), 0, s, q, B, cents, cnorm, nlist, metric,
-                       scores, ld, grp.mb);
+                       scores, ld, grp.mb, grp);
     if (nlist <= 1024) hipLaunchKernelGGL(ivf_pick_kernel<4>, dim3(B, n_batches), dim3(256), 0, s, scores, ld, nlist, nprobe, probes, grp);
     else if (nlist <= 2048) hipLaunchKernelGGL(ivf_pick_kernel<8>, dim3(B, n_batches), dim3(256), 0, s, scores, ld, nlist, nprobe, probes, grp);
     else hipLaunchKernelGGL(ivf_pick_kernel<16>, dim3(B, n_batches), dim3(256), 0, s, scores, ld, nlist, nprobe, probes, grp);
@@ -3946,8 +4043,6 @@ hipError_t launch_ivf_wide(const IvfWideParams& p, int num_cus, hipStream_t s) {
     if (p.nlist > kIvfFastNlist || p.nprobe > kIvfMaxProbe || p.k > 16) return hipErrorInvalidValue;
     const int n_sb = (p.n_batches + kIvfWideBatches - 1) / kIvfWideBatches;
     hipLaunchKernelGGL(ivf_tau_kernel, dim3((p.n_batches * kMaxBatch + 1) / 2), dim3(256), 0, s, p);
-    const int pairs = std::min(p.n_batches, kIvfWideBatches) * p.B * p.nprobe;
-    hipLaunchKernelGGL(ivf_count_wide_kernel, dim3((pairs + 255) / 256, n_sb), dim3(256), 0, s, p);
     hipLaunchKernelGGL(ivf_plan_wide_kernel, dim3(std::max(kPlanSplit, 32 / n_sb), n_sb), dim3(1024), 0, s, p);
     static bool attr_set[64] = {};
     int dev = 0;
