@@ -76,6 +76,15 @@ struct vs_index {
     // int8 data path: only when every base value is an integer in [0, 255]
     int8_t* d_vecs_u8 = nullptr;   // [n_rows][128] bytes (x - 128)
     int32_t* d_rterm = nullptr;    // [n_rows + 64] ||b||^2 - 256 * sum(b - 128)
+    // wide IVF scan: the byte rows once more, every list padded to a multiple of 32 rows ("padded rows") and stored as
+    // 16-row MFMA tiles of 2 KB, [half of the row][16-byte chunk][row][16 bytes] -- a wave's A-operand load is then 1 KB
+    // of consecutive bytes (from the row-major copy the same load touches 16 B in each of 64 places)
+    int8_t* d_vecs_t8 = nullptr;   // [n_padded + 64 rows]
+    int32_t* d_nrh_t = nullptr;    // [n_padded + 64] -(rterm >> 1) by padded row: the MFMA C operand
+    int32_t* d_rterm_t = nullptr;  // [n_padded + 64]
+    int32_t* d_r2o_t = nullptr;    // [n_padded + 64] padded row -> original id (-1: padding)
+    int32_t* d_tdelta = nullptr;   // [nlist] padded row - row, per list
+    int32_t* d_chunk_trow0 = nullptr;  // [n_chunks] first padded row of a chunk
     int32_t* d_invalid = nullptr;  // [kMaxMulti] batches the int8 scan had to skip
     int precision = 0;             // 0 = auto (int8 when possible), 1 = fp32, 2 = int8
 
@@ -165,7 +174,8 @@ struct vs_index {
         int32_t* lq = nullptr;      // [n_sb][nlist][kIvfWideQ]
         int32_t* zero = nullptr;    // one zeroed block per launch group: [4][nlist + 16] | slow [1024] | overflow (16) | list counters [1024][16]
         size_t zero_words = 0;
-        int32_t* units = nullptr;   // [4][n_units_max][4]
+        int32_t* units = nullptr;   // [n_sb_max][units_cap][4]
+        int units_cap = 0;
         float* tau = nullptr;       // [1024]
         float* qnorm = nullptr;     // [1024]
         int8_t* q8 = nullptr;       // [1024][128]
@@ -256,7 +266,7 @@ void free_all(vs_index* h) {
         if (L.s) (void)hipStreamDestroy(L.s);
     }
     if (h->fork) (void)hipEventDestroy(h->fork);
-    void* ptrs[] = {h->d_vecs, h->d_norm, h->d_vecs_u8, h->d_rterm, h->d_invalid, h->d_centroids, h->d_cnorm, h->d_offsets, h->d_r2o, h->d_q,
+    void* ptrs[] = {h->d_vecs, h->d_norm, h->d_vecs_u8, h->d_rterm, h->d_vecs_t8, h->d_nrh_t, h->d_rterm_t, h->d_r2o_t, h->d_tdelta, h->d_chunk_trow0, h->d_invalid, h->d_centroids, h->d_cnorm, h->d_offsets, h->d_r2o, h->d_q,
                     h->d_out_d, h->d_out_i,
                     h->d_flags, h->d_scores, h->d_probes, h->d_ipart_d, h->d_ipart_i, h->d_cand,
                     h->d_chunk_list, h->d_chunk_row0, h->d_chunk_rows, h->d_lcnt, h->d_lq, h->d_lbase, h->d_qoff,
@@ -459,7 +469,7 @@ int upload_vectors(vs_index* h, const float* host, int64_t rows) {
 
 // int8 copy of the base when it is exactly representable: bytes (x - 128) and the per-row term
 // ||b||^2 - 256 * sum(b - 128); dist = [||q||^2 - 256 sum(q-128) - 2*128^3] + rterm - 2 * sum((q-128)(b-128)).
-int build_u8_copy(vs_index* h, const float* host, int64_t rows) {
+int build_u8_copy(vs_index* h, const float* host, int64_t rows, std::vector<int8_t>* bytes_out = nullptr, std::vector<int32_t>* rterm_out = nullptr) {
     std::vector<int8_t> bytes(((size_t)rows + vs::kScanPadRows) * vs::kDim, 0);  // spare rows: tile DMAs are not clamped
     std::vector<int32_t> rterm((size_t)rows + 64, 0);
     for (int64_t i = 0; i < rows; ++i) {
@@ -480,6 +490,8 @@ int build_u8_copy(vs_index* h, const float* host, int64_t rows) {
     if ((rc = dev_alloc(&h->d_invalid, (size_t)kMaxMulti))) return rc;
     HIPCHK(hipMemcpy(h->d_vecs_u8, bytes.data(), bytes.size(), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->d_rterm, rterm.data(), rterm.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (bytes_out) bytes_out->swap(bytes);
+    if (rterm_out) rterm_out->swap(rterm);
     return VS_OK;
 }
 
@@ -961,7 +973,8 @@ int ensure_ivf_wide(vs_index* h) {
     W.zero_words = (size_t)n_sb_max * (h->nlist + 16) + nq + 64 + nq * kWideSub;
     if ((rc = dev_alloc(&W.lq, (size_t)n_sb_max * h->nlist * vs::kIvfWideQ))) return rc;
     if ((rc = dev_alloc(&W.zero, W.zero_words))) return rc;
-    if ((rc = dev_alloc(&W.units, (size_t)n_sb_max * std::max<int64_t>(h->n_units_max, 1) * 4))) return rc;
+    W.units_cap = (int)std::min<int64_t>(2 * h->n_units_max + 4096, 0x7fffffff / 16);
+    if ((rc = dev_alloc(&W.units, (size_t)n_sb_max * W.units_cap * 4))) return rc;
     if ((rc = dev_alloc(&W.tau, nq))) return rc;
     if ((rc = dev_alloc(&W.qnorm, nq))) return rc;
     if ((rc = dev_alloc(&W.q8, nq * vs::kDim))) return rc;
@@ -1014,12 +1027,21 @@ int ivf_group_wide_dev(vs_index* h, const float* q_dev, int nb, int B, int k, in
                                       reinterpret_cast<float*>(sl + h->mb_off_scores), (h->nlist + 63) & ~63, probes, grp, s, nb));
     stage_mark(h, 1, s);
     vs::IvfWideParams wp{};
+#ifdef VS_STAMPS
+    wp.dbg = g_dbg;
+    wp.diag = getenv("VSEARCH_DIAG") ? atoi(getenv("VSEARCH_DIAG")) : 0;
+#endif
     wp.vecs = h->d_vecs;
     wp.vnorm = h->d_norm;
     if (h->d_vecs_u8 && g_ivf_i8) {
         wp.vecs_u8 = h->d_vecs_u8;
         wp.rterm = h->d_rterm;
+        wp.vecs_t8 = h->d_vecs_t8;
+        wp.nrh_t = h->d_nrh_t;
+        wp.rterm_t = h->d_rterm_t;
     }
+    wp.tdelta = h->d_tdelta;  // (null without a tiled copy: padded rows = rows)
+    wp.chunk_trow0 = h->d_chunk_trow0 ? h->d_chunk_trow0 : h->d_chunk_row0;
     wp.offsets = h->d_offsets;
     wp.chunk_list = h->d_chunk_list;
     wp.chunk_row0 = h->d_chunk_row0;
@@ -1042,7 +1064,8 @@ int ivf_group_wide_dev(vs_index* h, const float* q_dev, int nb, int B, int k, in
     wp.lq = W.lq;
     wp.zero = z_plan;
     wp.units = W.units;
-    wp.units_sb_stride = std::max<int64_t>(h->n_units_max, 1) * 4;
+    wp.units_sb_stride = (long long)W.units_cap * 4;
+    wp.units_cap = W.units_cap;
     wp.tau = W.tau;
     wp.slow = z_slow;
     wp.sink.wbuf = W.wbuf;
@@ -1055,6 +1078,8 @@ int ivf_group_wide_dev(vs_index* h, const float* q_dev, int nb, int B, int k, in
     wp.sink.cap = kIvfWideSubCap;
     wp.sink.nsub = kWideSub;
     wp.sink.slow = z_slow;
+    wp.sink.xcd_subs = kWideSub / 8;
+    wp.sink.cnt_sub_stride = (int)nq;
     wp.out_d = out_d;
     wp.out_i = out_i;
     wp.id_map = h->d_r2o;
@@ -1074,7 +1099,8 @@ int ivf_group_wide_dev(vs_index* h, const float* q_dev, int nb, int B, int k, in
     m.q_group_out = B;
     m.q_group_in = vs::kMaxBatch;
     m.flat_len = z_cnt;
-    m.id_map = h->d_r2o;
+    m.flat_len_sub_stride = (int)nq;
+    m.id_map = h->d_r2o_t ? h->d_r2o_t : h->d_r2o;  // the scan's candidates are padded rows
     HIPCHK(vs::launch_merge_layout(m, kIvfWideSubCap, (int64_t)kWideSub * kIvfWideSubCap, s));
     HIPCHK(vs::launch_ivf_wide_slow(wp, s));
     stage_mark(h, 3, s);
@@ -1772,7 +1798,9 @@ static int ivf_create_impl(const float* vectors, int64_t n_rows, int dim, const 
     };
     if ((rc = upload_vectors(h, up, n_local))) return fail(rc);
     // exact int8 copy of the (reordered, local) rows when they are byte valued: the list scan then moves 4x fewer bytes
-    if (h->metric == VS_METRIC_L2 && n_local > 0 && (rc = build_u8_copy(h, up, n_local))) return fail(rc);
+    std::vector<int8_t> host_bytes;
+    std::vector<int32_t> host_rterm;
+    if (h->metric == VS_METRIC_L2 && n_local > 0 && (rc = build_u8_copy(h, up, n_local, &host_bytes, &host_rterm))) return fail(rc);
     if ((rc = dev_alloc(&h->d_centroids, ((size_t)nlist + vs::kScanPadRows) * dim))) return fail(rc);
     if (hipMemset(h->d_centroids + (size_t)nlist * dim, 0, (size_t)vs::kScanPadRows * dim * sizeof(float)) != hipSuccess) return fail(VS_ERR_DEVICE);
     if ((rc = dev_alloc(&h->d_cnorm, (size_t)nlist + 64))) return fail(rc);
@@ -1803,6 +1831,47 @@ static int ivf_create_impl(const float* vectors, int64_t n_rows, int dim, const 
         }
         h->n_chunks = (int)cl.size();
         h->max_list = mx;
+        if (h->n_chunks > 0 && h->d_vecs_u8) {
+            // the tiled, padded copy for the wide scan (see vs_index::d_vecs_t8)
+            std::vector<int32_t> toff((size_t)nlist + 1), tdelta((size_t)nlist), ctr0;
+            int64_t t = 0;
+            for (int c = 0; c < nlist; ++c) {
+                toff[c] = (int32_t)t;
+                tdelta[c] = (int32_t)t - loc_off[c];
+                t += ((int64_t)(loc_off[c + 1] - loc_off[c]) + 31) & ~31ll;
+            }
+            toff[nlist] = (int32_t)t;
+            if (t + 64 >= (1ll << 31)) {  // (padded rows are int32 like rows)
+                set_error("ivf: too many rows for one shard");
+                return fail(VS_ERR_UNSUPPORTED);
+            }
+            const size_t n_t = (size_t)t + 64;
+            std::vector<int8_t> tb(n_t * vs::kDim, 0);
+            std::vector<int32_t> nrh_t(n_t, 0), rterm_t(n_t, 0), r2o_t(n_t, -1);
+            for (int c = 0; c < nlist; ++c)
+                for (int32_t j = 0; j < loc_off[c + 1] - loc_off[c]; ++j) {
+                    const size_t R = (size_t)toff[c] + j, row = (size_t)loc_off[c] + j;
+                    const int8_t* src = &host_bytes[row * vs::kDim];
+                    int8_t* tile = &tb[(R >> 4) * 16 * vs::kDim + (R & 15) * 16];
+                    for (int ch = 0; ch < 8; ++ch) std::memcpy(tile + (ch >> 2) * 1024 + (ch & 3) * 256, src + 16 * ch, 16);
+                    rterm_t[R] = host_rterm[row];
+                    nrh_t[R] = -(host_rterm[row] >> 1);
+                    r2o_t[R] = loc_r2o[row];
+                }
+            for (size_t i = 0; i < cl.size(); ++i) ctr0.push_back(cr0[i] + tdelta[cl[i]]);
+            if ((rc = dev_alloc(&h->d_vecs_t8, tb.size())) || (rc = dev_alloc(&h->d_nrh_t, n_t)) || (rc = dev_alloc(&h->d_rterm_t, n_t)) ||
+                (rc = dev_alloc(&h->d_r2o_t, n_t)) || (rc = dev_alloc(&h->d_tdelta, tdelta.size())) || (rc = dev_alloc(&h->d_chunk_trow0, ctr0.size())))
+                return fail(rc);
+            if ((e = hipMemcpy(h->d_vecs_t8, tb.data(), tb.size(), hipMemcpyHostToDevice)) != hipSuccess ||
+                (e = hipMemcpy(h->d_nrh_t, nrh_t.data(), n_t * 4, hipMemcpyHostToDevice)) != hipSuccess ||
+                (e = hipMemcpy(h->d_rterm_t, rterm_t.data(), n_t * 4, hipMemcpyHostToDevice)) != hipSuccess ||
+                (e = hipMemcpy(h->d_r2o_t, r2o_t.data(), n_t * 4, hipMemcpyHostToDevice)) != hipSuccess ||
+                (e = hipMemcpy(h->d_tdelta, tdelta.data(), tdelta.size() * 4, hipMemcpyHostToDevice)) != hipSuccess ||
+                (e = hipMemcpy(h->d_chunk_trow0, ctr0.data(), ctr0.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) {
+                set_error(std::string("ivf tiled copy: ") + hipGetErrorString(e));
+                return fail(VS_ERR_DEVICE);
+            }
+        }
         if (h->n_chunks > 0) {
             if ((rc = dev_alloc(&h->d_chunk_list, cl.size()))) return fail(rc);
             if ((rc = dev_alloc(&h->d_chunk_row0, cl.size()))) return fail(rc);
@@ -2327,7 +2396,6 @@ __attribute__((visibility("default"))) int vs_debug_ivf_wide_stats(vs_index* h, 
     for (size_t i = 0; i < nq * kWideSub; ++i) maxsub = std::max<int64_t>(maxsub, cnt[i]);
     out[0] = ovf[0];
     out[1] = nslow;
-    out[2] = total;
     out[3] = maxw;
     out[4] = maxsub;
     out[5] = ninf;
@@ -2335,10 +2403,12 @@ __attribute__((visibility("default"))) int vs_debug_ivf_wide_stats(vs_index* h, 
     int64_t big = 0, maxq = 0;
     for (size_t i = 0; i < nq; ++i) {
         int64_t t = 0;
-        for (int g = 0; g < kWideSub; ++g) t += cnt[i * kWideSub + g];
+        for (int g = 0; g < kWideSub; ++g) t += cnt[(size_t)g * nq + i];
         big += t > 256;
         maxq = std::max(maxq, t);
+        total += t;
     }
+    out[2] = total;
     out[7] = big * 100000 + maxq;
     return VS_OK;
 }

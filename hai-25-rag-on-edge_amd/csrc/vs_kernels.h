@@ -108,6 +108,12 @@ struct CandSink {
     int cap;                 // per sub-list
     int nsub;
     int32_t* slow;           // optional [queries]: a query whose lists overflow is marked here instead of raising `overflow`
+    // XCD-local sub-lists (0 = off): sub-list = xcd * xcd_subs + hash % xcd_subs (nsub = 8 * xcd_subs) and the counters
+    // are sub-list major, cnt[sub * cnt_sub_stride + query]: every counter line and every list is then written by the
+    // workgroups of ONE XCD and stays in that XCD's L2 (lines appended to from several XCDs travel between the L2s
+    // on every atomic and every store)
+    int xcd_subs;
+    int cnt_sub_stride;
 };
 
 struct WideParams {
@@ -163,6 +169,7 @@ struct MergeParams {
     const int32_t* run_if;   // optional [1] with run_mode: 1 = run only if *run_if != 0, 2 = only if *run_if == 0 (the other
     int run_mode;            //   launch of the pair writes the outputs)
     const int32_t* flat_len; // optional [queries][G]: list (q, g) holds flat_len[q * G + g] <= kin UNSORTED candidates
+    int flat_len_sub_stride; // != 0: the lengths are list major instead, flat_len[g * flat_len_sub_stride + q]
 };
 hipError_t launch_merge(const MergeParams& p, hipStream_t s);  // scan-partial layout [G][nq_stride][kin]
 // general layout: entry (g, q, j) at g*stride_g + q*stride_q + j
@@ -302,6 +309,12 @@ struct IvfWideParams {
     const float* vnorm;       // [n_rows + 64]
     const int8_t* vecs_u8;    // optional exact int8 copy (x - 128) + row terms
     const int32_t* rterm;
+    // the scan's own copy: lists padded to multiples of 32 rows ("padded rows"), 16-row tiles [half][chunk][row][16 B]
+    const int8_t* vecs_t8;
+    const int32_t* nrh_t;     // [padded rows + 64] -(rterm >> 1): the MFMA C operand
+    const int32_t* rterm_t;
+    const int32_t* tdelta;    // [nlist] padded row - row (null: 0)
+    const int32_t* chunk_trow0;  // [n_chunks] first padded row of a chunk: the plan's records and the candidates are padded rows
     const int32_t* offsets;   // [nlist+1] local list offsets (lists not resident here are empty)
     const int32_t* chunk_list;
     const int32_t* chunk_row0;
@@ -316,16 +329,19 @@ struct IvfWideParams {
     const int32_t* invalid;   // [n_batches] (pre-set to 0) a query of the batch is not byte valued
     const int32_t* probes;    // batch b's [B][nprobe] at (char*)probes + b * probes_batch_bytes
     long long probes_batch_bytes;
-    int32_t* lq;              // [n_sb][nlist][kIvfWideQ] query slots (batch * 32 + q) probing each list
+    int32_t* lq;              // [n_sb][nlist][kIvfWideQ] query slots ((batch % 32) * 32 + q: local to the super-batch) probing each list
     int32_t* zero;            // [n_sb][nlist + 16] (pre-set to 0): word nlist = units in the super-batch's plan
-    int32_t* units;           // [n_sb][units_sb_stride / 4][4] unit records (first row, chunk end, list, queries probing it)
-    long long units_sb_stride;  // in int32
+    int32_t* units;           // [n_sb][units_cap][4] records (first row, chunk end, list, first slot | end slot << 16)
+    long long units_sb_stride;  // in int32 (= 4 units_cap)
+    int units_cap;            // records per super-batch the plan may hold (>= the index's units: the unsplit plan fits)
     float* tau;               // [n_batches][32] bounds
     int32_t* slow;            // [n_batches][32] (pre-set to 0): no bound could be had -> exact slow path
     CandSink sink;
     float* out_d;             // [n_batches][B][k]   (slow path writes here directly)
     int32_t* out_i;
-    const int32_t* id_map;    // reorder_to_original (local)
+    const int32_t* id_map;    // reorder_to_original (local), by row: the slow path's
+    int32_t* dbg;             // diagnostic builds (-DVS_STAMPS) only: per-workgroup time stamps, dbg[0..] see ivf_scan_wide_kernel
+    int diag;                 // diagnostic builds only: bit 0 no column blocks, bit 1 every unit = the wave's first, bit 2 no binning
 };
 hipError_t launch_query_prep(const SeedParams& p, hipStream_t s);  // ||q||^2, queries as bytes, constant terms, validity
 hipError_t launch_ivf_wide(const IvfWideParams& p, int num_cus, hipStream_t s);       // tau, plan, scan

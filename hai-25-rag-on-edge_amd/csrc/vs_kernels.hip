@@ -935,21 +935,40 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_kernel(const ScanParams 
 // ------------------------------------------------------------------------------------------------
 // A wave bins the candidates it has collected (its private buffer `wb`, `n` entries) into the per-query lists.  Called at
 // the very end of a streaming scan, outside the tile loop: the returning atomics cost nothing there.
-__device__ __forceinline__ void sink_bin_wave(const CandSink& p, int wb, int n, int lane) {
+struct SinkEntryAsIs {
+    __device__ __forceinline__ int4 operator()(const int4& c) const { return c; }
+};
+template <typename Fix = SinkEntryAsIs>
+__device__ __forceinline__ void sink_bin_wave(const CandSink& p, int wb, int n, int lane, const Fix fix = Fix(), int diag = 0) {
     if (n > p.wcap) {
         if (lane == 0) p.overflow[0] = 1;  // entries were dropped: the fallback kernels behind take over
         return;
     }
     if (n == 0) return;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the wave's own stores to the buffer are complete ...
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // ... and its loads below do not come from a stale cache line
+    // The wave reads back what it stored itself.  Its stores are complete after the wait; the lines were never read in
+    // this launch before (so no stale copy can sit in this CU's vector cache), and the loads below are agent-scope
+    // atomic loads anyway, which do not hit that cache.  (An acquire fence here invalidates the whole vector cache
+    // under the CU's other 15 waves: measured 11 us of a 45 us kernel.)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const int4* src = p.wbuf + (int64_t)wb * p.wcap;
     // (a hash: neighbouring buffers hold neighbouring units of one list, whose candidates belong to the same queries)
-    const int sub = (int)((((unsigned)wb * 2654435761u) >> 16) % (unsigned)p.nsub);
+    const unsigned hash = ((unsigned)wb * 2654435761u) >> 16;
+    int sub = (int)(hash % (unsigned)p.nsub);
+    if (p.xcd_subs) sub = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7) * p.xcd_subs + (int)(hash % (unsigned)p.xcd_subs);  // XCC_ID
     for (int e = lane; e < n; e += 64) {
-        const int4 c = src[e];
+        const unsigned long long* s64 = reinterpret_cast<const unsigned long long*>(src + e);
+        const unsigned long long lo = __hip_atomic_load(s64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long hi = __hip_atomic_load(s64 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int4 c = fix(make_int4((int)lo, (int)(lo >> 32), (int)hi, (int)(hi >> 32)));  // (query, distance bits, id, -)
         const int64_t lst = (int64_t)c.x * p.nsub + sub;
-        const int pos = atomicAdd(p.cnt + lst, 1);
+#ifdef VS_STAMPS
+        if (diag & 32) {
+            p.cand_d[lst * p.cap + (e & 63)] = __builtin_bit_cast(float, c.y);
+            continue;
+        }
+        if (diag & 64) continue;
+#endif
+        const int pos = atomicAdd(p.cnt + (p.xcd_subs ? (int64_t)sub * p.cnt_sub_stride + c.x : lst), 1);
         if (pos < p.cap) {
             p.cand_d[lst * p.cap + pos] = __builtin_bit_cast(float, c.y);
             p.cand_i[lst * p.cap + pos] = c.z;
@@ -1834,7 +1853,8 @@ __global__ __launch_bounds__(256) void merge_compact_kernel(const MergeParams p,
         // G unsorted candidate lists per query (streaming scans): list g holds flat_len[q_in * G + g] <= kin entries
         // (the lengths are fetched together: one after the other they would cost G cache round trips)
         __shared__ int s_len[64];
-        if (tid < p.G && tid < 64) s_len[tid] = min(p.flat_len[(int64_t)q_in * p.G + tid], p.kin);
+        if (tid < p.G && tid < 64)
+            s_len[tid] = min(p.flat_len[p.flat_len_sub_stride ? (int64_t)tid * p.flat_len_sub_stride + q_in : (int64_t)q_in * p.G + tid], p.kin);
         __syncthreads();
         int off = 0;
         for (int g = 0; g < p.G && g < 64; ++g) {
@@ -2432,7 +2452,7 @@ __global__ __launch_bounds__(256) void ivf_pick_kernel(const float* __restrict__
         // thousands of pairs over a thousand zeroed counters)
         const int c = s_probe[tid];
         const int slot = atomicAdd(grp.w_cnt + c, 1);  // < w_q: a list is probed at most once per query
-        grp.w_lq[(int64_t)c * grp.w_q + slot] = (int)blockIdx.y * kMaxBatch + b;
+        grp.w_lq[(int64_t)c * grp.w_q + slot] = ((int)blockIdx.y % kIvfWideBatches) * kMaxBatch + b;  // the query's slot in its super-batch
     }
 }
 
@@ -3652,43 +3672,63 @@ __global__ __launch_bounds__(256) void ivf_tau_kernel(const IvfWideParams p) {
     }
 }
 
-// Grouping of one super-batch (blockIdx.y): every (query, probe) pair takes a slot in its list's query table (one global
-// atomic per pair on the zeroed per-list counters: tens of thousands of pairs over a thousand counters, all in flight).
-__global__ __launch_bounds__(256) void ivf_count_wide_kernel(const IvfWideParams p) {
-    const int sb = blockIdx.y;
-    const int b0 = sb * kIvfWideBatches, b1 = min(p.n_batches, b0 + kIvfWideBatches);
-    const int per_batch = p.B * p.nprobe;
-    const int e = (int)blockIdx.x * 256 + (int)threadIdx.x;
-    if (e >= (b1 - b0) * per_batch) return;
-    const int bb = e / per_batch, rem = e - bb * per_batch;
-    const int qi = rem / p.nprobe, pp = rem - qi * p.nprobe;
-    const int batch = b0 + bb;
-    const int c = reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(p.probes) + (long long)batch * p.probes_batch_bytes)[qi * p.nprobe + pp];
-    if (c < 0) return;
-    if (p.offsets[c + 1] == p.offsets[c]) return;  // empty (or not resident) list
-    const int slot = atomicAdd(p.zero + (int64_t)sb * (p.nlist + 16) + c, 1);  // < kIvfWideQ: a list is probed at most once per query
-    p.lq[((int64_t)sb * p.nlist + c) * kIvfWideQ + slot] = batch * kMaxBatch + qi;
-}
-
-// Work plan of one super-batch (blockIdx.y), several workgroups each (see ivf_group_plan_kernel): the 32-row units of
-// every chunk whose list is probed, as self-contained records.
+// Work plan of one super-batch (blockIdx.y), several workgroups each (see ivf_group_plan_kernel): records of bounded cost.
+// A record is one kIvfWideUnit-row unit of a chunk whose list is probed, times one range of at most S of the slots of
+// the list's query table: (first row, chunk end, list, first slot | end slot << 16).  S = 256 (a record costs between 1
+// and 16 column blocks beside its rows; every further record of a unit reads the unit's rows again) unless the plan would
+// not fit `units_cap`, then the next power of two that does (1024 = no split always fits).
+constexpr int kIvfWideUnit = 32;  // rows per unit: two 16-row MFMA tiles
+constexpr int kIvfWideTiles = kIvfWideUnit / 16;
+constexpr int kIvfWideSplits = 3;  // S = 256 << i
 __global__ __launch_bounds__(1024) void ivf_plan_wide_kernel(const IvfWideParams p) {
     __shared__ int cnt_s[kIvfFastNlist];
     __shared__ int s_carry;
     __shared__ int s_wtot[16];
+    __shared__ int s_tot[16][kIvfWideSplits];
+    __shared__ int s_shift;
     const int tid = threadIdx.x;
     const int sb = blockIdx.y;
     int32_t* units = p.units + (int64_t)sb * p.units_sb_stride;
-    for (int c = tid; c < p.nlist; c += 1024) cnt_s[c] = p.zero[(int64_t)sb * (p.nlist + 16) + c];
+    for (int c = tid; c < p.nlist; c += 1024) cnt_s[c] = min(p.zero[(int64_t)sb * (p.nlist + 16) + c], kIvfWideQ);
     if (tid == 0) s_carry = 0;
     __syncthreads();
     const int pl = tid & 63, wv = tid >> 6;
     const int nsl = (int)gridDim.x;
     const int c0 = (int)((long long)p.n_chunks * blockIdx.x / nsl), c1 = (int)((long long)p.n_chunks * (blockIdx.x + 1) / nsl);
-    auto units_of = [&](int chunk) { return cnt_s[p.chunk_list[chunk]] > 0 ? (p.chunk_rows[chunk] + 31) >> 5 : 0; };
+    auto units_of = [&](int chunk) { return (p.chunk_rows[chunk] + kIvfWideUnit - 1) / kIvfWideUnit; };
+    {   // the split size (every workgroup works it out for itself: the same numbers, the same answer)
+        int tot[kIvfWideSplits];
+#pragma unroll
+        for (int i = 0; i < kIvfWideSplits; ++i) tot[i] = 0;
+        for (int chunk = tid; chunk < p.n_chunks; chunk += 1024) {
+            const int nq = cnt_s[p.chunk_list[chunk]];
+            const int nu = units_of(chunk);
+#pragma unroll
+            for (int i = 0; i < kIvfWideSplits; ++i) tot[i] += nu * ((nq + (256 << i) - 1) >> (8 + i));
+        }
+#pragma unroll
+        for (int i = 0; i < kIvfWideSplits; ++i) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) tot[i] += __shfl_xor(tot[i], o);
+            if (pl == 0) s_tot[wv][i] = tot[i];
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int sh = kIvfWideSplits - 1;
+            for (int i = kIvfWideSplits - 1; i >= 0; --i) {
+                long long t = 0;
+                for (int w = 0; w < 16; ++w) t += s_tot[w][i];
+                if (t <= p.units_cap) sh = i;
+            }
+            s_shift = 8 + sh;
+        }
+        __syncthreads();
+    }
+    const int shift = s_shift;
+    auto recs_of = [&](int chunk) { return units_of(chunk) * ((cnt_s[p.chunk_list[chunk]] + (1 << shift) - 1) >> shift); };
     {
         int pre = 0;
-        for (int chunk = tid; chunk < c0; chunk += 1024) pre += units_of(chunk);
+        for (int chunk = tid; chunk < c0; chunk += 1024) pre += recs_of(chunk);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) pre += __shfl_xor(pre, o);
         if (pl == 0) s_wtot[wv] = pre;
@@ -3702,8 +3742,8 @@ __global__ __launch_bounds__(1024) void ivf_plan_wide_kernel(const IvfWideParams
     }
     for (int base = c0; base < c1; base += 1024) {
         const int chunk = base + tid;
-        const int nu = chunk < c1 ? units_of(chunk) : 0;
-        int incl = nu;
+        const int nr = chunk < c1 ? recs_of(chunk) : 0;
+        int incl = nr;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const int t = __shfl_up(incl, o);
@@ -3717,13 +3757,17 @@ __global__ __launch_bounds__(1024) void ivf_plan_wide_kernel(const IvfWideParams
             if (w < wv) woff += t;
             tot += t;
         }
-        const int pos = s_carry + woff + incl - nu;
-        if (nu > 0) {
+        int pos = s_carry + woff + incl - nr;
+        if (nr > 0) {
             const int c = p.chunk_list[chunk];
-            const int r0 = p.chunk_row0[chunk];
+            const int r0 = p.chunk_trow0[chunk];  // padded rows
             const int r_end = r0 + p.chunk_rows[chunk];
-            const int nq = min(cnt_s[c], kIvfWideQ);
-            for (int i = 0; i < nu; ++i) reinterpret_cast<int4*>(units)[pos + i] = make_int4(r0 + 32 * i, r_end, c, nq);
+            const int nq = cnt_s[c];
+            const int nu = units_of(chunk);
+            // the records of one unit are neighbours: the waves that take them read the same rows at about the same time
+            for (int i = 0; i < nu; ++i)
+                for (int q0 = 0; q0 < nq; q0 += 1 << shift)
+                    reinterpret_cast<int4*>(units)[pos++] = make_int4(r0 + kIvfWideUnit * i, r_end, c, q0 | (min(nq, q0 + (1 << shift)) << 16));
         }
         __syncthreads();
         if (tid == 0) s_carry += tot;
@@ -3732,41 +3776,76 @@ __global__ __launch_bounds__(1024) void ivf_plan_wide_kernel(const IvfWideParams
     if (tid == 0 && (int)blockIdx.x == nsl - 1) p.zero[(int64_t)sb * (p.nlist + 16) + p.nlist] = s_carry;
 }
 
-// The list-major scan of one super-batch (blockIdx.y).  A workgroup stages the super-batch's queries once (as bytes: 32
-// KB) with their constant terms and thresholds; after that every wave works alone on 32-row units of the plan: the
-// unit's two 16-row tiles are the MFMA A operands, the queries probing the unit's list come 16 at a time as B operands
-// (gathered from the staged bytes through the list's slot table), and a distance under its query's bound goes to the
-// wave's candidate buffer (plain stores, positions from a ballot).  Rows that are not bytes, or a super-batch with a
-// non-byte query: the same on the fp32 rows with queries gathered from global memory.
+// The list-major scan of one super-batch (blockIdx.y).  A workgroup stages the super-batch's queries once (as bytes: 128
+// KB) with their constant terms and thresholds; after that every wave works alone on records of the plan: the unit's two
+// 16-row tiles are the MFMA A operands, the queries of the record's slot range come 16 at a time as B operands (gathered
+// from the staged bytes through the list's slot table), and a distance under its query's bound goes to the wave's
+// candidate buffer (plain stores, positions from a ballot).  Rows that are not bytes, or a super-batch with a non-byte
+// query: the same on the fp32 rows with queries gathered from global memory.
+//
+// Cost model of the int8 path (measured with -DVS_STAMPS: the loop took the same time on cache-hot rows): a wave64 VALU
+// instruction occupies its SIMD for 4 cycles and four waves share the SIMD, a column block is 4 MFMAs (64 cycles), so the
+// instructions around the MFMAs are what the kernel costs.  Hence:
+//  - d < ti  <=>  2 dot - rt > th (th = qt - ti); with rt = 2 rh + ro (ro = 0 or 1) and acc = dot - rh that is
+//    2 acc - ro > th, and for EVEN th simply acc > th / 2.  The bound is an upper bound of the k-th distance and only
+//    filters, so ti is raised by one where th would be odd: the test per value is one comparison with th >> 1, -rh
+//    enters as the MFMA's C operand straight from an array that holds it (`nrh`), and the hot path is the maximum of
+//    the 8 results against th >> 1.
+//  - the distance itself (qt + ro - 2 acc) is completed when the wave bins its candidates at the end;
+//  - rows past the chunk end are poisoned in the C operand (only a chunk's last unit pays), dead lanes of a column block
+//    point at a dummy query slot whose bound admits nothing;
+//  - a record's fields are scalars, its rows are read unclamped (the arrays are padded) at scalar base + one lane offset,
+//    the first four column blocks are straight-line code on slots fetched with the rows, and two register sets
+//    alternate instead of being copied.
 constexpr int kIvfWideThreads = 1024;  // 16 waves, one workgroup per CU (its LDS holds the super-batch's queries)
 constexpr int kIvfWideWaves = kIvfWideThreads / 64;
-constexpr int kIvfWideLds = kIvfWideQ * kDim + 4 * kIvfWideQ * 4;  // query bytes + four per-query words
+constexpr int kIvfWideSlots = kIvfWideQ + 1;  // + the dummy slot
+constexpr int kIvfWideLds = kIvfWideSlots * kDim + 4 * kIvfWideSlots * 4;  // query bytes + four per-query words
+constexpr int kIvfWideDeadThr = 0x3fffffff;
 __global__ __launch_bounds__(kIvfWideThreads) void ivf_scan_wide_kernel(const IvfWideParams p) {
     typedef int i32x4 __attribute__((ext_vector_type(4)));
-    typedef int i32x4_u __attribute__((ext_vector_type(4), aligned(4)));
     typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
     extern __shared__ __attribute__((aligned(16))) char wide_smem[];
-    int* q8_s = reinterpret_cast<int*>(wide_smem);                       // [slot][128 bytes]
-    int* qt_s = reinterpret_cast<int*>(wide_smem + kIvfWideQ * kDim);    // [slot]
-    int* thr_s = qt_s + kIvfWideQ;                                       // int8 path: 2 dot - rt > thr  <=>  d < tau
-    float* tau_s = reinterpret_cast<float*>(thr_s + kIvfWideQ);
-    float* qn_s = tau_s + kIvfWideQ;
+    int* q8_s = reinterpret_cast<int*>(wide_smem);                          // [slot][128 bytes]
+    int* qt_s = reinterpret_cast<int*>(wide_smem + kIvfWideSlots * kDim);   // [slot]
+    int* thh_s = qt_s + kIvfWideSlots;                                      // int8 path: acc > thh  <=>  d < ti (see above)
+    float* tau_s = reinterpret_cast<float*>(thh_s + kIvfWideSlots);
+    float* qn_s = tau_s + kIvfWideSlots;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, g = lane >> 4;
     const int sb = blockIdx.y;
     const int b0 = sb * kIvfWideBatches, b1 = min(p.n_batches, b0 + kIvfWideBatches);
+    const int qbase = b0 * kMaxBatch;
     const int nslots = (b1 - b0) * kMaxBatch;
-    const int n_units = p.zero[(int64_t)sb * (p.nlist + 16) + p.nlist];
     const int wb = ((int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x) * kIvfWideWaves + wave;  // this wave's candidate buffer
+    const int nw = (int)gridDim.x * kIvfWideWaves;
+    // records are dealt round-robin over the workgroups first: what a workgroup's 16 waves hold at any moment comes from
+    // 16 places of the plan (a popular list's records are expensive and sit together)
+    int u = wave * (int)gridDim.x + (int)blockIdx.x;
+    const int4* recs = reinterpret_cast<const int4*>(p.units + (int64_t)sb * p.units_sb_stride);
+    const int32_t* lq = p.lq + (int64_t)sb * p.nlist * kIvfWideQ;
+    int4* wbuf = p.sink.wbuf + (int64_t)wb * p.sink.wcap;
     int wbase = 0;
-    if ((int)blockIdx.x < n_units) {  // workgroup-uniform: wave 0's first unit exists
-    bool any_invalid = false;
-    for (int b = b0; b < b1; ++b) any_invalid = any_invalid || p.invalid[b] != 0;
-    const bool i8 = p.vecs_u8 && p.metric == 0 && !any_invalid;
-    for (int s = tid; s < nslots; s += kIvfWideThreads) {
-        const int qg = b0 * kMaxBatch + s;
-        const bool live = (s & 31) < p.B && p.slow[qg] == 0;  // a query without a bound goes through the slow path only
+    VS_STAMP(0);
+    // everything the staging needs is requested in one go (a kernel start is a chain of cold round trips otherwise)
+    const int n_units = p.zero[(int64_t)sb * (p.nlist + 16) + p.nlist];
+    int4 rv0 = recs[min(u, p.units_cap - 1)], rv1 = recs[min(u + nw, p.units_cap - 1)];
+    int inv = 0;
+    for (int b = b0; b < b1; ++b) inv |= p.invalid[b];
+    constexpr int PER = kIvfWideQ * 8 / kIvfWideThreads;
+    int4 v[PER];
+    {
+        const int4* src = reinterpret_cast<const int4*>(p.q8 + (int64_t)qbase * kDim);
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int i = tid + j * kIvfWideThreads;
+            v[j] = i < nslots * 8 ? src[i] : make_int4(0, 0, 0, 0);
+        }
+    }
+    for (int s = tid; s < kIvfWideSlots; s += kIvfWideThreads) {
+        const int qg = qbase + min(s, nslots - 1);
+        const bool live = s < nslots && (s & 31) < p.B && p.slow[qg] == 0;  // a query without a bound goes through the slow path only
         const float t0 = live ? p.tau[qg] : -VS_INF;
         tau_s[s] = t0;
         qn_s[s] = p.qnorm[qg];
@@ -3774,162 +3853,197 @@ __global__ __launch_bounds__(kIvfWideThreads) void ivf_scan_wide_kernel(const Iv
         qt_s[s] = qt;
         // d < tau for integer d  <=>  d < ceil(tau)  (distances are below 2^24: any bound from 2^26 on admits everything)
         const int ti = (int)ceilf(fminf(fmaxf(t0, -67108864.f), 67108864.f));
-        thr_s[s] = live ? qt - ti : 0x7fffffff;
+        thh_s[s] = live ? (qt - ti) >> 1 : kIvfWideDeadThr;
     }
-    if (i8) {
-        const int4* src = reinterpret_cast<const int4*>(p.q8 + (int64_t)b0 * kMaxBatch * kDim);
-        for (int i = tid; i < nslots * 8; i += kIvfWideThreads) reinterpret_cast<int4*>(q8_s)[i] = src[i];
-    }
-    __syncthreads();
-    const int4* recs = reinterpret_cast<const int4*>(p.units + (int64_t)sb * p.units_sb_stride);
-    const int32_t* lq = p.lq + (int64_t)sb * p.nlist * kIvfWideQ;
-    int4* wbuf = p.sink.wbuf + (int64_t)wb * p.sink.wcap;
-    const int nw = (int)gridDim.x * kIvfWideWaves;
-    // units are dealt so that the waves of a workgroup take neighbouring units (neighbouring rows) at any moment
-    int u = wave * (int)gridDim.x + (int)blockIdx.x;
-    if (i8) {
-        // software pipeline: the next unit's rows are requested before this unit is scored (a wave has a handful of units:
-        // one at a time it would pay the cache latency of its rows per unit)
-        constexpr int PF = 4;  // column blocks whose query slots are fetched together with the unit's rows
-        auto load_unit = [&](const int4& rc, i32x4 (&a0)[2], i32x4 (&a1)[2], i32x4 (&rt)[2], int (&qgp)[PF]) __attribute__((always_inline)) {
-            const int ur0 = rc.x, ur_end = rc.y;
+    // 16-byte segment s of slot ql sits at segment s ^ (ql & 7) of the slot's 128 bytes: the B-operand gather below reads
+    // the same segment of 16 arbitrary slots at once, which unswizzled is a 16-way bank conflict
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int row = max(min(ur0 + 16 * t + r, ur_end - 1), 0);
-                a0[t] = *reinterpret_cast<const i32x4*>(p.vecs_u8 + (int64_t)row * kDim + 16 * g);
-                a1[t] = *reinterpret_cast<const i32x4*>(p.vecs_u8 + (int64_t)row * kDim + 64 + 16 * g);
-                rt[t] = *reinterpret_cast<const i32x4_u*>(p.rterm + ur0 + 16 * t + 4 * g);  // past the chunk: readable, never used
+    for (int j = 0; j < PER; ++j) {
+        const int i = tid + j * kIvfWideThreads;
+        reinterpret_cast<int4*>(q8_s)[i ^ ((i >> 3) & 7)] = v[j];
+    }
+    if (tid < 8) reinterpret_cast<int4*>(q8_s)[kIvfWideQ * 8 + tid] = make_int4(0, 0, 0, 0);
+    const bool i8 = p.vecs_t8 && p.metric == 0 && inv == 0;
+    if (u >= n_units) rv0 = make_int4(0, 0, 0, 0);
+    if (u + nw >= n_units) rv1 = make_int4(0, 0, 0, 0);
+    if ((int)blockIdx.x >= n_units) return;  // workgroup-uniform: not even wave 0 has a record (nothing to bin either)
+
+    struct Rec {
+        int r0, r_end, c, q0, nq;
+    };
+    auto unpack = [&](const int4& rv) __attribute__((always_inline)) {
+        Rec rc;
+        rc.r0 = __builtin_amdgcn_readfirstlane(rv.x);
+        rc.r_end = __builtin_amdgcn_readfirstlane(rv.y);
+        rc.c = __builtin_amdgcn_readfirstlane(rv.z);
+        const int w = __builtin_amdgcn_readfirstlane(rv.w);
+        rc.q0 = w & 0xffff;
+        rc.nq = (w >> 16) - rc.q0;
+#ifdef VS_STAMPS
+        if (p.diag & 1) rc.nq = 0;
+#endif
+        return rc;
+    };
+    constexpr int PF = 4;  // column blocks whose query slots are fetched together with the unit's rows
+    constexpr int NT = kIvfWideTiles;
+    const unsigned loff = (unsigned)(16 * lane);  // the lane's bytes inside one half of a tile: a load is 1 KB in one piece
+    auto issue = [&](const Rec& rc, i32x4 (&a0)[NT], i32x4 (&a1)[NT], i32x4 (&nr)[NT], int (&qlp)[PF]) __attribute__((always_inline)) {
+        const int8_t* rows = p.vecs_t8 + (int64_t)rc.r0 * kDim;  // r0 is a multiple of 32 (rows past the chunk end: poisoned below)
+        const int32_t* nrp = p.nrh_t + rc.r0;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            a0[t] = *reinterpret_cast<const i32x4*>(rows + loff + t * 16 * kDim);
+            a1[t] = *reinterpret_cast<const i32x4*>(rows + loff + t * 16 * kDim + 1024);
+            nr[t] = *reinterpret_cast<const i32x4*>(nrp + 4 * g + 16 * t);
+        }
+        const int32_t* lqn = lq + (int64_t)rc.c * kIvfWideQ + rc.q0;
+        // (raw table entries, whatever the record's slot range: a row of the table has room for them, and selecting here
+        // would make the compiler wait for the loads right away)
+#pragma unroll
+        for (int i = 0; i < PF; ++i) qlp[i] = lqn[16 * i + r];
+    };
+    if (i8) {
+        i32x4 A0[NT], A1[NT], AN[NT], B0[NT], B1[NT], BN[NT];
+        int AQ[PF], BQ[PF];
+        Rec ra = unpack(rv0), rb;
+        issue(ra, A0, A1, AN, AQ);  // the first record's rows travel while the queries are stored
+        __syncthreads();
+        VS_STAMP(1);
+        int4 rvn = rv1;
+        auto compute = [&](const Rec& rc, const i32x4 (&a0)[NT], const i32x4 (&a1)[NT], i32x4 (&nr)[NT], const int (&qlc)[PF]) __attribute__((always_inline)) {
+            if (rc.r0 + kIvfWideUnit > rc.r_end) {  // wave-uniform, a chunk's last unit: rows past its end can never pass
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (rc.r0 + 16 * t + 4 * g + j >= rc.r_end) nr[t][j] = -(1 << 28);
             }
-            const int32_t* lqn = lq + (int64_t)rc.z * kIvfWideQ;
+            auto block = [&](const int ql) __attribute__((always_inline)) {
+                const int o0 = ql * 32 + 4 * (g ^ (ql & 7));
+                const i32x4 bq0 = *reinterpret_cast<const i32x4*>(q8_s + o0);
+                const i32x4 bq1 = *reinterpret_cast<const i32x4*>(q8_s + (o0 ^ 16));
+                const int thh = thh_s[ql];
+                i32x4 acc[NT];
 #pragma unroll
-            for (int i = 0; i < PF; ++i) qgp[i] = 16 * i + r < rc.w ? lqn[16 * i + r] : b0 * kMaxBatch;
-        };
-        int4 rec = u < n_units ? recs[u] : make_int4(0, 0, 0, 0);
-        int4 rec_n = u + nw < n_units ? recs[u + nw] : make_int4(0, 0, 0, 0);
-        i32x4 a0[2], a1[2], rt[2];
-        int qgc[PF];
-        if (u < n_units) load_unit(rec, a0, a1, rt, qgc);
-        for (; u < n_units; u += nw) {
-            const int r0 = __builtin_amdgcn_readfirstlane(rec.x);
-            const int r_end = __builtin_amdgcn_readfirstlane(rec.y);
-            const int c = __builtin_amdgcn_readfirstlane(rec.z);
-            const int nq = __builtin_amdgcn_readfirstlane(rec.w);
-            const int4 rec_nn = u + 2 * nw < n_units ? recs[u + 2 * nw] : make_int4(0, 0, 0, 0);
-            i32x4 b0n[2], b1n[2], rtn[2];
-            int qgn[PF];
-            load_unit(rec_n, b0n, b1n, rtn, qgn);  // (a zero record past the end reads row 0 and no slots: harmless)
-            const int32_t* lqc = lq + (int64_t)c * kIvfWideQ;
-            i32x4 nrh[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) nrh[t] = -(rt[t] >> 1);
-            for (int cb = 0; cb < nq; cb += 16) {
-                const int sq = cb + r;
-                const bool live = sq < nq;
-                int qg;
-                if (cb < 16 * PF) {  // wave-uniform: prefetched slots (static indexing)
-                    qg = qgc[0];
-#pragma unroll
-                    for (int i = 1; i < PF; ++i) qg = cb == 16 * i ? qgc[i] : qg;
-                } else {
-                    qg = live ? lqc[sq] : b0 * kMaxBatch;
-                }
-                const int ql = qg - b0 * kMaxBatch;
-                const i32x4 bq0 = *reinterpret_cast<const i32x4*>(q8_s + ql * 32 + 4 * g);
-                const i32x4 bq1 = *reinterpret_cast<const i32x4*>(q8_s + ql * 32 + 16 + 4 * g);
-                const int th = live ? thr_s[ql] : 0x7fffffff;
-                // d < tau  <=>  2 dot - rt > thr; with rt = 2 rh + ro and thr lowered to even that is dot - rh > thr >> 1:
-                // -rh is the C operand of the first MFMA and the hot path only takes the maximum of the 8 results (a block
-                // that passes is tested exactly below) -- see scan_i8w_kernel
-                i32x4 acc[2];
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0[t], bq0, nrh[t], 0, 0, 0);
+                for (int t = 0; t < NT; ++t) {
+                    acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0[t], bq0, nr[t], 0, 0, 0);
                     acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1[t], bq1, acc[t], 0, 0, 0);
                 }
-                const int emax = max(max(max(acc[0][0], acc[0][1]), max(acc[0][2], acc[0][3])),
-                                     max(max(acc[1][0], acc[1][1]), max(acc[1][2], acc[1][3])));
-                if (__ballot(emax > (th >> 1))) {  // rare
-                    const int qt = qt_s[ql];
+                int emax = max(max(acc[0][0], acc[0][1]), max(acc[0][2], acc[0][3]));
 #pragma unroll
-                    for (int t = 0; t < 2; ++t)
+                for (int t = 1; t < NT; ++t) emax = max(max(emax, acc[t][0]), max(max(acc[t][1], acc[t][2]), acc[t][3]));
+#ifdef VS_STAMPS
+                if ((p.diag & 8) && emax != 0x12345678) return;
+#endif
+                if (__ballot(emax > thh)) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            const int row = r0 + 16 * t + 4 * g + j;
-                            const int dot = acc[t][j] - nrh[t][j];  // = (x - 128) . (q - 128)
-                            const bool pass = live && 2 * dot - rt[t][j] > th && row < r_end;
+                            const bool pass = acc[t][j] > thh;
                             const unsigned long long mask = __ballot(pass);
                             if (mask) {
                                 const int pos = wbase + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
-                                if (pass && pos < p.sink.wcap)
-                                    wbuf[pos] = make_int4(qg, __builtin_bit_cast(int, (float)(qt + rt[t][j] - 2 * dot)), row, 0);
+                                // (slot, acc, row of the lane group's first value, lane group): sink_bin_wave's hook below
+                                // completes row and distance (no per-value lane constants here: they would be spilled)
+                                if (pass && pos < p.sink.wcap) wbuf[pos] = make_int4(ql, acc[t][j], rc.r0 + 16 * t + j, g);
                                 wbase += __popcll(mask);
                             }
                         }
                 }
-            }
+            };
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                a0[t] = b0n[t];
-                a1[t] = b1n[t];
-                rt[t] = rtn[t];
+            for (int i = 0; i < PF; ++i)
+                if (16 * i < rc.nq) block(16 * i + r < rc.nq ? qlc[i] : kIvfWideQ);  // wave-uniform
+            if (rc.nq > 16 * PF) {  // only when the plan had to use a wider split
+                const int32_t* lqc = lq + (int64_t)rc.c * kIvfWideQ + rc.q0;
+                for (int cb = 16 * PF; cb < rc.nq; cb += 16) block(cb + r < rc.nq ? lqc[cb + r] : kIvfWideQ);
             }
-#pragma unroll
-            for (int i = 0; i < PF; ++i) qgc[i] = qgn[i];
-            rec = rec_n;
-            rec_n = rec_nn;
+        };
+        auto next_record = [&](int idx) __attribute__((always_inline)) {
+#ifdef VS_STAMPS
+            if (p.diag & 2) idx = wave * (int)gridDim.x + (int)blockIdx.x;
+#endif
+            return idx < n_units ? recs[idx] : make_int4(0, 0, 0, 0);  // (a zero record reads rows 0.. and no slots: harmless)
+        };
+        for (;;) {
+            rb = unpack(rvn);
+            rvn = next_record(u + 2 * nw);
+            issue(rb, B0, B1, BN, BQ);
+            compute(ra, A0, A1, AN, AQ);
+            u += nw;
+            if (u >= n_units) break;
+            ra = unpack(rvn);
+            rvn = next_record(u + 2 * nw);
+            issue(ra, A0, A1, AN, AQ);
+            compute(rb, B0, B1, BN, BQ);
+            u += nw;
+            if (u >= n_units) break;
         }
-    } else {
-    int4 rec = u < n_units ? recs[u] : make_int4(0, 0, 0, 0);
+        VS_STAMP(2);
+#ifdef VS_STAMPS
+        if (p.diag & 4) return;
+#endif
+        // the wave's candidates go to the per-query lists here (no binning launch); an entry's distance is qt + ro - 2 acc
+        sink_bin_wave(p.sink, wb, wbase, lane, [&](const int4& c) {
+            const int row = c.z + 4 * c.w;
+            const int d = qt_s[c.x] + (p.rterm_t[row] & 1) - 2 * c.y;
+            return make_int4(qbase + c.x, __builtin_bit_cast(int, (float)d), row, 0);
+        }
+#ifdef VS_STAMPS
+        , p.diag
+#endif
+        );
+        VS_STAMP(3);
+        return;
+    }
+    __syncthreads();
+    int4 rec = rv0;
     for (; u < n_units; u += nw) {
-        const int r0 = __builtin_amdgcn_readfirstlane(rec.x);
-        const int r_end = __builtin_amdgcn_readfirstlane(rec.y);
-        const int c = __builtin_amdgcn_readfirstlane(rec.z);
-        const int nq = __builtin_amdgcn_readfirstlane(rec.w);
-        if (u + nw < n_units) rec = recs[u + nw];  // the next unit's record, in flight during this unit
-        const int32_t* lqc = lq + (int64_t)c * kIvfWideQ;
-        {
+        const Rec rc = unpack(rec);
+        const int td = p.tdelta ? p.tdelta[rc.c] : 0;  // the record is in padded rows, so are the candidates
+        const int r0 = rc.r0 - td, r_end = rc.r_end - td, nq = rc.nq;
+        if (u + nw < n_units) rec = recs[u + nw];  // the next record, in flight during this one
+        const int32_t* lqc = lq + (int64_t)rc.c * kIvfWideQ + rc.q0;
 #pragma unroll 1
-            for (int t = 0; t < 2; ++t) {
-                if (r0 + 16 * t >= r_end) break;  // wave-uniform
-                const int row = min(r0 + 16 * t + r, r_end - 1);
-                f32x4 a[8];
+        for (int t = 0; t < kIvfWideTiles; ++t) {
+            if (r0 + 16 * t >= r_end) break;  // wave-uniform
+            const int row = min(r0 + 16 * t + r, r_end - 1);
+            f32x4 a[8];
 #pragma unroll
-                for (int c8 = 0; c8 < 8; ++c8) a[c8] = *reinterpret_cast<const f32x4*>(p.vecs + (int64_t)row * kDim + 16 * c8 + 4 * g);
-                const f32x4 bn = *reinterpret_cast<const f32x4_u*>(p.vnorm + r0 + 16 * t + 4 * g);
-                for (int cb = 0; cb < nq; cb += 16) {
-                    const int sq = cb + r;
-                    const bool live = sq < nq;
-                    const int qg = live ? lqc[sq] : b0 * kMaxBatch;
-                    const int ql = qg - b0 * kMaxBatch;
-                    const float* qsrc = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.q) + (long long)(qg >> 5) * p.q_batch_bytes) + (qg & 31) * kDim;
-                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int c8 = 0; c8 < 8; ++c8) a[c8] = *reinterpret_cast<const f32x4*>(p.vecs + (int64_t)row * kDim + 16 * c8 + 4 * g);
+            const f32x4 bn = *reinterpret_cast<const f32x4_u*>(p.vnorm + r0 + 16 * t + 4 * g);
+            for (int cb = 0; cb < nq; cb += 16) {
+                const int sq = cb + r;
+                const bool live = sq < nq;
+                const int ql = live ? lqc[sq] : 0;
+                const int qg = qbase + ql;
+                const float* qsrc = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.q) + (long long)(qg >> 5) * p.q_batch_bytes) + (qg & 31) * kDim;
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int c8 = 0; c8 < 8; ++c8) {
-                        const f32x4 qf = *reinterpret_cast<const f32x4*>(qsrc + 16 * c8 + 4 * g);
+                for (int c8 = 0; c8 < 8; ++c8) {
+                    const f32x4 qf = *reinterpret_cast<const f32x4*>(qsrc + 16 * c8 + 4 * g);
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c8][i], qf[i], acc, 0, 0, 0);
-                    }
-                    const float qn = qn_s[ql];
-                    const float tq = live ? tau_s[ql] : -VS_INF;
+                    for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c8][i], qf[i], acc, 0, 0, 0);
+                }
+                const float qn = qn_s[ql];
+                const float tq = live ? tau_s[ql] : -VS_INF;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float d = p.metric ? -acc[j] : fmaf(-2.0f, acc[j], qn + bn[j]);
-                        const int rowj = r0 + 16 * t + 4 * g + j;
-                        const bool pass = d < tq && rowj < r_end;
-                        const unsigned long long mask = __ballot(pass);
-                        if (mask) {
-                            const int pos = wbase + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
-                            if (pass && pos < p.sink.wcap) wbuf[pos] = make_int4(qg, __builtin_bit_cast(int, d), rowj, 0);
-                            wbase += __popcll(mask);
-                        }
+                for (int j = 0; j < 4; ++j) {
+                    const float d = p.metric ? -acc[j] : fmaf(-2.0f, acc[j], qn + bn[j]);
+                    const int rowj = r0 + 16 * t + 4 * g + j;
+                    const bool pass = d < tq && rowj < r_end;
+                    const unsigned long long mask = __ballot(pass);
+                    if (mask) {
+                        const int pos = wbase + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+                        if (pass && pos < p.sink.wcap) wbuf[pos] = make_int4(qg, __builtin_bit_cast(int, d), rowj + td, 0);
+                        wbase += __popcll(mask);
                     }
                 }
             }
         }
     }
-    }
-    }
-    sink_bin_wave(p.sink, wb, wbase, lane);  // the wave's candidates go to the per-query lists here: no binning launch
+    sink_bin_wave(p.sink, wb, wbase, lane);
 }
 
 // Exact slow path, one workgroup per query that has no usable bound (or every query when a candidate buffer overflowed:
