@@ -172,7 +172,7 @@ struct vs_index {
     // bounds, prepared queries, candidate sink
     struct IvfWide {
         int32_t* lq = nullptr;      // [n_sb][nlist][kIvfWideQ]
-        int32_t* zero = nullptr;    // one zeroed block per launch group: [4][nlist + 16] | slow [1024] | overflow (16) | list counters [1024][16]
+        int32_t* zero = nullptr;    // one zeroed block per launch group: plan words (pair counters, record count) | slow [1024] | overflow (16) | list counters [16][1024]
         size_t zero_words = 0;
         int32_t* units = nullptr;   // [n_sb_max][units_cap][4]
         int units_cap = 0;
@@ -970,7 +970,7 @@ int ensure_ivf_wide(vs_index* h) {
     const int n_sb_max = (kMaxMulti + vs::kIvfWideBatches - 1) / vs::kIvfWideBatches;
     W.n_waves = 0;
     for (int n = 1; n <= n_sb_max; ++n) W.n_waves = std::max(W.n_waves, vs::ivf_wide_waves(h->num_cus, n));
-    W.zero_words = (size_t)n_sb_max * (h->nlist + 16) + nq + 64 + nq * kWideSub;
+    W.zero_words = (size_t)n_sb_max * vs::ivf_wide_plan_words(h->nlist) + nq + 64 + nq * kWideSub;
     if ((rc = dev_alloc(&W.lq, (size_t)n_sb_max * h->nlist * vs::kIvfWideQ))) return rc;
     if ((rc = dev_alloc(&W.zero, W.zero_words))) return rc;
     W.units_cap = (int)std::min<int64_t>(2 * h->n_units_max + 4096, 0x7fffffff / 16);
@@ -995,9 +995,9 @@ int ivf_group_wide_dev(vs_index* h, const float* q_dev, int nb, int B, int k, in
     if ((rc = ensure_ivf_wide(h))) return rc;
     vs_index::IvfWide& W = h->wide;
     const size_t nq = (size_t)kMaxMulti * 32;
-    int32_t* const z_plan = W.zero;                                   // [n_sb_max][nlist + 16]
+    int32_t* const z_plan = W.zero;                                   // [n_sb_max][ivf_wide_plan_words]
     const int n_sb_max = (kMaxMulti + vs::kIvfWideBatches - 1) / vs::kIvfWideBatches;
-    int32_t* const z_slow = z_plan + (size_t)n_sb_max * (h->nlist + 16);  // [1024]
+    int32_t* const z_slow = z_plan + (size_t)n_sb_max * vs::ivf_wide_plan_words(h->nlist);  // [1024]
     int32_t* const z_ovf = z_slow + nq;                               // [16]: word 0 = overflow
     int32_t* const invalid = z_ovf + 16;                              // [32] batches with a query that is not byte valued
     int32_t* const z_cnt = z_ovf + 64;                                // [1024][16]
@@ -1011,11 +1011,11 @@ int ivf_group_wide_dev(vs_index* h, const float* q_dev, int nb, int B, int k, in
     stage_mark(h, 0, s);
     vs::IvfGroup grp{};
     grp.offsets = h->d_offsets;
-    grp.lcnt = z_plan;  // non-null: the pick kernel also writes the window offsets and adds up the candidate count
+    grp.lcnt = z_plan;
     grp.qoff = reinterpret_cast<int32_t*>(sl + h->mb_off_qoff);
-    grp.cand_count = h->d_cand;
     grp.mb = mb;
     // the coarse kernel also prepares the queries for the int8 paths, the pick kernel also fills the lists' slot tables
+    // (the candidate statistic is added up by the plan kernel: one atomic per launch instead of one per query)
     grp.w_qnorm = W.qnorm;
     grp.w_q8 = W.q8;
     grp.w_qterm = W.qterm;
@@ -1023,6 +1023,9 @@ int ivf_group_wide_dev(vs_index* h, const float* q_dev, int nb, int B, int k, in
     grp.w_cnt = z_plan;
     grp.w_lq = W.lq;
     grp.w_q = vs::kIvfWideQ;
+#ifdef VS_STAMPS
+    grp.dbg = g_dbg ? g_dbg + 4096 * 16 : nullptr;
+#endif
     HIPCHK(vs::launch_ivf_coarse_pick(q_dev, B, h->d_centroids, h->d_cnorm, h->nlist, nprobe, h->metric,
                                       reinterpret_cast<float*>(sl + h->mb_off_scores), (h->nlist + 63) & ~63, probes, grp, s, nb));
     stage_mark(h, 1, s);
@@ -1063,6 +1066,7 @@ int ivf_group_wide_dev(vs_index* h, const float* q_dev, int nb, int B, int k, in
     wp.probes_batch_bytes = mb.slab;
     wp.lq = W.lq;
     wp.zero = z_plan;
+    wp.cand_count = h->d_cand;
     wp.units = W.units;
     wp.units_sb_stride = (long long)W.units_cap * 4;
     wp.units_cap = W.units_cap;
@@ -2383,7 +2387,7 @@ __attribute__((visibility("default"))) int vs_debug_ivf_wide_stats(vs_index* h, 
     HIPCHK(hipMemcpy(z.data(), h->wide.zero, z.size() * 4, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(wc.data(), h->wide.wcount, wc.size() * 4, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(tau.data(), h->wide.tau, nq * 4, hipMemcpyDeviceToHost));
-    const int32_t* slow = z.data() + (size_t)n_sb_max * (h->nlist + 16);
+    const int32_t* slow = z.data() + (size_t)n_sb_max * vs::ivf_wide_plan_words(h->nlist);
     const int32_t* ovf = slow + nq;
     const int32_t* cnt = ovf + 64;
     int64_t nslow = 0, total = 0, maxw = 0, maxsub = 0, ninf = 0;
@@ -2399,7 +2403,7 @@ __attribute__((visibility("default"))) int vs_debug_ivf_wide_stats(vs_index* h, 
     out[3] = maxw;
     out[4] = maxsub;
     out[5] = ninf;
-    out[6] = z[h->nlist];  // units of super-batch 0
+    out[6] = z[(size_t)h->nlist * vs::kIvfWideCntStride];  // records of super-batch 0
     int64_t big = 0, maxq = 0;
     for (size_t i = 0; i < nq; ++i) {
         int64_t t = 0;

@@ -232,6 +232,7 @@ struct IvfGroup {
     int32_t* w_cnt;                  // [nlist] (pre-set to 0) queries of the GROUP probing each list
     int32_t* w_lq;                   // [nlist][w_q] their slots (batch * 32 + q)
     int w_q;
+    int32_t* dbg;             // diagnostic builds (-DVS_STAMPS) only: time stamps of the pick kernel
 };
 
 // Coarse stage: Q x C^T + L2 epilogue on MFMA into scores [n_batches][32][ld] (ld >= nlist rounded up to 64; batch y's
@@ -304,6 +305,8 @@ hipError_t launch_ivf_select(const IvfSelectParams& p, int B, hipStream_t s, int
 constexpr int kIvfWideBatches = 32;  // = a whole launch group: every resident list is read once per 1024 queries
 constexpr int kIvfWideQ = kIvfWideBatches * kMaxBatch;  // query slots per super-batch
 constexpr int kIvfTauRows = 256;                         // rows of the nearest list that seed a query's bound
+constexpr int kIvfWideCntStride = 32;
+constexpr long long ivf_wide_plan_words(int nlist) { return (long long)nlist * kIvfWideCntStride + 16; }
 struct IvfWideParams {
     const float* vecs;        // [n_rows (+64)][128] cluster-reordered
     const float* vnorm;       // [n_rows + 64]
@@ -330,7 +333,10 @@ struct IvfWideParams {
     const int32_t* probes;    // batch b's [B][nprobe] at (char*)probes + b * probes_batch_bytes
     long long probes_batch_bytes;
     int32_t* lq;              // [n_sb][nlist][kIvfWideQ] query slots ((batch % 32) * 32 + q: local to the super-batch) probing each list
-    int32_t* zero;            // [n_sb][nlist + 16] (pre-set to 0): word nlist = units in the super-batch's plan
+    int32_t* zero;            // [n_sb][ivf_wide_plan_words(nlist)] (pre-set to 0): list c's pair counter at word c * kIvfWideCntStride
+                              //   (a 128-byte line each: the pick kernel's atomics come from all XCDs), the super-batch's record
+                              //   count at word nlist * kIvfWideCntStride
+    unsigned long long* cand_count;  // optional: += rows the probed lists hold per (query, probe) pair
     int32_t* units;           // [n_sb][units_cap][4] records (first row, chunk end, list, first slot | end slot << 16)
     long long units_sb_stride;  // in int32 (= 4 units_cap)
     int units_cap;            // records per super-batch the plan may hold (>= the index's units: the unsplit plan fits)

@@ -1798,6 +1798,17 @@ __device__ __forceinline__ void wave_rank_and_emit(const MergeParams& p, int q, 
         d[e] = idx < M ? cd[idx] : VS_INF;
         id[e] = idx < M ? ci[idx] : 0x7fffffff;
     }
+    // lane (round % 64) keeps the round's winner; the wave writes 64 rounds at a time (the id map is read once per output
+    // there, all lanes at once: read inside the rounds it costs a cache round trip per round)
+    float keep_d = VS_INF;
+    int keep_i = -1;
+    auto flush = [&](int first, int n) {
+        if (lane < n) {
+            const int round = first + lane;
+            if (p.out_d) p.out_d[(int64_t)q * p.kout + round] = keep_d;
+            if (p.out_i) p.out_i[(int64_t)q * p.kout + round] = (keep_i >= 0 && p.id_map) ? p.id_map[keep_i] : keep_i;
+        }
+    };
     for (int round = 0; round < p.kout; ++round) {
         float md = d[0];
         int mi = id[0];
@@ -1811,11 +1822,12 @@ __device__ __forceinline__ void wave_rank_and_emit(const MergeParams& p, int q, 
         int bi;
         wave_lexmin(md, mi, bd, bi);
         const bool none = bi == 0x7fffffff;
-        if (lane == 0) {
-            if (round < kMergeTrack) outd[round] = none ? VS_INF : bd;
-            if (p.out_d) p.out_d[(int64_t)q * p.kout + round] = none ? VS_INF : bd;
-            if (p.out_i) p.out_i[(int64_t)q * p.kout + round] = none ? -1 : (p.id_map ? p.id_map[bi] : bi);
+        if (lane == 0 && round < kMergeTrack) outd[round] = none ? VS_INF : bd;
+        if (lane == (round & 63)) {
+            keep_d = none ? VS_INF : bd;
+            keep_i = none ? -1 : bi;
         }
+        if ((round & 63) == 63) flush(round - 63, 64);
 #pragma unroll
         for (int e = 0; e < EPL; ++e)
             if (id[e] == bi && d[e] == bd) {
@@ -1823,6 +1835,7 @@ __device__ __forceinline__ void wave_rank_and_emit(const MergeParams& p, int q, 
                 id[e] = 0x7fffffff;
             }
     }
+    if (p.kout & 63) flush(p.kout & ~63, p.kout & 63);
 }
 
 __global__ __launch_bounds__(256) void merge_compact_kernel(const MergeParams p, const MergeLayout L) {
@@ -1852,19 +1865,48 @@ __global__ __launch_bounds__(256) void merge_compact_kernel(const MergeParams p,
     if (p.flat_len) {
         // G unsorted candidate lists per query (streaming scans): list g holds flat_len[q_in * G + g] <= kin entries
         // (the lengths are fetched together: one after the other they would cost G cache round trips)
-        __shared__ int s_len[64];
+        __shared__ int s_len[64], s_off[65];
         if (tid < p.G && tid < 64)
             s_len[tid] = min(p.flat_len[p.flat_len_sub_stride ? (int64_t)tid * p.flat_len_sub_stride + q_in : (int64_t)q_in * p.G + tid], p.kin);
         __syncthreads();
-        int off = 0;
-        for (int g = 0; g < p.G && g < 64; ++g) {
-            const int len = s_len[g];
-            const int64_t src = ((int64_t)q_in * p.G + g) * p.kin;
-            for (int e = tid; e < len; e += 256) {
-                cd[off + e] = p.part_d[src + e];
-                ci[off + e] = p.part_i[src + e];
+        const int G = min(p.G, 64);
+        if (tid == 0) {
+            int o = 0;
+            for (int g = 0; g < G; ++g) {
+                s_off[g] = o;
+                o += s_len[g];
             }
-            off += len;
+            s_off[G] = o;
+        }
+        __syncthreads();
+        const int off = s_off[G];
+        // all lists in one loop over the entries (list by list the copies are G cache round trips one after the other)
+        for (int e0 = 0; e0 < off; e0 += 256 * 4) {
+            float vd[4];
+            int vi[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + 256 * u + tid;
+                vd[u] = 0.f;
+                vi[u] = 0;
+                if (e0 + 256 * u < off) {  // workgroup-uniform
+                    int g = 0;
+                    for (int t = 1; t < G; ++t) g += s_off[t] <= e ? 1 : 0;  // the list entry e belongs to
+                    const int64_t src = ((int64_t)q_in * p.G + g) * p.kin + (e - s_off[g]);
+                    if (e < off) {
+                        vd[u] = p.part_d[src];
+                        vi[u] = p.part_i[src];
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + 256 * u + tid;
+                if (e < off) {
+                    cd[e] = vd[u];
+                    ci[e] = vi[u];
+                }
+            }
         }
         if (tid == 0) cnt = off;
     } else
@@ -2351,6 +2393,12 @@ __global__ __launch_bounds__(256) void ivf_pick_kernel(const float* __restrict__
     __shared__ int s_cnt;
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
+#ifdef VS_STAMPS
+#define PICK_STAMP(i) do { if (grp.dbg && tid == 0) grp.dbg[((int)blockIdx.y * 32 + b) * 16 + (i)] = (int)(__builtin_amdgcn_s_memrealtime() & 0x7fffffff); } while (0)
+#else
+#define PICK_STAMP(i)
+#endif
+    PICK_STAMP(0);
     if (tid == 0) {
         s_cnt = 0;
         s_tk = ~0ull;
@@ -2372,17 +2420,27 @@ __global__ __launch_bounds__(256) void ivf_pick_kernel(const float* __restrict__
     }
     mnk[tid] = mk;
     __syncthreads();
-    {
-        int rank = 0;
-        const u64x2* p2 = reinterpret_cast<const u64x2*>(mnk);
-#pragma unroll 8
-        for (int j = 0; j < 128; ++j) {
-            const u64x2 w = p2[j];
-            rank += (w.x < mk ? 1 : 0) + (w.y < mk ? 1 : 0);
+    PICK_STAMP(1);
+    if (tid < 64) {
+        // the nprobe-th smallest score among the 256 per-thread minima (they are 256 different lists, so at least nprobe
+        // lists score that or less), bit by bit from the top: the largest x with fewer than nprobe minima below x.  One
+        // wave, 32 rounds of 4 compares and 4 scalar popcounts (ranking every minimum against every other one cost 4 us).
+        unsigned hi[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) hi[i] = (unsigned)(mnk[tid + 64 * i] >> 32);
+        unsigned x = 0;
+#pragma unroll 4
+        for (int bit = 31; bit >= 0; --bit) {
+            const unsigned t = x | (1u << bit);
+            int below = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) below += __popcll(__ballot(hi[i] < t));
+            if (below < nprobe) x = t;  // wave-uniform
         }
-        if (rank == nprobe - 1 && mk != ~0ull) s_tk = mk;  // unique: keys are distinct
+        if (tid == 0) s_tk = ((u64)x << 32) | 0xffffffffull;  // every list scoring x or less is a candidate (ties included)
     }
     __syncthreads();
+    PICK_STAMP(2);
     {
         const u64 tk = s_tk;
 #pragma unroll
@@ -2417,7 +2475,21 @@ __global__ __launch_bounds__(256) void ivf_pick_kernel(const float* __restrict__
         probes[(int64_t)b * nprobe + c] = -1;
         s_probe[c] = -1;
     }
+    PICK_STAMP(3);
     if (!grp.lcnt) return;
+    if (grp.w_cnt) {
+        // wide pipeline: every (query, probe) pair takes a slot in its list's table (one global atomic per pair; a list
+        // without rows here has no records in the plan, its table is simply never read)
+        __syncthreads();
+        const int c = tid < nprobe ? s_probe[tid] : -1;
+        if (c >= 0) {
+            const int sb = (int)blockIdx.y / kIvfWideBatches;
+            const int slot = atomicAdd(grp.w_cnt + sb * ivf_wide_plan_words(nlist) + (int64_t)c * kIvfWideCntStride, 1);  // < w_q: once per query
+            grp.w_lq[((int64_t)sb * nlist + c) * grp.w_q + slot] = ((int)blockIdx.y % kIvfWideBatches) * kMaxBatch + b;  // the query's slot in its super-batch
+        }
+        PICK_STAMP(5);
+        return;
+    }
     // ---- every (query, probe) gets a window [qoff[p], qoff[p+1]) in the query's candidate-score array (probe order) ----
     __syncthreads();
     int sz = 0;
@@ -2446,13 +2518,6 @@ __global__ __launch_bounds__(256) void ivf_pick_kernel(const float* __restrict__
     if (tid == 0) {
         grp.qoff[(int64_t)b * (kIvfMaxProbe + 1) + nprobe] = tot;
         if (grp.cand_count) atomicAdd(grp.cand_count, (unsigned long long)tot);
-    }
-    if (grp.w_cnt && tid < nprobe && sz > 0) {
-        // wide pipeline: this (query, probe) pair takes a slot in its list's table (one global atomic per pair; tens of
-        // thousands of pairs over a thousand zeroed counters)
-        const int c = s_probe[tid];
-        const int slot = atomicAdd(grp.w_cnt + c, 1);  // < w_q: a list is probed at most once per query
-        grp.w_lq[(int64_t)c * grp.w_q + slot] = ((int)blockIdx.y % kIvfWideBatches) * kMaxBatch + b;  // the query's slot in its super-batch
     }
 }
 
@@ -3532,28 +3597,45 @@ __global__ __launch_bounds__(256) void ivf_tau_kernel(const IvfWideParams p) {
     const int batch = qg >> 5, qi = qg & 31;
     const bool valid = batch < p.n_batches && qi < p.B;  // wave-uniform
     const int r = lane & 15, g = lane >> 4;
-    int seg_start[NSEG], seg_rows[NSEG];
+    int seg_start[NSEG], seg_rows[NSEG], seg_td[NSEG];
     int nseg = 0, total_rows = 0;
 #pragma unroll
-    for (int sgm = 0; sgm < NSEG; ++sgm) seg_start[sgm] = seg_rows[sgm] = 0;
+    for (int sgm = 0; sgm < NSEG; ++sgm) seg_start[sgm] = seg_rows[sgm] = seg_td[sgm] = 0;
     if (valid) {
         const int32_t* pr = reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(p.probes) + (long long)batch * p.probes_batch_bytes) + qi * p.nprobe;
-        // the first NSEG probed lists that are resident here: their first SEGR rows each (k rows in all are needed)
-        for (int pp = 0; pp < p.nprobe && nseg < NSEG; ++pp) {
+        // the first NSEG probed lists that are resident here: their first SEGR rows each (k rows in all are needed).  The
+        // first LOOK probes and their lists' extents are fetched together (one after the other: a chain of cache round trips)
+        constexpr int LOOK = 4;
+        int cs[LOOK], o0[LOOK], o1[LOOK], td[LOOK];
+#pragma unroll
+        for (int i = 0; i < LOOK; ++i) cs[i] = i < p.nprobe ? pr[i] : -1;
+#pragma unroll
+        for (int i = 0; i < LOOK; ++i) {
+            const int c = max(cs[i], 0);
+            o0[i] = p.offsets[c];
+            o1[i] = p.offsets[c + 1];
+            td[i] = p.tdelta ? p.tdelta[c] : 0;
+        }
+        auto take_list = [&](int start, int len, int delta) {
+            const int take = min(len, SEGR);
+#pragma unroll
+            for (int sgm = 0; sgm < NSEG; ++sgm)
+                if (sgm == nseg) {
+                    seg_start[sgm] = start;
+                    seg_rows[sgm] = take;
+                    seg_td[sgm] = delta;
+                }
+            ++nseg;
+            total_rows += take;
+        };
+#pragma unroll
+        for (int i = 0; i < LOOK; ++i)
+            if (cs[i] >= 0 && o1[i] > o0[i] && nseg < NSEG) take_list(o0[i], o1[i] - o0[i], td[i]);
+        for (int pp = LOOK; pp < p.nprobe && nseg < NSEG; ++pp) {  // (rare: lists without rows here among the nearest)
             const int c = pr[pp];
             if (c < 0) continue;
             const int len = p.offsets[c + 1] - p.offsets[c];
-            if (len > 0) {
-                const int take = min(len, SEGR);
-#pragma unroll
-                for (int sgm = 0; sgm < NSEG; ++sgm)
-                    if (sgm == nseg) {
-                        seg_start[sgm] = p.offsets[c];
-                        seg_rows[sgm] = take;
-                    }
-                ++nseg;
-                total_rows += take;
-            }
+            if (len > 0) take_list(p.offsets[c], len, p.tdelta ? p.tdelta[c] : 0);
         }
     }
     const bool usable = valid && total_rows >= p.k;
@@ -3583,7 +3665,35 @@ __global__ __launch_bounds__(256) void ivf_tau_kernel(const IvfWideParams p) {
         const int start = myseg ? seg_start[1] : seg_start[0], rows = myseg ? seg_rows[1] : seg_rows[0];
         const int tiles = (rows + 15) >> 4;
         float* dseg = &dist[slot][myseg * SEGR];
-        if (i8) {
+        if (i8 && p.vecs_t8) {
+            // the tiled copy (see IvfWideParams): a list starts on a tile boundary there and a load is 1 KB in one piece
+            const int tstart = start + (myseg ? seg_td[1] : seg_td[0]);
+            const int8_t* rows_t = p.vecs_t8 + (int64_t)tstart * kDim + 16 * lane;
+            constexpr int U = 8;  // tiles whose loads go out together
+            for (int t0 = 0; t0 < tiles; t0 += U) {
+                i32x4 a0[U], a1[U], rt[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int t = min(t0 + u, tiles - 1);
+                    a0[u] = *reinterpret_cast<const i32x4*>(rows_t + (int64_t)t * 16 * kDim);
+                    a1[u] = *reinterpret_cast<const i32x4*>(rows_t + (int64_t)t * 16 * kDim + 1024);
+                    rt[u] = *reinterpret_cast<const i32x4*>(p.rterm_t + tstart + 16 * t + 4 * g);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int t = t0 + u;
+                    if (t >= tiles) break;
+                    i32x4 acc = {0, 0, 0, 0};
+                    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0[u], b0, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1[u], b1, acc, 0, 0, 0);
+                    if (r == 0) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (16 * t + 4 * g + j < rows) dseg[16 * t + 4 * g + j] = (float)(qt + rt[u][j] - 2 * acc[j]);
+                    }
+                }
+            }
+        } else if (i8) {
             constexpr int U = 4;  // tiles whose loads go out together
             for (int t0 = 0; t0 < tiles; t0 += U) {
                 i32x4 a0[U], a1[U], rt[U];
@@ -3684,30 +3794,62 @@ __global__ __launch_bounds__(1024) void ivf_plan_wide_kernel(const IvfWideParams
     __shared__ int cnt_s[kIvfFastNlist];
     __shared__ int s_carry;
     __shared__ int s_wtot[16];
-    __shared__ int s_tot[16][kIvfWideSplits];
+    __shared__ int s_tot[16][2 * kIvfWideSplits];
     __shared__ int s_shift;
     const int tid = threadIdx.x;
     const int sb = blockIdx.y;
     int32_t* units = p.units + (int64_t)sb * p.units_sb_stride;
-    for (int c = tid; c < p.nlist; c += 1024) cnt_s[c] = min(p.zero[(int64_t)sb * (p.nlist + 16) + c], kIvfWideQ);
-    if (tid == 0) s_carry = 0;
-    __syncthreads();
     const int pl = tid & 63, wv = tid >> 6;
     const int nsl = (int)gridDim.x;
     const int c0 = (int)((long long)p.n_chunks * blockIdx.x / nsl), c1 = (int)((long long)p.n_chunks * (blockIdx.x + 1) / nsl);
-    auto units_of = [&](int chunk) { return (p.chunk_rows[chunk] + kIvfWideUnit - 1) / kIvfWideUnit; };
-    {   // the split size (every workgroup works it out for itself: the same numbers, the same answer)
-        int tot[kIvfWideSplits];
+    // Everything read from global memory is requested before the first barrier (one cache round trip, not one per phase):
+    // the pair counters, the chunk table entries of the all-chunks pass (two per thread in registers, more only for
+    // very large indexes) and this thread's chunk of the workgroup's own slice.
+    constexpr int EARLY = 2;
+    int e_list[EARLY], e_rows[EARLY];
 #pragma unroll
-        for (int i = 0; i < kIvfWideSplits; ++i) tot[i] = 0;
-        for (int chunk = tid; chunk < p.n_chunks; chunk += 1024) {
-            const int nq = cnt_s[p.chunk_list[chunk]];
-            const int nu = units_of(chunk);
+    for (int i = 0; i < EARLY; ++i) {
+        const int chunk = tid + 1024 * i;
+        e_list[i] = chunk < p.n_chunks ? p.chunk_list[chunk] : 0;
+        e_rows[i] = chunk < p.n_chunks ? p.chunk_rows[chunk] : 0;
+    }
+    const int own = c0 + tid;
+    const int o_list = own < c1 ? p.chunk_list[own] : 0, o_rows = own < c1 ? p.chunk_rows[own] : 0, o_row0 = own < c1 ? p.chunk_trow0[own] : 0;
+    long long cand = 0;
+    for (int c = tid; c < p.nlist; c += 1024) {
+        const int n = min(p.zero[sb * ivf_wide_plan_words(p.nlist) + (int64_t)c * kIvfWideCntStride], kIvfWideQ);
+        cnt_s[c] = n;
+        if (p.cand_count && blockIdx.x == 0 && n > 0) cand += (long long)n * (p.offsets[c + 1] - p.offsets[c]);
+    }
+    if (p.cand_count && blockIdx.x == 0) {  // the candidate statistic (IVFIndex.cpp: total_candidates), one atomic per wave
 #pragma unroll
-            for (int i = 0; i < kIvfWideSplits; ++i) tot[i] += nu * ((nq + (256 << i) - 1) >> (8 + i));
-        }
+        for (int o = 32; o > 0; o >>= 1) cand += __shfl_xor(cand, o);
+        if ((tid & 63) == 0 && cand) atomicAdd(p.cand_count, (unsigned long long)cand);
+    }
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    auto units_of = [&](int rows) { return (rows + kIvfWideUnit - 1) / kIvfWideUnit; };
+    {   // one pass over all chunks: for every split size the plan's record count (does it fit?) and the records before
+        // this workgroup's slice (every workgroup works both out for itself: the same numbers, the same answer)
+        int tot[2 * kIvfWideSplits];
 #pragma unroll
-        for (int i = 0; i < kIvfWideSplits; ++i) {
+        for (int i = 0; i < 2 * kIvfWideSplits; ++i) tot[i] = 0;
+        auto add = [&](int chunk, int list, int rows) {
+            const int nq = cnt_s[list];
+            const int nu = units_of(rows);
+#pragma unroll
+            for (int i = 0; i < kIvfWideSplits; ++i) {
+                const int n = nu * ((nq + (256 << i) - 1) >> (8 + i));
+                tot[i] += n;
+                if (chunk < c0) tot[kIvfWideSplits + i] += n;
+            }
+        };
+#pragma unroll
+        for (int i = 0; i < EARLY; ++i)
+            if (tid + 1024 * i < p.n_chunks) add(tid + 1024 * i, e_list[i], e_rows[i]);
+        for (int chunk = tid + 1024 * EARLY; chunk < p.n_chunks; chunk += 1024) add(chunk, p.chunk_list[chunk], p.chunk_rows[chunk]);
+#pragma unroll
+        for (int i = 0; i < 2 * kIvfWideSplits; ++i) {
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) tot[i] += __shfl_xor(tot[i], o);
             if (pl == 0) s_tot[wv][i] = tot[i];
@@ -3720,29 +3862,22 @@ __global__ __launch_bounds__(1024) void ivf_plan_wide_kernel(const IvfWideParams
                 for (int w = 0; w < 16; ++w) t += s_tot[w][i];
                 if (t <= p.units_cap) sh = i;
             }
+            int pre = 0;
+            for (int w = 0; w < 16; ++w) pre += s_tot[w][kIvfWideSplits + sh];
             s_shift = 8 + sh;
+            s_carry = pre;
         }
         __syncthreads();
     }
     const int shift = s_shift;
-    auto recs_of = [&](int chunk) { return units_of(chunk) * ((cnt_s[p.chunk_list[chunk]] + (1 << shift) - 1) >> shift); };
-    {
-        int pre = 0;
-        for (int chunk = tid; chunk < c0; chunk += 1024) pre += recs_of(chunk);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) pre += __shfl_xor(pre, o);
-        if (pl == 0) s_wtot[wv] = pre;
-        __syncthreads();
-        if (tid == 0) {
-            int t = 0;
-            for (int w = 0; w < 16; ++w) t += s_wtot[w];
-            s_carry = t;
-        }
-        __syncthreads();
-    }
     for (int base = c0; base < c1; base += 1024) {
         const int chunk = base + tid;
-        const int nr = chunk < c1 ? recs_of(chunk) : 0;
+        const bool first = base == c0;
+        const int c = chunk < c1 ? (first ? o_list : p.chunk_list[chunk]) : 0;
+        const int rows = chunk < c1 ? (first ? o_rows : p.chunk_rows[chunk]) : 0;
+        const int nq = chunk < c1 ? cnt_s[c] : 0;
+        const int nu = units_of(rows);
+        const int nr = nu * ((nq + (1 << shift) - 1) >> shift);
         int incl = nr;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -3759,11 +3894,8 @@ __global__ __launch_bounds__(1024) void ivf_plan_wide_kernel(const IvfWideParams
         }
         int pos = s_carry + woff + incl - nr;
         if (nr > 0) {
-            const int c = p.chunk_list[chunk];
-            const int r0 = p.chunk_trow0[chunk];  // padded rows
-            const int r_end = r0 + p.chunk_rows[chunk];
-            const int nq = cnt_s[c];
-            const int nu = units_of(chunk);
+            const int r0 = first ? o_row0 : p.chunk_trow0[chunk];  // padded rows
+            const int r_end = r0 + rows;
             // the records of one unit are neighbours: the waves that take them read the same rows at about the same time
             for (int i = 0; i < nu; ++i)
                 for (int q0 = 0; q0 < nq; q0 += 1 << shift)
@@ -3773,7 +3905,7 @@ __global__ __launch_bounds__(1024) void ivf_plan_wide_kernel(const IvfWideParams
         if (tid == 0) s_carry += tot;
         __syncthreads();
     }
-    if (tid == 0 && (int)blockIdx.x == nsl - 1) p.zero[(int64_t)sb * (p.nlist + 16) + p.nlist] = s_carry;
+    if (tid == 0 && (int)blockIdx.x == nsl - 1) p.zero[sb * ivf_wide_plan_words(p.nlist) + (int64_t)p.nlist * kIvfWideCntStride] = s_carry;
 }
 
 // The list-major scan of one super-batch (blockIdx.y).  A workgroup stages the super-batch's queries once (as bytes: 128
@@ -3829,7 +3961,7 @@ __global__ __launch_bounds__(kIvfWideThreads) void ivf_scan_wide_kernel(const Iv
     int wbase = 0;
     VS_STAMP(0);
     // everything the staging needs is requested in one go (a kernel start is a chain of cold round trips otherwise)
-    const int n_units = p.zero[(int64_t)sb * (p.nlist + 16) + p.nlist];
+    const int n_units = p.zero[sb * ivf_wide_plan_words(p.nlist) + (int64_t)p.nlist * kIvfWideCntStride];
     int4 rv0 = recs[min(u, p.units_cap - 1)], rv1 = recs[min(u + nw, p.units_cap - 1)];
     int inv = 0;
     for (int b = b0; b < b1; ++b) inv |= p.invalid[b];
