@@ -1105,6 +1105,9 @@ int ivf_group_wide_dev(vs_index* h, const float* q_dev, int nb, int B, int k, in
     m.flat_len = z_cnt;
     m.flat_len_sub_stride = (int)nq;
     m.id_map = h->d_r2o_t ? h->d_r2o_t : h->d_r2o;  // the scan's candidates are padded rows
+#ifdef VS_STAMPS
+    m.dbg = g_dbg ? g_dbg + 8192 * 16 : nullptr;
+#endif
     HIPCHK(vs::launch_merge_layout(m, kIvfWideSubCap, (int64_t)kWideSub * kIvfWideSubCap, s));
     HIPCHK(vs::launch_ivf_wide_slow(wp, s));
     stage_mark(h, 3, s);

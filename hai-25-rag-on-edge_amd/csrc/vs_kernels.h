@@ -170,6 +170,7 @@ struct MergeParams {
     int run_mode;            //   launch of the pair writes the outputs)
     const int32_t* flat_len; // optional [queries][G]: list (q, g) holds flat_len[q * G + g] <= kin UNSORTED candidates
     int flat_len_sub_stride; // != 0: the lengths are list major instead, flat_len[g * flat_len_sub_stride + q]
+    int32_t* dbg;            // diagnostic builds (-DVS_STAMPS) only
 };
 hipError_t launch_merge(const MergeParams& p, hipStream_t s);  // scan-partial layout [G][nq_stride][kin]
 // general layout: entry (g, q, j) at g*stride_g + q*stride_q + j

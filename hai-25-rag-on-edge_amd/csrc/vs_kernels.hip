@@ -1850,6 +1850,12 @@ __global__ __launch_bounds__(256) void merge_compact_kernel(const MergeParams p,
     const int q_in = p.q_group_out > 0 ? (q / p.q_group_out) * p.q_group_in + (q % p.q_group_out) : q;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
+#ifdef VS_STAMPS
+#define MRG_STAMP(i) do { if (p.dbg && tid == 0) p.dbg[(int)blockIdx.x * 16 + (i)] = (int)(__builtin_amdgcn_s_memrealtime() & 0x7fffffff); } while (0)
+#else
+#define MRG_STAMP(i)
+#endif
+    MRG_STAMP(0);
     if (p.run_if && ((p.run_mode == 1 && !p.run_if[0]) || (p.run_mode == 2 && p.run_if[0]))) return;
     if (p.invalid && p.q_group_out > 0 && p.invalid[q / p.q_group_out]) {
         // the int8 scan skipped this batch (a query was not an integer in [0, 255]): tell the caller to rerun it
@@ -1880,32 +1886,31 @@ __global__ __launch_bounds__(256) void merge_compact_kernel(const MergeParams p,
         }
         __syncthreads();
         const int off = s_off[G];
-        // all lists in one loop over the entries (list by list the copies are G cache round trips one after the other)
-        for (int e0 = 0; e0 < off; e0 += 256 * 4) {
-            float vd[4];
-            int vi[4];
+        // all lists in one pass over the entries (list by list the copies are G cache round trips one after the other)
+        constexpr int GU = kCompactCap / 256;  // every entry of the longest possible set in one go: one cache round trip
+        float vd[GU];
+        int vi[GU];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int e = e0 + 256 * u + tid;
-                vd[u] = 0.f;
-                vi[u] = 0;
-                if (e0 + 256 * u < off) {  // workgroup-uniform
-                    int g = 0;
-                    for (int t = 1; t < G; ++t) g += s_off[t] <= e ? 1 : 0;  // the list entry e belongs to
-                    const int64_t src = ((int64_t)q_in * p.G + g) * p.kin + (e - s_off[g]);
-                    if (e < off) {
-                        vd[u] = p.part_d[src];
-                        vi[u] = p.part_i[src];
-                    }
+        for (int u = 0; u < GU; ++u) {
+            const int e = 256 * u + tid;
+            vd[u] = 0.f;
+            vi[u] = 0;
+            if (256 * u < off) {  // workgroup-uniform
+                int g = 0;
+                for (int t = 1; t < G; ++t) g += s_off[t] <= e ? 1 : 0;  // the list entry e belongs to
+                const int64_t src = ((int64_t)q_in * p.G + g) * p.kin + (e - s_off[g]);
+                if (e < off) {
+                    vd[u] = p.part_d[src];
+                    vi[u] = p.part_i[src];
                 }
             }
+        }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int e = e0 + 256 * u + tid;
-                if (e < off) {
-                    cd[e] = vd[u];
-                    ci[e] = vi[u];
-                }
+        for (int u = 0; u < GU; ++u) {
+            const int e = 256 * u + tid;
+            if (e < off) {
+                cd[e] = vd[u];
+                ci[e] = vi[u];
             }
         }
         if (tid == 0) cnt = off;
@@ -1926,21 +1931,25 @@ __global__ __launch_bounds__(256) void merge_compact_kernel(const MergeParams p,
     }
     __syncthreads();
     const int M = cnt;
+    MRG_STAMP(1);
+#ifdef VS_STAMPS
+    if (p.dbg && tid == 0) p.dbg[(int)blockIdx.x * 16 + 8] = M;
+#endif
     const int n_track = p.kout < kMergeTrack ? p.kout : kMergeTrack;
 
-    // Many candidates (a loose bound on a few queries): the kout-th smallest of the first 1024 bounds the answer; whatever
+    // Many candidates (a loose bound on a few queries): the kout-th smallest of the first 256 bounds the answer; whatever
     // is not above it (usually a few dozen entries) is copied aside and ranked by one wave like a short list.
     __shared__ float cd2[1024];
     __shared__ int ci2[1024];
     __shared__ float s_thr_d;
     __shared__ int s_thr_i, s_keep;
     bool filtered = false;
-    if (M > 1024 && p.kout <= 64) {  // workgroup-uniform
+    if (M > 256 && p.kout <= 64) {  // workgroup-uniform
         if (wave == 0) {
-            float d[16];
-            int id[16];
+            float d[4];
+            int id[4];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
+            for (int e = 0; e < 4; ++e) {
                 d[e] = cd[e * 64 + lane];
                 id[e] = ci[e * 64 + lane];
             }
@@ -1950,14 +1959,14 @@ __global__ __launch_bounds__(256) void merge_compact_kernel(const MergeParams p,
                 float md = d[0];
                 int mi = id[0];
 #pragma unroll
-                for (int e = 1; e < 16; ++e)
+                for (int e = 1; e < 4; ++e)
                     if (lex_lt(d[e], id[e], md, mi)) {
                         md = d[e];
                         mi = id[e];
                     }
                 wave_lexmin(md, mi, bd, bi);
 #pragma unroll
-                for (int e = 0; e < 16; ++e)
+                for (int e = 0; e < 4; ++e)
                     if (id[e] == bi && d[e] == bd) {
                         d[e] = VS_INF;
                         id[e] = 0x7fffffff;
@@ -1993,7 +2002,7 @@ __global__ __launch_bounds__(256) void merge_compact_kernel(const MergeParams p,
             else if (S <= 256) wave_rank_and_emit<4>(p, q, cd2, ci2, S, outd, lane);
             else wave_rank_and_emit<16>(p, q, cd2, ci2, S, outd, lane);
         }
-    } else if (M <= 1024) {
+    } else if (M <= 1024) {  // (between 257 and 1024 only when kout > 64)
         if (wave == 0) {
             if (M <= 64) wave_rank_and_emit<1>(p, q, cd, ci, M, outd, lane);
             else if (M <= 256) wave_rank_and_emit<4>(p, q, cd, ci, M, outd, lane);
@@ -2050,6 +2059,7 @@ __global__ __launch_bounds__(256) void merge_compact_kernel(const MergeParams p,
             __syncthreads();
         }
     }
+    MRG_STAMP(2);
     if (tid == 0) {
         if (p.flags) {
             int f = 0;
@@ -2294,37 +2304,61 @@ __global__ __launch_bounds__(256) void ivf_coarse_mfma_kernel(const float* __res
     __shared__ float qn_s[kMaxBatch];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
+    // both operands are requested first: the centroid tile (A) and the batch's queries as two 16-column B operands; the
+    // norms below then cost no further cache round trip
+    const int row0 = ((int)blockIdx.x * 4 + wave) * 16;  // centroid tile (the centroid array has kScanPadRows spare rows)
+    f32x4 a[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) a[c] = *reinterpret_cast<const f32x4*>(cents + (int64_t)(row0 + r) * kDim + 16 * c + 4 * g);
+    const f32x4 cn = *reinterpret_cast<const f32x4*>(cnorm + row0 + 4 * g);  // padded by 64
+    f32x4 qf[2][8];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int qrow = h * 16 + r;
+        const bool qv = qrow < B;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            qf[h][c] = *reinterpret_cast<const f32x4*>(q + (qv ? qrow : 0) * kDim + 16 * c + 4 * g);
+            if (!qv) qf[h][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    }
     {   // ||q||^2 in the reference's AVX2 order (cpu_baseline.cpp:95-114): 8 lanes per query
         const int row = tid >> 3, j = tid & 7;
-        // wide pipeline: the first block of every batch also writes the queries as bytes, their constant terms and the
-        // batch's "byte valued" verdict (what seed_qnorm_kernel does for the brute-force scans)
-        const bool prep = grp.w_q8 != nullptr && blockIdx.x == 0;
-        const int64_t qslot = (int64_t)blockIdx.y * kMaxBatch + row;
         float acc = 0.f;
-        int part = 0;
-        bool q_ok = true;
         if (row < B) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const float x = q[row * kDim + 8 * i + j];
                 acc = fmaf(x, x, acc);
-                if (prep) {
-                    const int xi = (int)x;
-                    q_ok = q_ok && ((float)xi == x) && xi >= 0 && xi <= 255;
-                    part += xi - 128;
-                    grp.w_q8[qslot * kDim + 8 * i + j] = (int8_t)(xi - 128);
-                }
             }
-        } else if (prep) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) grp.w_q8[qslot * kDim + 8 * i + j] = 0;  // padding queries
         }
         const int b8 = lane & ~7;
         float sum = __shfl(acc, b8);
 #pragma unroll
         for (int u = 1; u < 8; ++u) sum = sum + __shfl(acc, b8 + u);
         if (j == 0) qn_s[row] = row < B ? sum : 0.f;
-        if (prep) {
+        // wide pipeline: the first block of every batch also writes the queries as bytes, their constant terms and the
+        // batch's "byte valued" verdict (what seed_qnorm_kernel does for the brute-force scans); a thread converts 16
+        // neighbouring components and stores them as one 16-byte word
+        if (grp.w_q8 != nullptr && blockIdx.x == 0) {
+            const int64_t qslot = (int64_t)blockIdx.y * kMaxBatch + row;
+            int part = 0;
+            bool q_ok = true;
+            int w[4] = {0, 0, 0, 0};
+            if (row < B) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const f32x4 x = *reinterpret_cast<const f32x4*>(q + row * kDim + 16 * j + 4 * v);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int xi = (int)x[e];
+                        q_ok = q_ok && ((float)xi == x[e]) && xi >= 0 && xi <= 255;
+                        part += xi - 128;
+                        w[v] |= ((xi - 128) & 0xff) << (8 * e);
+                    }
+                }
+            }
+            *reinterpret_cast<int4*>(grp.w_q8 + qslot * kDim + 16 * j) = make_int4(w[0], w[1], w[2], w[3]);  // (padding queries: 0)
             part += __shfl_xor(part, 1);
             part += __shfl_xor(part, 2);
             part += __shfl_xor(part, 4);
@@ -2335,11 +2369,6 @@ __global__ __launch_bounds__(256) void ivf_coarse_mfma_kernel(const float* __res
             if (!q_ok) grp.w_invalid[blockIdx.y] = 1;
         }
     }
-    const int row0 = ((int)blockIdx.x * 4 + wave) * 16;  // centroid tile (the centroid array has kScanPadRows spare rows)
-    f32x4 a[8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) a[c] = *reinterpret_cast<const f32x4*>(cents + (int64_t)(row0 + r) * kDim + 16 * c + 4 * g);
-    const f32x4 cn = *reinterpret_cast<const f32x4*>(cnorm + row0 + 4 * g);  // padded by 64
     __syncthreads();
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -2348,12 +2377,9 @@ __global__ __launch_bounds__(256) void ivf_coarse_mfma_kernel(const float* __res
         const bool qv = qrow < B;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            f32x4 qf = *reinterpret_cast<const f32x4*>(q + (qv ? qrow : 0) * kDim + 16 * c + 4 * g);
-            if (!qv) qf = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < 8; ++c)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][i], qf[i], acc, 0, 0, 0);
-        }
+            for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][i], qf[h][c][i], acc, 0, 0, 0);
         if (qv) {
             const float qn = qn_s[qrow];
             f32x4 d;
@@ -3582,7 +3608,7 @@ hipError_t launch_query_prep(const SeedParams& p, hipStream_t s) {
 // query's own neighbourhood is not always in the nearest one).  One wave per query: 16-row MFMA tiles with the query in
 // column 0 of the B operand, distances through LDS, k rounds of a wave minimum.  Fewer than k rows: tau = +inf and the
 // query is marked for the exact slow path.
-__global__ __launch_bounds__(256) void ivf_tau_kernel(const IvfWideParams p) {
+__device__ __forceinline__ void ivf_tau_body(const IvfWideParams& p, const int wg) {
     typedef int i32x4 __attribute__((ext_vector_type(4)));
     typedef int i32x4_u __attribute__((ext_vector_type(4), aligned(4)));
     typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
@@ -3592,8 +3618,14 @@ __global__ __launch_bounds__(256) void ivf_tau_kernel(const IvfWideParams p) {
     // a workgroup = 2 queries x NSEG waves: wave (slot, sgm) scores segment sgm of its query, the segment-0 wave selects
     __shared__ __attribute__((aligned(16))) float dist[2][NR];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#ifdef VS_STAMPS
+#define TAU_STAMP(i) do { if (p.dbg && threadIdx.x == 0) p.dbg[(7168 + wg) * 16 + (i)] = (int)(__builtin_amdgcn_s_memrealtime() & 0x7fffffff); } while (0)
+#else
+#define TAU_STAMP(i)
+#endif
+    TAU_STAMP(0);
     const int slot = wave >> 1, myseg = wave & 1;
-    const int qg = (int)blockIdx.x * 2 + slot;
+    const int qg = wg * 2 + slot;
     const int batch = qg >> 5, qi = qg & 31;
     const bool valid = batch < p.n_batches && qi < p.B;  // wave-uniform
     const int r = lane & 15, g = lane >> 4;
@@ -3639,6 +3671,7 @@ __global__ __launch_bounds__(256) void ivf_tau_kernel(const IvfWideParams p) {
         }
     }
     const bool usable = valid && total_rows >= p.k;
+    TAU_STAMP(1);
     for (int i = lane; i < SEGR; i += 64) dist[slot][myseg * SEGR + i] = VS_INF;
     if (usable) {
     const bool i8 = p.vecs_u8 && p.metric == 0 && p.invalid[batch] == 0;
@@ -3741,6 +3774,7 @@ __global__ __launch_bounds__(256) void ivf_tau_kernel(const IvfWideParams p) {
     }
     }
     __syncthreads();
+    TAU_STAMP(2);
     if (!valid || myseg != 0) return;
     if (!usable) {
         if (lane == 0) {
@@ -3773,6 +3807,7 @@ __global__ __launch_bounds__(256) void ivf_tau_kernel(const IvfWideParams p) {
                 }
         }
     }
+    TAU_STAMP(3);
     if (lane == 0) {
         // integer distances (int8 path) are exact: the bound may sit right above the k-th value; fp32 rows are scored
         // with the same MFMA chain as the scan here, but leave slack anyway (the bound only filters)
@@ -3790,44 +3825,61 @@ __global__ __launch_bounds__(256) void ivf_tau_kernel(const IvfWideParams p) {
 constexpr int kIvfWideUnit = 32;  // rows per unit: two 16-row MFMA tiles
 constexpr int kIvfWideTiles = kIvfWideUnit / 16;
 constexpr int kIvfWideSplits = 3;  // S = 256 << i
-__global__ __launch_bounds__(1024) void ivf_plan_wide_kernel(const IvfWideParams p) {
+constexpr int kPlanThreads = 256, kPlanWaves = kPlanThreads / 64;
+__device__ __forceinline__ void ivf_plan_body(const IvfWideParams& p, const int sb, const int slice, const int nsl) {
     __shared__ int cnt_s[kIvfFastNlist];
     __shared__ int s_carry;
-    __shared__ int s_wtot[16];
-    __shared__ int s_tot[16][2 * kIvfWideSplits];
+    __shared__ int s_wtot[kPlanWaves];
+    __shared__ int s_tot[kPlanWaves][2 * kIvfWideSplits];
     __shared__ int s_shift;
     const int tid = threadIdx.x;
-    const int sb = blockIdx.y;
+#ifdef VS_STAMPS
+#define PLAN_STAMP(i) do { if (p.dbg && tid == 0) p.dbg[(6144 + slice) * 16 + (i)] = (int)(__builtin_amdgcn_s_memrealtime() & 0x7fffffff); } while (0)
+#else
+#define PLAN_STAMP(i)
+#endif
+    PLAN_STAMP(0);
     int32_t* units = p.units + (int64_t)sb * p.units_sb_stride;
     const int pl = tid & 63, wv = tid >> 6;
-    const int nsl = (int)gridDim.x;
-    const int c0 = (int)((long long)p.n_chunks * blockIdx.x / nsl), c1 = (int)((long long)p.n_chunks * (blockIdx.x + 1) / nsl);
+    const int c0 = (int)((long long)p.n_chunks * slice / nsl), c1 = (int)((long long)p.n_chunks * (slice + 1) / nsl);
     // Everything read from global memory is requested before the first barrier (one cache round trip, not one per phase):
-    // the pair counters, the chunk table entries of the all-chunks pass (two per thread in registers, more only for
+    // the pair counters, the chunk table entries of the all-chunks pass (eight per thread in registers, more only for
     // very large indexes) and this thread's chunk of the workgroup's own slice.
-    constexpr int EARLY = 2;
+    constexpr int EARLY = 8;
     int e_list[EARLY], e_rows[EARLY];
 #pragma unroll
     for (int i = 0; i < EARLY; ++i) {
-        const int chunk = tid + 1024 * i;
+        const int chunk = tid + kPlanThreads * i;
         e_list[i] = chunk < p.n_chunks ? p.chunk_list[chunk] : 0;
         e_rows[i] = chunk < p.n_chunks ? p.chunk_rows[chunk] : 0;
     }
     const int own = c0 + tid;
     const int o_list = own < c1 ? p.chunk_list[own] : 0, o_rows = own < c1 ? p.chunk_rows[own] : 0, o_row0 = own < c1 ? p.chunk_trow0[own] : 0;
     long long cand = 0;
-    for (int c = tid; c < p.nlist; c += 1024) {
-        const int n = min(p.zero[sb * ivf_wide_plan_words(p.nlist) + (int64_t)c * kIvfWideCntStride], kIvfWideQ);
-        cnt_s[c] = n;
-        if (p.cand_count && blockIdx.x == 0 && n > 0) cand += (long long)n * (p.offsets[c + 1] - p.offsets[c]);
+    {
+        constexpr int CPT = kIvfFastNlist / kPlanThreads;  // counters per thread: loaded together, then stored
+        int n[CPT], len[CPT];
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+            const int c = tid + kPlanThreads * i;
+            n[i] = c < p.nlist ? p.zero[sb * ivf_wide_plan_words(p.nlist) + (int64_t)c * kIvfWideCntStride] : 0;
+            len[i] = (p.cand_count && slice == 0 && c < p.nlist) ? p.offsets[c + 1] - p.offsets[c] : 0;
+        }
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+            const int c = tid + kPlanThreads * i;
+            if (c < p.nlist) cnt_s[c] = min(n[i], kIvfWideQ);
+            cand += (long long)min(n[i], kIvfWideQ) * len[i];
+        }
     }
-    if (p.cand_count && blockIdx.x == 0) {  // the candidate statistic (IVFIndex.cpp: total_candidates), one atomic per wave
+    if (p.cand_count && slice == 0) {  // the candidate statistic (IVFIndex.cpp: total_candidates), one atomic per wave
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) cand += __shfl_xor(cand, o);
         if ((tid & 63) == 0 && cand) atomicAdd(p.cand_count, (unsigned long long)cand);
     }
     if (tid == 0) s_carry = 0;
     __syncthreads();
+    PLAN_STAMP(1);
     auto units_of = [&](int rows) { return (rows + kIvfWideUnit - 1) / kIvfWideUnit; };
     {   // one pass over all chunks: for every split size the plan's record count (does it fit?) and the records before
         // this workgroup's slice (every workgroup works both out for itself: the same numbers, the same answer)
@@ -3846,8 +3898,8 @@ __global__ __launch_bounds__(1024) void ivf_plan_wide_kernel(const IvfWideParams
         };
 #pragma unroll
         for (int i = 0; i < EARLY; ++i)
-            if (tid + 1024 * i < p.n_chunks) add(tid + 1024 * i, e_list[i], e_rows[i]);
-        for (int chunk = tid + 1024 * EARLY; chunk < p.n_chunks; chunk += 1024) add(chunk, p.chunk_list[chunk], p.chunk_rows[chunk]);
+            if (tid + kPlanThreads * i < p.n_chunks) add(tid + kPlanThreads * i, e_list[i], e_rows[i]);
+        for (int chunk = tid + kPlanThreads * EARLY; chunk < p.n_chunks; chunk += kPlanThreads) add(chunk, p.chunk_list[chunk], p.chunk_rows[chunk]);
 #pragma unroll
         for (int i = 0; i < 2 * kIvfWideSplits; ++i) {
 #pragma unroll
@@ -3859,18 +3911,19 @@ __global__ __launch_bounds__(1024) void ivf_plan_wide_kernel(const IvfWideParams
             int sh = kIvfWideSplits - 1;
             for (int i = kIvfWideSplits - 1; i >= 0; --i) {
                 long long t = 0;
-                for (int w = 0; w < 16; ++w) t += s_tot[w][i];
+                for (int w = 0; w < kPlanWaves; ++w) t += s_tot[w][i];
                 if (t <= p.units_cap) sh = i;
             }
             int pre = 0;
-            for (int w = 0; w < 16; ++w) pre += s_tot[w][kIvfWideSplits + sh];
+            for (int w = 0; w < kPlanWaves; ++w) pre += s_tot[w][kIvfWideSplits + sh];
             s_shift = 8 + sh;
             s_carry = pre;
         }
         __syncthreads();
     }
     const int shift = s_shift;
-    for (int base = c0; base < c1; base += 1024) {
+    PLAN_STAMP(2);
+    for (int base = c0; base < c1; base += kPlanThreads) {
         const int chunk = base + tid;
         const bool first = base == c0;
         const int c = chunk < c1 ? (first ? o_list : p.chunk_list[chunk]) : 0;
@@ -3887,7 +3940,7 @@ __global__ __launch_bounds__(1024) void ivf_plan_wide_kernel(const IvfWideParams
         if (pl == 63) s_wtot[wv] = incl;
         __syncthreads();
         int woff = 0, tot = 0;
-        for (int w = 0; w < 16; ++w) {
+        for (int w = 0; w < kPlanWaves; ++w) {
             const int t = s_wtot[w];
             if (w < wv) woff += t;
             tot += t;
@@ -3905,7 +3958,16 @@ __global__ __launch_bounds__(1024) void ivf_plan_wide_kernel(const IvfWideParams
         if (tid == 0) s_carry += tot;
         __syncthreads();
     }
-    if (tid == 0 && (int)blockIdx.x == nsl - 1) p.zero[sb * ivf_wide_plan_words(p.nlist) + (int64_t)p.nlist * kIvfWideCntStride] = s_carry;
+    PLAN_STAMP(3);
+    if (tid == 0 && slice == nsl - 1) p.zero[sb * ivf_wide_plan_words(p.nlist) + (int64_t)p.nlist * kIvfWideCntStride] = s_carry;
+}
+
+// Bounds and plan in ONE launch (both need the pick kernel's output only and take about 10 us each: side by side instead
+// of one after the other).  The first n_plan * n_sb workgroups plan, the rest compute bounds, two queries each.
+__global__ __launch_bounds__(256) void ivf_tau_plan_kernel(const IvfWideParams p, const int n_plan, const int n_sb) {
+    const int wg = blockIdx.x;
+    if (wg < n_plan * n_sb) ivf_plan_body(p, wg / n_plan, wg % n_plan, n_plan);
+    else ivf_tau_body(p, wg - n_plan * n_sb);
 }
 
 // The list-major scan of one super-batch (blockIdx.y).  A workgroup stages the super-batch's queries once (as bytes: 128
@@ -4288,8 +4350,8 @@ int ivf_wide_waves(int num_cus, int n_sb) { return ivf_wide_grid_x(num_cus, n_sb
 hipError_t launch_ivf_wide(const IvfWideParams& p, int num_cus, hipStream_t s) {
     if (p.nlist > kIvfFastNlist || p.nprobe > kIvfMaxProbe || p.k > 16) return hipErrorInvalidValue;
     const int n_sb = (p.n_batches + kIvfWideBatches - 1) / kIvfWideBatches;
-    hipLaunchKernelGGL(ivf_tau_kernel, dim3((p.n_batches * kMaxBatch + 1) / 2), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(ivf_plan_wide_kernel, dim3(std::max(kPlanSplit, 32 / n_sb), n_sb), dim3(1024), 0, s, p);
+    const int n_plan = std::max(4, 16 / n_sb);  // (every planning workgroup reads all pair counters, a cache line each)
+    hipLaunchKernelGGL(ivf_tau_plan_kernel, dim3(n_plan * n_sb + (p.n_batches * kMaxBatch + 1) / 2), dim3(256), 0, s, p, n_plan, n_sb);
     static bool attr_set[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
