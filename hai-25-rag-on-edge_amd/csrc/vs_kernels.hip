@@ -3825,12 +3825,12 @@ __device__ __forceinline__ void ivf_tau_body(const IvfWideParams& p, const int w
 constexpr int kIvfWideUnit = 32;  // rows per unit: two 16-row MFMA tiles
 constexpr int kIvfWideTiles = kIvfWideUnit / 16;
 constexpr int kIvfWideSplits = 3;  // S = 256 << i
-constexpr int kPlanThreads = 256, kPlanWaves = kPlanThreads / 64;
+constexpr int kPlanThreads = 256, kPlanWaves = kPlanThreads / 64, kPlanClasses = 16;
 __device__ __forceinline__ void ivf_plan_body(const IvfWideParams& p, const int sb, const int slice, const int nsl) {
     __shared__ int cnt_s[kIvfFastNlist];
     __shared__ int s_carry;
-    __shared__ int s_wtot[kPlanWaves];
-    __shared__ int s_tot[kPlanWaves][2 * kIvfWideSplits];
+    __shared__ int s_tot[kPlanWaves][kIvfWideSplits];
+    __shared__ int s_ctot[kPlanClasses + 1], s_cpre[kPlanClasses + 1], s_cpos[kPlanClasses + 1];
     __shared__ int s_shift;
     const int tid = threadIdx.x;
 #ifdef VS_STAMPS
@@ -3881,31 +3881,28 @@ __device__ __forceinline__ void ivf_plan_body(const IvfWideParams& p, const int 
     __syncthreads();
     PLAN_STAMP(1);
     auto units_of = [&](int rows) { return (rows + kIvfWideUnit - 1) / kIvfWideUnit; };
-    {   // one pass over all chunks: for every split size the plan's record count (does it fit?) and the records before
-        // this workgroup's slice (every workgroup works both out for itself: the same numbers, the same answer)
-        int tot[2 * kIvfWideSplits];
+    {   // one pass over all chunks: for every split size the plan's record count -- does it fit? (every workgroup works
+        // this out for itself: the same numbers, the same answer)
+        int tot[kIvfWideSplits];
 #pragma unroll
-        for (int i = 0; i < 2 * kIvfWideSplits; ++i) tot[i] = 0;
-        auto add = [&](int chunk, int list, int rows) {
+        for (int i = 0; i < kIvfWideSplits; ++i) tot[i] = 0;
+        auto add = [&](int list, int rows) {
             const int nq = cnt_s[list];
             const int nu = units_of(rows);
 #pragma unroll
-            for (int i = 0; i < kIvfWideSplits; ++i) {
-                const int n = nu * ((nq + (256 << i) - 1) >> (8 + i));
-                tot[i] += n;
-                if (chunk < c0) tot[kIvfWideSplits + i] += n;
-            }
+            for (int i = 0; i < kIvfWideSplits; ++i) tot[i] += nu * ((nq + (256 << i) - 1) >> (8 + i));
         };
 #pragma unroll
         for (int i = 0; i < EARLY; ++i)
-            if (tid + kPlanThreads * i < p.n_chunks) add(tid + kPlanThreads * i, e_list[i], e_rows[i]);
-        for (int chunk = tid + kPlanThreads * EARLY; chunk < p.n_chunks; chunk += kPlanThreads) add(chunk, p.chunk_list[chunk], p.chunk_rows[chunk]);
+            if (tid + kPlanThreads * i < p.n_chunks) add(e_list[i], e_rows[i]);
+        for (int chunk = tid + kPlanThreads * EARLY; chunk < p.n_chunks; chunk += kPlanThreads) add(p.chunk_list[chunk], p.chunk_rows[chunk]);
 #pragma unroll
-        for (int i = 0; i < 2 * kIvfWideSplits; ++i) {
+        for (int i = 0; i < kIvfWideSplits; ++i) {
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) tot[i] += __shfl_xor(tot[i], o);
             if (pl == 0) s_tot[wv][i] = tot[i];
         }
+        if (tid <= kPlanClasses) s_ctot[tid] = s_cpre[tid] = 0;
         __syncthreads();
         if (tid == 0) {
             int sh = kIvfWideSplits - 1;
@@ -3914,49 +3911,58 @@ __device__ __forceinline__ void ivf_plan_body(const IvfWideParams& p, const int 
                 for (int w = 0; w < kPlanWaves; ++w) t += s_tot[w][i];
                 if (t <= p.units_cap) sh = i;
             }
-            int pre = 0;
-            for (int w = 0; w < kPlanWaves; ++w) pre += s_tot[w][kIvfWideSplits + sh];
             s_shift = 8 + sh;
-            s_carry = pre;
         }
         __syncthreads();
     }
     const int shift = s_shift;
     PLAN_STAMP(2);
+    // The records are laid out by cost class, the most expensive class first (class = column blocks of a record = queries
+    // of its slot range / 16, capped): the scan deals records round-robin, so every wave gets one record of every
+    // stratum and the sums come out alike (dealt in list order the slowest of 4096 waves took 25 % longer than the
+    // average).  Second pass over all chunks: records per class in all chunks and in the chunks before this slice.
+    auto class_of = [&](int nq) { return min((min(nq, 1 << shift) + 15) >> 4, kPlanClasses); };
+    {
+        auto add = [&](int chunk, int list, int rows) {
+            const int nq = cnt_s[list];
+            if (nq == 0) return;
+            const int n = units_of(rows) * ((nq + (1 << shift) - 1) >> shift);
+            const int cl = class_of(nq);
+            atomicAdd(&s_ctot[cl], n);
+            if (chunk < c0) atomicAdd(&s_cpre[cl], n);
+        };
+#pragma unroll
+        for (int i = 0; i < EARLY; ++i)
+            if (tid + kPlanThreads * i < p.n_chunks) add(tid + kPlanThreads * i, e_list[i], e_rows[i]);
+        for (int chunk = tid + kPlanThreads * EARLY; chunk < p.n_chunks; chunk += kPlanThreads) add(chunk, p.chunk_list[chunk], p.chunk_rows[chunk]);
+        __syncthreads();
+        if (tid == 0) {
+            int base = 0;
+            for (int cl = kPlanClasses; cl >= 1; --cl) {
+                s_cpos[cl] = base + s_cpre[cl];  // where this slice's records of the class start
+                base += s_ctot[cl];
+            }
+            s_carry = base;  // records in the plan
+        }
+        __syncthreads();
+    }
     for (int base = c0; base < c1; base += kPlanThreads) {
         const int chunk = base + tid;
+        if (chunk >= c1) break;
         const bool first = base == c0;
-        const int c = chunk < c1 ? (first ? o_list : p.chunk_list[chunk]) : 0;
-        const int rows = chunk < c1 ? (first ? o_rows : p.chunk_rows[chunk]) : 0;
-        const int nq = chunk < c1 ? cnt_s[c] : 0;
+        const int c = first ? o_list : p.chunk_list[chunk];
+        const int rows = first ? o_rows : p.chunk_rows[chunk];
+        const int nq = cnt_s[c];
+        if (nq == 0) continue;
         const int nu = units_of(rows);
         const int nr = nu * ((nq + (1 << shift) - 1) >> shift);
-        int incl = nr;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int t = __shfl_up(incl, o);
-            if (pl >= o) incl += t;
-        }
-        if (pl == 63) s_wtot[wv] = incl;
-        __syncthreads();
-        int woff = 0, tot = 0;
-        for (int w = 0; w < kPlanWaves; ++w) {
-            const int t = s_wtot[w];
-            if (w < wv) woff += t;
-            tot += t;
-        }
-        int pos = s_carry + woff + incl - nr;
-        if (nr > 0) {
-            const int r0 = first ? o_row0 : p.chunk_trow0[chunk];  // padded rows
-            const int r_end = r0 + rows;
-            // the records of one unit are neighbours: the waves that take them read the same rows at about the same time
-            for (int i = 0; i < nu; ++i)
-                for (int q0 = 0; q0 < nq; q0 += 1 << shift)
-                    reinterpret_cast<int4*>(units)[pos++] = make_int4(r0 + kIvfWideUnit * i, r_end, c, q0 | (min(nq, q0 + (1 << shift)) << 16));
-        }
-        __syncthreads();
-        if (tid == 0) s_carry += tot;
-        __syncthreads();
+        int pos = atomicAdd(&s_cpos[class_of(nq)], nr);  // (the order inside a class is whatever the threads make it)
+        const int r0 = first ? o_row0 : p.chunk_trow0[chunk];  // padded rows
+        const int r_end = r0 + rows;
+        // the records of one unit are neighbours: the waves that take them read the same rows at about the same time
+        for (int i = 0; i < nu; ++i)
+            for (int q0 = 0; q0 < nq; q0 += 1 << shift)
+                reinterpret_cast<int4*>(units)[pos++] = make_int4(r0 + kIvfWideUnit * i, r_end, c, q0 | (min(nq, q0 + (1 << shift)) << 16));
     }
     PLAN_STAMP(3);
     if (tid == 0 && slice == nsl - 1) p.zero[sb * ivf_wide_plan_words(p.nlist) + (int64_t)p.nlist * kIvfWideCntStride] = s_carry;
