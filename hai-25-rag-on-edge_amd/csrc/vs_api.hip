@@ -1108,8 +1108,7 @@ int ivf_group_wide_dev(vs_index* h, const float* q_dev, int nb, int B, int k, in
 #ifdef VS_STAMPS
     m.dbg = g_dbg ? g_dbg + 8192 * 16 : nullptr;
 #endif
-    HIPCHK(vs::launch_merge_layout(m, kIvfWideSubCap, (int64_t)kWideSub * kIvfWideSubCap, s));
-    HIPCHK(vs::launch_ivf_wide_slow(wp, s));
+    HIPCHK(vs::launch_ivf_wide_rank(m, kIvfWideSubCap, (int64_t)kWideSub * kIvfWideSubCap, wp, s));
     stage_mark(h, 3, s);
     return VS_OK;
 }

@@ -354,7 +354,8 @@ hipError_t launch_query_prep(const SeedParams& p, hipStream_t s);  // ||q||^2, q
 hipError_t launch_ivf_wide(const IvfWideParams& p, int num_cus, hipStream_t s);       // tau, plan, scan
 int ivf_wide_grid_x(int num_cus, int n_sb);  // grid.x of the scan
 int ivf_wide_waves(int num_cus, int n_sb);   // its waves = candidate buffers
-hipError_t launch_ivf_wide_slow(const IvfWideParams& p, hipStream_t s);               // after bin + merge
+// merge of the candidate lists (flat layout, see launch_merge_layout) or the exact slow path, per query
+hipError_t launch_ivf_wide_rank(const MergeParams& m, int64_t stride_g, int64_t stride_q, const IvfWideParams& p, hipStream_t s);
 
 struct IvfScanParams {
     const float* vecs;        // [n_rows][128] cluster-reordered (vectors_reordered.npy)

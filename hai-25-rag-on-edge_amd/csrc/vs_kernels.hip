@@ -1838,9 +1838,8 @@ __device__ __forceinline__ void wave_rank_and_emit(const MergeParams& p, int q, 
     if (p.kout & 63) flush(p.kout & ~63, p.kout & 63);
 }
 
-__global__ __launch_bounds__(256) void merge_compact_kernel(const MergeParams p, const MergeLayout L) {
-    __shared__ float cd[kCompactCap];
-    __shared__ int ci[kCompactCap];
+// (cd, ci: kCompactCap words of LDS each, from the kernel)
+__device__ __forceinline__ void merge_compact_body(const MergeParams& p, const MergeLayout& L, float* const cd, int* const ci) {
     __shared__ int cnt;
     __shared__ float wbd[4];
     __shared__ int wbi[4];
@@ -2075,6 +2074,12 @@ __global__ __launch_bounds__(256) void merge_compact_kernel(const MergeParams p,
     }
 }
 
+__global__ __launch_bounds__(256) void merge_compact_kernel(const MergeParams p, const MergeLayout L) {
+    __shared__ float cd[kCompactCap];
+    __shared__ int ci[kCompactCap];
+    merge_compact_body(p, L, cd, ci);
+}
+
 hipError_t launch_merge_layout(const MergeParams& p, int64_t stride_g, int64_t stride_q, hipStream_t s) {
     if (p.kout < 1 || p.G < 1 || p.nq < 1) return hipErrorInvalidValue;
     MergeLayout L{stride_g, stride_q};
@@ -2302,33 +2307,56 @@ __global__ __launch_bounds__(256) void ivf_coarse_mfma_kernel(const float* __res
         scores = mb_adv(scores, y * mb.slab);
     }
     __shared__ float qn_s[kMaxBatch];
+    // Both operands go through LDS: the workgroup's 64 centroids and the batch's queries are read from global memory as
+    // whole rows (a wave instruction = 1 KB in one piece) and the MFMA fragments are cut out of LDS.  Read as fragments
+    // straight from memory, every load instruction touched 64 separate 16-byte pieces 512 bytes apart, and the address
+    // unit, not the arithmetic, set the kernel's time (13 us).  Rows are 132 floats apart in LDS: fragment reads of
+    // 8 neighbouring rows then fall into different banks.
+    constexpr int LD = kDim + 4;
+    __shared__ __attribute__((aligned(16))) float q_s[kMaxBatch * LD];
+    __shared__ __attribute__((aligned(16))) float c_s[64 * LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
-    // both operands are requested first: the centroid tile (A) and the batch's queries as two 16-column B operands; the
-    // norms below then cost no further cache round trip
-    const int row0 = ((int)blockIdx.x * 4 + wave) * 16;  // centroid tile (the centroid array has kScanPadRows spare rows)
-    f32x4 a[8];
+    const int row0 = ((int)blockIdx.x * 4 + wave) * 16;  // this wave's centroid tile (the centroid array has kScanPadRows spare rows)
+    {
+        f32x4 vc[8], vq[4];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) a[c] = *reinterpret_cast<const f32x4*>(cents + (int64_t)(row0 + r) * kDim + 16 * c + 4 * g);
-    const f32x4 cn = *reinterpret_cast<const f32x4*>(cnorm + row0 + 4 * g);  // padded by 64
-    f32x4 qf[2][8];
+        for (int i = 0; i < 8; ++i) {
+            const int idx = tid + 256 * i;  // float4 (row, column) of the 64 x 32 tile
+            vc[i] = *reinterpret_cast<const f32x4*>(cents + ((int64_t)blockIdx.x * 64 + (idx >> 5)) * kDim + 4 * (idx & 31));
+        }
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int qrow = h * 16 + r;
-        const bool qv = qrow < B;
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i;
+            vq[i] = (idx >> 5) < B ? *reinterpret_cast<const f32x4*>(q + (idx >> 5) * kDim + 4 * (idx & 31)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            qf[h][c] = *reinterpret_cast<const f32x4*>(q + (qv ? qrow : 0) * kDim + 16 * c + 4 * g);
-            if (!qv) qf[h][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < 8; ++i) {
+            const int idx = tid + 256 * i;
+            *reinterpret_cast<f32x4*>(c_s + (idx >> 5) * LD + 4 * (idx & 31)) = vc[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i;
+            *reinterpret_cast<f32x4*>(q_s + (idx >> 5) * LD + 4 * (idx & 31)) = vq[i];
         }
     }
+    const f32x4 cn = *reinterpret_cast<const f32x4*>(cnorm + row0 + 4 * g);  // padded by 64
+    __syncthreads();
+    f32x4 a[8], qf[2][8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) a[c] = *reinterpret_cast<const f32x4*>(c_s + (wave * 16 + r) * LD + 16 * c + 4 * g);
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) qf[h][c] = *reinterpret_cast<const f32x4*>(q_s + (h * 16 + r) * LD + 16 * c + 4 * g);  // (rows >= B: zeros)
     {   // ||q||^2 in the reference's AVX2 order (cpu_baseline.cpp:95-114): 8 lanes per query
         const int row = tid >> 3, j = tid & 7;
         float acc = 0.f;
         if (row < B) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const float x = q[row * kDim + 8 * i + j];
+                const float x = q_s[row * LD + 8 * i + j];
                 acc = fmaf(x, x, acc);
             }
         }
@@ -2348,7 +2376,7 @@ __global__ __launch_bounds__(256) void ivf_coarse_mfma_kernel(const float* __res
             if (row < B) {
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
-                    const f32x4 x = *reinterpret_cast<const f32x4*>(q + row * kDim + 16 * j + 4 * v);
+                    const f32x4 x = *reinterpret_cast<const f32x4*>(q_s + row * LD + 16 * j + 4 * v);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int xi = (int)x[e];
@@ -4248,14 +4276,11 @@ __global__ __launch_bounds__(kIvfWideThreads) void ivf_scan_wide_kernel(const Iv
 
 // Exact slow path, one workgroup per query that has no usable bound (or every query when a candidate buffer overflowed:
 // masses of duplicate rows): all rows of the query's probed lists, thread-private sorted lists, ranking through LDS.
-__global__ __launch_bounds__(256) void ivf_wide_slow_kernel(const IvfWideParams p) {
-    const int qg = blockIdx.x;
+// (sd, sp: 256 * 16 words of LDS each, from the kernel)
+__device__ __forceinline__ void ivf_wide_slow_body(const IvfWideParams& p, const int qg, float* const sd, int* const sp) {
     const int batch = qg >> 5, qi = qg & 31;
-    if (batch >= p.n_batches || qi >= p.B) return;
-    if (!p.sink.overflow[0] && !p.slow[qg]) return;
     constexpr int KM = 16;
-    __shared__ float sd[256 * KM];
-    __shared__ int sp[256 * KM];
+    static_assert(256 * KM <= kCompactCap, "the slow path shares the merge's LDS");
     __shared__ float r_d[4];
     __shared__ int r_p[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -4370,8 +4395,23 @@ hipError_t launch_ivf_wide(const IvfWideParams& p, int num_cus, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_ivf_wide_slow(const IvfWideParams& p, hipStream_t s) {
-    hipLaunchKernelGGL(ivf_wide_slow_kernel, dim3(p.n_batches * kMaxBatch), dim3(256), 0, s, p);
+// The ranking of the wide pipeline, one workgroup per query: the merge of the query's candidate lists, or -- for a query
+// without a usable bound, or for every query when a candidate buffer overflowed -- the exact slow path (as one launch:
+// a separate slow-path launch that finds nothing to do still costs its 4 us).
+__global__ __launch_bounds__(256) void ivf_wide_rank_kernel(const MergeParams m, const MergeLayout L, const IvfWideParams p) {
+    const int q = blockIdx.x;  // output query = batch * B + qi
+    const int qg = (q / p.B) * kMaxBatch + q % p.B;
+    __shared__ float cd[kCompactCap];
+    __shared__ int ci[kCompactCap];
+    if (p.sink.overflow[0] || p.slow[qg]) ivf_wide_slow_body(p, qg, cd, ci);  // workgroup-uniform
+    else merge_compact_body(m, L, cd, ci);
+}
+
+hipError_t launch_ivf_wide_rank(const MergeParams& m, int64_t stride_g, int64_t stride_q, const IvfWideParams& p, hipStream_t s) {
+    if (m.kout < 1 || m.G < 1 || m.nq != p.n_batches * p.B || (int64_t)m.G * m.kin > kCompactCap || m.q_group_out != p.B || m.q_group_in != kMaxBatch)
+        return hipErrorInvalidValue;
+    MergeLayout L{stride_g, stride_q};
+    hipLaunchKernelGGL(ivf_wide_rank_kernel, dim3(m.nq), dim3(256), 0, s, m, L, p);
     return hipGetLastError();
 }
 
