@@ -409,8 +409,11 @@ def main():
         sizes = np.diff(off)
         log(f"IVF index: nlist={nlist}, list sizes min/avg/max = {sizes.min()}/{sizes.mean():.0f}/{sizes.max()}, "
             f"built in {time.time() - t0:.1f}s")
-        iout_d = torch.zeros((S * BATCH, K), dtype=torch.float32, device=dev)
-        iout_i = torch.zeros((S * BATCH, K), dtype=torch.int32, device=dev)
+        # one vs_ivf_search_dev_multi call takes up to SI batches (N = 1: the library splits a call into launch groups of
+        # 32 batches and runs consecutive groups on two streams; N > 1: one call = one group = one all-gather)
+        SI = min(n_qbatches, 128) if world == 1 else S
+        iout_d = torch.zeros((SI * BATCH, K), dtype=torch.float32, device=dev)
+        iout_i = torch.zeros((SI * BATCH, K), dtype=torch.int32, device=dev)
         i8_rows = bool(np.all(full == np.floor(full)) and full.min() >= 0 and full.max() <= 255)
         row_bytes = (DIM + 4) if i8_rows else (4 * DIM + 4)
         cn = (cents_h.astype(np.float64) ** 2).sum(1)
@@ -420,10 +423,14 @@ def main():
 
         def ivf_leg(nprobe):
             def ivf_step(i, n):
-                g = group_of(i, n)
-                if g is None:
+                si = i % SI
+                if si != SI - 1 and i != n - 1:
                     return
-                gs, qp = g
+                gs = si + 1
+                qb = (i - si) % n_qbatches
+                if qb + gs > n_qbatches:
+                    qb = 0
+                qp = q_dev.data_ptr() + qb * BATCH * DIM * 4
                 if world == 1:
                     ivf.search_dev_multi(qp, gs, BATCH, K, nprobe, iout_i.data_ptr(), iout_d.data_ptr(), sptr)
                 else:
@@ -437,44 +444,52 @@ def main():
             ivf.prof_enable(False)
             iel = median(ireg)
             info = {"metric": "ivf_qps", "value": round(steps * BATCH / iel, 1), "ms_per_step": round(iel / steps * 1e3, 4),
-                    "nlist": nlist, "nprobe": nprobe, "batch": BATCH}
+                    "nlist": nlist, "nprobe": nprobe, "batch": BATCH, "batches_per_call": min(SI, steps)}
             if world == 1:
                 nrec = 1024
                 ids, _, total = ivf.searchBatch(queries[:nrec], nrec, K, nprobe)
                 info["recall_at_1"] = float(np.mean(ids[:, 0] == gt_ids[:, 0]))          # main_ivf.cpp:52-59 with k = 1
                 info["recall_at_5"] = float(np.mean([len(set(ids[i]) & set(gt_ids[i])) / K for i in range(nrec)]))
                 info["avg_candidates"] = total / nrec
-                # The list-major scan reads every probed list ONCE per batch, so its algorithmic bytes are
-                # row_bytes * rows of the distinct lists probed by the batch (+ 4 B per (query, row) score written),
-                # not SURVEY 8(d)'s per-query (4d + 8) * S_q, which assumes one pass per query.
-                uniq_rows, nb_s = 0, 8
-                for b0 in range(nb_s):
-                    qs = queries[b0 * BATCH:(b0 + 1) * BATCH].astype(np.float64)
-                    pr = np.argsort(cn[None, :] - 2.0 * qs @ cents_h.astype(np.float64).T, axis=1)[:, :nprobe]
-                    uniq_rows += int(sizes[np.unique(pr)].sum())
-                uniq_rows /= nb_s
-                ib = row_bytes * uniq_rows + 4 * info["avg_candidates"] * BATCH   # per batch
-                # kernel time per batch: every launch of the prof window (warm-up + R regions), divided by the batches
-                # they held -- launches of different sizes are never averaged as if they were equal
-                ks_batch = (okern_ms * 1e-3) / (warmup + len(ireg) * steps) if okern_n else 0.0
-                ach = ib / ks_batch / 1e9 if ks_batch > 0 else None
+                # The list-major scan reads every list probed by the launch group (S batches = S * BATCH queries share ONE
+                # pass) once, so its algorithmic bytes per launch are row_bytes * rows of the distinct lists the group
+                # probes + 4 B per (query, probe) slot-table entry + the group's queries, not SURVEY 8(d)'s per-query
+                # (4d + 8) * S_q, which assumes one pass per query.
+                cents64 = cents_h.astype(np.float64)
+
+                def launch_bytes(gs):
+                    gq = queries[:gs * BATCH].astype(np.float64)
+                    pr = np.argsort(cn[None, :] - 2.0 * gq @ cents64.T, axis=1)[:, :nprobe]
+                    rows = int(sizes[np.unique(pr)].sum())
+                    return row_bytes * rows + 4 * pr.size + len(gq) * (DIM + 16 if i8_rows else 4 * DIM + 16), rows
+
+                def launches_of(n):  # sizes of the launch groups of a run of n steps: calls of <= SI batches, groups of <= 32
+                    calls = [SI] * (n // SI) + ([n % SI] if n % SI else [])
+                    return [g for c in calls for g in [32] * (c // 32) + ([c % 32] if c % 32 else [])]
+
+                window = launches_of(warmup) + launches_of(steps) * len(ireg)   # every launch of the prof window
+                per_size = {gs: launch_bytes(gs) for gs in set(window)}
+                ib = sum(per_size[gs][0] for gs in window) / max(len(window), 1)   # mean algorithmic bytes per launch
+                uniq_rows = per_size[max(per_size)][1]
+                ks_launch = (okern_ms * 1e-3) / okern_n if okern_n else 0.0       # mean kernel time per launch
+                ach = ib / ks_launch / 1e9 if ks_launch > 0 else None
                 itraffic = None
                 ipath = os.path.join(ROOT, "profiles", "traffic_ivf_list_scan.json")
-                if os.path.exists(ipath) and n_rows == N_BASE and i8_rows and nprobe == NPROBE:
+                if os.path.exists(ipath) and n_rows == N_BASE and i8_rows and nprobe == NPROBE and set(window) == {32}:
                     itraffic = json.load(open(ipath)).get("hbm_bytes_per_launch_32_batches")
-                    itraffic = int(itraffic * S / 32) if itraffic else None
                 frac = round(ach / HBM_PEAK_GBS, 4) if ach else None
                 info["roofline"] = {"bound": "hbm", "achieved": round(ach, 1) if ach else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                     "frac": frac if (frac is not None and frac <= 1.0) else None, "traffic": itraffic,
-                                    "kernel": "vs::ivf_unit_scan_kernel", "kernel_us_per_batch": round(ks_batch * 1e6, 2),
-                                    "kernel_us": round(ks_batch * S * 1e6, 2), "batches_per_launch": S,
-                                    "algorithmic_bytes_per_launch": int(ib * S), "row_bytes": row_bytes,
-                                    "distinct_rows_per_batch": int(uniq_rows),
-                                    "per_query_pass_bytes": int((4 * DIM + 8) * info["avg_candidates"] * BATCH),
-                                    "note": "list-major scan on the exact int8 copy: the 132 MB of rows stay in the 256 MB "
-                                            "Infinity Cache across batches, so delivery (L2 / Infinity Cache -> CU) binds, not "
-                                            "HBM; fraction quoted against the HBM peak as the reference roof" if i8_rows else
-                                            "fp32 rows streamed from HBM"}
+                                    "kernel": "vs::ivf_scan_wide_kernel", "kernel_us": round(ks_launch * 1e6, 2),
+                                    "launches": int(okern_n), "batches_per_launch": round(sum(window) / max(len(window), 1), 2),
+                                    "algorithmic_bytes_per_launch": int(ib), "row_bytes": row_bytes,
+                                    "distinct_rows_per_launch": uniq_rows,
+                                    "per_query_pass_bytes": int((4 * DIM + 8) * info["avg_candidates"] * BATCH * max(per_size)),
+                                    "note": "one list-major pass per launch group over the tiled exact int8 copy (128 B of row + "
+                                            "4 B of row term per row); the 132 MB of rows fit the 256 MB Infinity Cache, so "
+                                            "repeated launches are served from there and the HBM counters can read below the "
+                                            "algorithmic bytes; fraction quoted against the HBM peak as the reference roof"
+                                            if i8_rows else "fp32 rows streamed from HBM"}
             log(f"IVF nprobe={nprobe}: {info['value']:.0f} QPS, recall@1={info.get('recall_at_1')}, "
                 f"recall@5={info.get('recall_at_5')}, avg candidates={info.get('avg_candidates')}")
             return info

@@ -120,7 +120,6 @@ struct vs_index {
         float* wcand_d = nullptr;    // [kMaxMulti][32][kWideCap]
         int32_t* wcand_i = nullptr;
         int4* wbuf = nullptr;        // [256 * 8][kWideWaveCap] wave-private candidate buffers of the scan
-        int32_t* wcount = nullptr;   // [256 * 8]
     };
     Lane lane[kMaxLanes];
     int n_lanes = 1;
@@ -181,11 +180,14 @@ struct vs_index {
         int8_t* q8 = nullptr;       // [1024][128]
         int32_t* qterm = nullptr;   // [1024]
         int4* wbuf = nullptr;       // [waves][kIvfWideWaveCap]
-        int32_t* wcount = nullptr;
         int n_waves = 0;
         float* cand_d = nullptr;    // [1024][16][kIvfWideSubCap]
         int32_t* cand_i = nullptr;
-    } wide;
+        char* slab = nullptr;       // per batch: probes [32][kMaxNprobe] | coarse scores [32][nlist padded]
+        long long slab_stride = 0, off_scores = 0;
+    } wide[2];                      // two scratch sets: consecutive launch groups of one call run on two streams
+    hipStream_t wide_stream[2] = {};
+    hipEvent_t wide_fork = nullptr, wide_join[2] = {};
     hipStream_t ivf_stream[8] = {};
     hipEvent_t ivf_fork = nullptr, ivf_join[8] = {};
     int64_t n_units_max = 0;
@@ -259,7 +261,7 @@ void free_all(vs_index* h) {
         if (L.seed_qnorm) (void)hipFree(L.seed_qnorm);
         if (L.seed_wmin) (void)hipFree(L.seed_wmin);
         if (L.tau0) (void)hipFree(L.tau0);
-        void* wide[] = {L.q8, L.qterm, L.wcnt, L.wcand_d, L.wcand_i, L.wbuf, L.wcount};
+        void* wide[] = {L.q8, L.qterm, L.wcnt, L.wcand_d, L.wcand_i, L.wbuf};
         for (void* w : wide)
             if (w) (void)hipFree(w);
         if (L.done_ev) (void)hipEventDestroy(L.done_ev);
@@ -286,10 +288,16 @@ void free_all(vs_index* h) {
         if (h->ivf_fork) (void)hipEventDestroy(h->ivf_fork);
         if (h->mb_slab) (void)hipFree(h->mb_slab);
         if (h->mb_zslab) (void)hipFree(h->mb_zslab);
-        void* wd[] = {h->wide.lq, h->wide.zero, h->wide.units, h->wide.tau, h->wide.qnorm, h->wide.q8, h->wide.qterm, h->wide.wbuf,
-                      h->wide.wcount, h->wide.cand_d, h->wide.cand_i};
-        for (void* w : wd)
-            if (w) (void)hipFree(w);
+        for (auto& W : h->wide) {
+            void* wd[] = {W.lq, W.zero, W.units, W.tau, W.qnorm, W.q8, W.qterm, W.wbuf, W.cand_d, W.cand_i, W.slab};
+            for (void* w : wd)
+                if (w) (void)hipFree(w);
+        }
+        for (int i = 0; i < 2; ++i) {
+            if (h->wide_stream[i]) (void)hipStreamDestroy(h->wide_stream[i]);
+            if (h->wide_join[i]) (void)hipEventDestroy(h->wide_join[i]);
+        }
+        if (h->wide_fork) (void)hipEventDestroy(h->wide_fork);
     }
     for (auto& ps : h->prof_slot)
         for (auto e : ps.ev) (void)hipEventDestroy(e);
@@ -577,7 +585,6 @@ int ensure_wide(vs_index::Lane& L) {
     if ((rc = dev_alloc(&L.wcand_d, (size_t)kMaxMulti * 32 * kWideSub * kWideCap))) return rc;
     if ((rc = dev_alloc(&L.wcand_i, (size_t)kMaxMulti * 32 * kWideSub * kWideCap))) return rc;
     if ((rc = dev_alloc(&L.wbuf, (size_t)vs::kSlotStride * vs::kScanWaves * kWideWaveCap))) return rc;
-    if ((rc = dev_alloc(&L.wcount, (size_t)vs::kSlotStride * vs::kScanWaves))) return rc;
     return VS_OK;
 }
 
@@ -671,7 +678,6 @@ int bf_launch(vs_index* h, vs_index::Lane& L, const float* q_dev, int nb, int B,
     if (stream) {
         vs::CandSink sink{};
         sink.wbuf = L.wbuf;
-        sink.wcount = L.wcount;
         sink.wcap = kWideWaveCap;
         sink.overflow = overflow;
         sink.cnt = L.wcnt + 64;
@@ -957,14 +963,21 @@ int g_ivf_multi = [] {
 
 int ensure_ivf_mb(vs_index* h, int nprobe, hipStream_t s);
 // tuning knob (VSEARCH_IVF_WIDE=0): launch groups use the per-batch list-major pipeline instead of the wide one
+// tuning knob (VSEARCH_IVF_WIDE_LANES=1): vs_ivf_search_dev_multi keeps all launch groups of a call on the caller's stream
+// instead of alternating them between two streams
+int g_ivf_wide_lanes = [] {
+    const char* e = getenv("VSEARCH_IVF_WIDE_LANES");
+    return e ? atoi(e) : 2;
+}();
+
 int g_ivf_wide = [] {
     const char* e = getenv("VSEARCH_IVF_WIDE");
     return e ? atoi(e) : 1;
 }();
 
-int ensure_ivf_wide(vs_index* h) {
-    vs_index::IvfWide& W = h->wide;
-    if (W.lq) return VS_OK;
+int ensure_ivf_wide(vs_index* h, int lane) {
+    vs_index::IvfWide& W = h->wide[lane];
+    if (W.slab) return VS_OK;
     int rc;
     const size_t nq = (size_t)kMaxMulti * 32;
     const int n_sb_max = (kMaxMulti + vs::kIvfWideBatches - 1) / vs::kIvfWideBatches;
@@ -980,20 +993,21 @@ int ensure_ivf_wide(vs_index* h) {
     if ((rc = dev_alloc(&W.q8, nq * vs::kDim))) return rc;
     if ((rc = dev_alloc(&W.qterm, nq))) return rc;
     if ((rc = dev_alloc(&W.wbuf, (size_t)W.n_waves * kIvfWideWaveCap))) return rc;
-    if ((rc = dev_alloc(&W.wcount, (size_t)W.n_waves))) return rc;
     if ((rc = dev_alloc(&W.cand_d, nq * kWideSub * kIvfWideSubCap))) return rc;
     if ((rc = dev_alloc(&W.cand_i, nq * kWideSub * kIvfWideSubCap))) return rc;
+    W.off_scores = (32ll * kMaxNprobe * 4 + 255) & ~255ll;
+    W.slab_stride = (W.off_scores + 32ll * ((h->nlist + 63) & ~63) * 4 + 255) & ~255ll;
+    if ((rc = dev_alloc(&W.slab, (size_t)W.slab_stride * kMaxMulti))) return rc;
     return VS_OK;
 }
 
 // nb <= kMaxMulti independent batches through the wide pipeline: query preparation, coarse (MFMA) + pick per batch,
 // bounds, then per super-batch of 8 batches ONE list-major pass with candidates to the sink; binning, ranking, and the
 // exact slow path for queries without a bound (or for everybody if a candidate buffer overflowed).
-int ivf_group_wide_dev(vs_index* h, const float* q_dev, int nb, int B, int k, int nprobe, float* out_d, int32_t* out_i, hipStream_t s) {
-    int rc = ensure_ivf_mb(h, nprobe, s);
+int ivf_group_wide_dev(vs_index* h, int lane, const float* q_dev, int nb, int B, int k, int nprobe, float* out_d, int32_t* out_i, hipStream_t s) {
+    int rc = ensure_ivf_wide(h, lane);
     if (rc) return rc;
-    if ((rc = ensure_ivf_wide(h))) return rc;
-    vs_index::IvfWide& W = h->wide;
+    vs_index::IvfWide& W = h->wide[lane];
     const size_t nq = (size_t)kMaxMulti * 32;
     int32_t* const z_plan = W.zero;                                   // [n_sb_max][ivf_wide_plan_words]
     const int n_sb_max = (kMaxMulti + vs::kIvfWideBatches - 1) / vs::kIvfWideBatches;
@@ -1003,16 +1017,14 @@ int ivf_group_wide_dev(vs_index* h, const float* q_dev, int nb, int B, int k, in
     int32_t* const z_cnt = z_ovf + 64;                                // [1024][16]
     HIPCHK(hipMemsetAsync(W.zero, 0, W.zero_words * sizeof(int32_t), s));
     vs::IvfMulti mb{};
-    mb.slab = h->mb_slab_stride;
-    mb.zslab = h->mb_zslab_stride * (long long)sizeof(int32_t);
+    mb.slab = W.slab_stride;
     mb.q = (long long)B * vs::kDim * sizeof(float);
-    char* sl = h->mb_slab;
-    int32_t* probes = reinterpret_cast<int32_t*>(sl + h->mb_off_probes);
+    char* sl = W.slab;
+    int32_t* probes = reinterpret_cast<int32_t*>(sl);
     stage_mark(h, 0, s);
     vs::IvfGroup grp{};
     grp.offsets = h->d_offsets;
-    grp.lcnt = z_plan;
-    grp.qoff = reinterpret_cast<int32_t*>(sl + h->mb_off_qoff);
+    grp.lcnt = z_plan;  // (non-null: the pick kernel goes on to the grouping; its wide branch needs neither lcnt nor qoff)
     grp.mb = mb;
     // the coarse kernel also prepares the queries for the int8 paths, the pick kernel also fills the lists' slot tables
     // (the candidate statistic is added up by the plan kernel: one atomic per launch instead of one per query)
@@ -1027,7 +1039,7 @@ int ivf_group_wide_dev(vs_index* h, const float* q_dev, int nb, int B, int k, in
     grp.dbg = g_dbg ? g_dbg + 4096 * 16 : nullptr;
 #endif
     HIPCHK(vs::launch_ivf_coarse_pick(q_dev, B, h->d_centroids, h->d_cnorm, h->nlist, nprobe, h->metric,
-                                      reinterpret_cast<float*>(sl + h->mb_off_scores), (h->nlist + 63) & ~63, probes, grp, s, nb));
+                                      reinterpret_cast<float*>(sl + W.off_scores), (h->nlist + 63) & ~63, probes, grp, s, nb));
     stage_mark(h, 1, s);
     vs::IvfWideParams wp{};
 #ifdef VS_STAMPS
@@ -1073,7 +1085,6 @@ int ivf_group_wide_dev(vs_index* h, const float* q_dev, int nb, int B, int k, in
     wp.tau = W.tau;
     wp.slow = z_slow;
     wp.sink.wbuf = W.wbuf;
-    wp.sink.wcount = W.wcount;
     wp.sink.wcap = kIvfWideWaveCap;
     wp.sink.overflow = z_ovf;
     wp.sink.cnt = z_cnt;
@@ -1087,9 +1098,10 @@ int ivf_group_wide_dev(vs_index* h, const float* q_dev, int nb, int B, int k, in
     wp.out_d = out_d;
     wp.out_i = out_i;
     wp.id_map = h->d_r2o;
-    stage_mark(h, 2, s);  // (grouping is part of the wide launch sequence below: it is charged to the fine search)
-    prof_begin(h, 1, s);
-    HIPCHK(vs::launch_ivf_wide(wp, h->num_cus, s));
+    HIPCHK(vs::launch_ivf_wide_bounds_plan(wp, s));
+    stage_mark(h, 2, s);  // "gather" (IVFIndex.cpp's second stage) = bounds + plan here; the fine search is the scan + ranking
+    prof_begin(h, 1, s);  // (the profiling window holds the scan kernel alone)
+    HIPCHK(vs::launch_ivf_wide_scan(wp, h->num_cus, s));
     prof_end(h, 1, s);
     vs::MergeParams m{};
     m.part_d = W.cand_d;
@@ -1147,9 +1159,8 @@ int ensure_ivf_mb(vs_index* h, int nprobe, hipStream_t s) {
 }
 
 // nb <= kMaxMulti independent batches, every kernel launched once for all of them (blockIdx.y = batch)
-int ivf_group_wide_dev(vs_index* h, const float* q_dev, int nb, int B, int k, int nprobe, float* out_d, int32_t* out_i, hipStream_t s);
 int ivf_group_dev(vs_index* h, const float* q_dev, int nb, int B, int k, int nprobe, float* out_d, int32_t* out_i, hipStream_t s) {
-    if (g_ivf_wide) return ivf_group_wide_dev(h, q_dev, nb, B, k, nprobe, out_d, out_i, s);
+    if (g_ivf_wide) return ivf_group_wide_dev(h, 0, q_dev, nb, B, k, nprobe, out_d, out_i, s);
     int rc = ensure_ivf_mb(h, nprobe, s);
     if (rc) return rc;
     HIPCHK(hipMemsetAsync(h->mb_zslab, 0, (size_t)h->mb_zslab_stride * nb * sizeof(int32_t), s));
@@ -2246,6 +2257,31 @@ int vs_ivf_search_dev_multi(vs_index* h, const float* queries_dev, int n_batches
                                ids_dev + (size_t)b * B * k, user, nullptr);
         return rc ? rc : order_end(h, user);
     }
+    if (ivf_multi_ok(h, k) && g_ivf_wide && g_ivf_wide_lanes > 1 && n_batches > kMaxMulti) {
+        // Launch groups of kMaxMulti batches alternate between two streams with a scratch set each: a group is a chain of
+        // dependent kernels, several of them small (coarse, pick, bounds + plan), and the next group's small kernels fill
+        // the device beside the current group's scan and ranking.
+        if (!h->wide_fork) {
+            HIPCHK(hipEventCreateWithFlags(&h->wide_fork, hipEventDisableTiming));
+            for (int i = 0; i < 2; ++i) {
+                HIPCHK(hipStreamCreateWithFlags(&h->wide_stream[i], hipStreamNonBlocking));
+                HIPCHK(hipEventCreateWithFlags(&h->wide_join[i], hipEventDisableTiming));
+            }
+        }
+        HIPCHK(hipEventRecord(h->wide_fork, user));
+        for (int i = 0; i < 2; ++i) HIPCHK(hipStreamWaitEvent(h->wide_stream[i], h->wide_fork, 0));
+        int g = 0;
+        for (int b0 = 0; b0 < n_batches && !rc; b0 += kMaxMulti, ++g) {
+            const int nb = std::min(kMaxMulti, n_batches - b0);
+            rc = ivf_group_wide_dev(h, g & 1, queries_dev + (size_t)b0 * B * vs::kDim, nb, B, k, nprobe, dists_dev + (size_t)b0 * B * k,
+                                    ids_dev + (size_t)b0 * B * k, h->wide_stream[g & 1]);
+        }
+        for (int i = 0; i < 2; ++i) {  // (also after an error: the user's stream must not run ahead of what was enqueued)
+            HIPCHK(hipEventRecord(h->wide_join[i], h->wide_stream[i]));
+            HIPCHK(hipStreamWaitEvent(user, h->wide_join[i], 0));
+        }
+        return rc ? rc : order_end(h, user);
+    }
     if (ivf_multi_ok(h, k)) {
         // every kernel once per group of up to kMaxMulti batches
         for (int b0 = 0; b0 < n_batches && !rc; b0 += kMaxMulti) {
@@ -2377,28 +2413,24 @@ int vs_ivf_search(vs_index* h, const float* queries_host, int64_t nq, int k, int
     });
 }
 
-// diagnostic (not part of the ABI header): state of the wide IVF pipeline after the last launch group
+#ifdef VS_STAMPS
+// diagnostic builds only (make EXTRA=-DVS_STAMPS; not part of the ABI): state of the wide IVF pipeline after the last launch group
 __attribute__((visibility("default"))) int vs_debug_ivf_wide_stats(vs_index* h, int64_t* out /*[8]*/) {
-    if (!h || !h->wide.lq) return VS_ERR_INVALID;
+    if (!h || !h->wide[0].lq) return VS_ERR_INVALID;
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
     const size_t nq = (size_t)kMaxMulti * 32;
     const int n_sb_max = (kMaxMulti + vs::kIvfWideBatches - 1) / vs::kIvfWideBatches;
-    std::vector<int32_t> z(h->wide.zero_words), wc((size_t)h->wide.n_waves);
+    std::vector<int32_t> z(h->wide[0].zero_words);
     std::vector<float> tau(nq);
-    HIPCHK(hipMemcpy(z.data(), h->wide.zero, z.size() * 4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(wc.data(), h->wide.wcount, wc.size() * 4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(tau.data(), h->wide.tau, nq * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(z.data(), h->wide[0].zero, z.size() * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(tau.data(), h->wide[0].tau, nq * 4, hipMemcpyDeviceToHost));
     const int32_t* slow = z.data() + (size_t)n_sb_max * vs::ivf_wide_plan_words(h->nlist);
     const int32_t* ovf = slow + nq;
     const int32_t* cnt = ovf + 64;
     int64_t nslow = 0, total = 0, maxw = 0, maxsub = 0, ninf = 0;
     for (size_t i = 0; i < nq; ++i) nslow += slow[i] != 0;
     for (size_t i = 0; i < nq; ++i) ninf += !(tau[i] < 3e38f);
-    for (int32_t v : wc) {
-        total += v;
-        maxw = std::max<int64_t>(maxw, v);
-    }
     for (size_t i = 0; i < nq * kWideSub; ++i) maxsub = std::max<int64_t>(maxsub, cnt[i]);
     out[0] = ovf[0];
     out[1] = nslow;
@@ -2423,6 +2455,7 @@ __attribute__((visibility("default"))) int vs_debug_buffer(int* dev_ptr) {
     g_dbg = dev_ptr;
     return VS_OK;
 }
+#endif
 
 // --------------------------------------------------------------------------------------- multi-GPU
 int vs_topk_merge_dev(const float* dists_dev, const int32_t* ids_dev, int G, int B, int kin, int64_t stride_g,

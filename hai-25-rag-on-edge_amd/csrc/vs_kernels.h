@@ -96,7 +96,6 @@ hipError_t launch_seed(const SeedParams& p, hipStream_t s);
 // every hit), binned into per-query lists by a small launch after the scan.
 struct CandSink {
     int4* wbuf;              // [grid * 8][wcap] x (query = batch * 32 + q, dist bits, id, 0)
-    int32_t* wcount;         // [grid * 8] fill of every wave buffer (may exceed wcap)
     int wcap;
     int32_t* overflow;       // [1] (pre-set to 0): a wave buffer or a query list overflowed -> the launch's fallback kernels
                              //     (the per-batch scan + its merge, enqueued behind with run_if = overflow) produce the result
@@ -147,7 +146,6 @@ struct StreamParams {
     CandSink sink;
 };
 hipError_t launch_scan_f32_stream(const StreamParams& p, int grid, hipStream_t s);
-hipError_t launch_cand_bin(const CandSink& sink, int n_buffers, hipStream_t s);  // after a streaming scan: its wave buffers
 
 // Cross-workgroup merge of sorted partial lists -> [nq][kout] + tie flags (+ seed thresholds).
 struct MergeParams {
@@ -327,7 +325,7 @@ struct IvfWideParams {
     const float* q;           // batch b's [B][128] at (char*)q + b * q_batch_bytes
     long long q_batch_bytes;
     int n_batches, B;
-    const float* qnorm;       // [n_batches][32]   | from seed_qnorm_kernel (launch_query_prep)
+    const float* qnorm;       // [n_batches][32]   | from ivf_coarse_mfma_kernel
     const int8_t* q8;         // [n_batches][32][128]
     const int32_t* qterm;     // [n_batches][32]
     const int32_t* invalid;   // [n_batches] (pre-set to 0) a query of the batch is not byte valued
@@ -350,8 +348,8 @@ struct IvfWideParams {
     int32_t* dbg;             // diagnostic builds (-DVS_STAMPS) only: per-workgroup time stamps, dbg[0..] see ivf_scan_wide_kernel
     int diag;                 // diagnostic builds only: bit 0 no column blocks, bit 1 every unit = the wave's first, bit 2 no binning
 };
-hipError_t launch_query_prep(const SeedParams& p, hipStream_t s);  // ||q||^2, queries as bytes, constant terms, validity
-hipError_t launch_ivf_wide(const IvfWideParams& p, int num_cus, hipStream_t s);       // tau, plan, scan
+hipError_t launch_ivf_wide_bounds_plan(const IvfWideParams& p, hipStream_t s);        // bounds (tau) and the plan, one launch
+hipError_t launch_ivf_wide_scan(const IvfWideParams& p, int num_cus, hipStream_t s);  // the list-major scan
 int ivf_wide_grid_x(int num_cus, int n_sb);  // grid.x of the scan
 int ivf_wide_waves(int num_cus, int n_sb);   // its waves = candidate buffers
 // merge of the candidate lists (flat layout, see launch_merge_layout) or the exact slow path, per query

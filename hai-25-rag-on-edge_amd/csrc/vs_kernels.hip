@@ -1184,34 +1184,6 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_i8w_kernel(const WidePar
     sink_bin_wave(p.sink, (int)blockIdx.x * kScanWaves + wave, wbase, lane);  // no separate binning launch
 }
 
-// Candidates of a streaming scan, wave buffers -> per-query lists (the only atomics of the path, massively parallel here).
-__global__ __launch_bounds__(256) void cand_bin_kernel(const CandSink p, int n_buffers) {
-    const int wb = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);  // one wave per wave buffer (a few dozen entries each)
-    if (wb >= n_buffers) return;
-    const int lane = threadIdx.x & 63;
-    const int n = p.wcount[wb];
-    if (n > p.wcap) {
-        if (lane == 0) p.overflow[0] = 1;  // entries were dropped: the fallback kernels behind take over
-        return;
-    }
-    const int4* src = p.wbuf + (int64_t)wb * p.wcap;
-    // (a hash: neighbouring buffers hold neighbouring units of one list, whose candidates belong to the same queries)
-    const int sub = (int)((((unsigned)wb * 2654435761u) >> 16) % (unsigned)p.nsub);
-    for (int e = lane; e < n; e += 64) {
-        const int4 c = src[e];
-        const int64_t lst = (int64_t)c.x * p.nsub + sub;
-        const int pos = atomicAdd(p.cnt + lst, 1);
-        if (pos < p.cap) {
-            p.cand_d[lst * p.cap + pos] = __builtin_bit_cast(float, c.y);
-            p.cand_i[lst * p.cap + pos] = c.z;
-        } else if (p.slow) {
-            p.slow[c.x] = 1;    // more rows under this query's bound than its lists hold: the exact slow path takes it
-        } else {
-            p.overflow[0] = 1;  // ... or, where there is no per-query slow path, the launch's fallback kernels
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // Streaming fp32 scan (see StreamParams): scan_kernel's fp32 data path and arithmetic, the wide int8 scan's organisation.
 // ------------------------------------------------------------------------------------------------
@@ -1397,12 +1369,6 @@ hipError_t launch_scan_f32_stream(const StreamParams& p, int grid, hipStream_t s
         attr_set[dev] = true;
     }
     hipLaunchKernelGGL(scan_f32s_kernel, dim3(grid), dim3(kScanThreads), kWideLds, s, p);
-    return hipGetLastError();
-}
-
-// wave buffers -> per-query lists (after a streaming scan that filled `n_buffers` of them)
-hipError_t launch_cand_bin(const CandSink& sink, int n_buffers, hipStream_t s) {
-    hipLaunchKernelGGL(cand_bin_kernel, dim3((n_buffers + 3) / 4), dim3(256), 0, s, sink, n_buffers);
     return hipGetLastError();
 }
 
@@ -3626,11 +3592,6 @@ __global__ __launch_bounds__(256) void ivf_select_kernel(IvfSelectParams p) {
 // ------------------------------------------------------------------------------------------------
 // Wide IVF pipeline (see IvfWideParams).
 // ------------------------------------------------------------------------------------------------
-hipError_t launch_query_prep(const SeedParams& p, hipStream_t s) {
-    hipLaunchKernelGGL(seed_qnorm_kernel, dim3(p.n_batches), dim3(256), 0, s, p);
-    return hipGetLastError();
-}
-
 // Bound of a query = k-th smallest distance among the first kIvfTauRows rows of each of its two nearest resident lists
 // (those rows are candidates, so k of them at most that far bound the k-th best of all candidates; two lists because the
 // query's own neighbourhood is not always in the nearest one).  One wave per query: 16-row MFMA tiles with the query in
@@ -4378,11 +4339,17 @@ __device__ __forceinline__ void ivf_wide_slow_body(const IvfWideParams& p, const
 int ivf_wide_grid_x(int num_cus, int n_sb) { return std::max(16, num_cus / n_sb); }
 int ivf_wide_waves(int num_cus, int n_sb) { return ivf_wide_grid_x(num_cus, n_sb) * n_sb * kIvfWideWaves; }
 
-hipError_t launch_ivf_wide(const IvfWideParams& p, int num_cus, hipStream_t s) {
+hipError_t launch_ivf_wide_bounds_plan(const IvfWideParams& p, hipStream_t s) {
     if (p.nlist > kIvfFastNlist || p.nprobe > kIvfMaxProbe || p.k > 16) return hipErrorInvalidValue;
     const int n_sb = (p.n_batches + kIvfWideBatches - 1) / kIvfWideBatches;
     const int n_plan = std::max(4, 16 / n_sb);  // (every planning workgroup reads all pair counters, a cache line each)
     hipLaunchKernelGGL(ivf_tau_plan_kernel, dim3(n_plan * n_sb + (p.n_batches * kMaxBatch + 1) / 2), dim3(256), 0, s, p, n_plan, n_sb);
+    return hipGetLastError();
+}
+
+hipError_t launch_ivf_wide_scan(const IvfWideParams& p, int num_cus, hipStream_t s) {
+    if (p.nlist > kIvfFastNlist || p.nprobe > kIvfMaxProbe || p.k > 16) return hipErrorInvalidValue;
+    const int n_sb = (p.n_batches + kIvfWideBatches - 1) / kIvfWideBatches;
     static bool attr_set[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
