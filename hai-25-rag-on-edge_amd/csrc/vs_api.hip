@@ -40,6 +40,7 @@ constexpr int kMaxNprobe = 256;
 constexpr int kSlotWords = 32 * vs::kIvfSlots;  // per-batch slot minima of the IVF list scan (in the zeroed block)
 constexpr int kMaxLanes = 4;
 constexpr int kMaxMulti = 32;  // batches per persistent scan launch
+constexpr int kWideLanesMax = 4;  // streams (and scratch sets) the launch groups of one wide IVF call may be dealt to
 constexpr int kWideWaveCap = 1024;  // entries per wave buffer of the wide int8 scan (expected fill: about 100 per launch)
 constexpr int kWideSub = 16;      // sub-lists per query of the streaming scans' candidate lists
 constexpr int kWideCap = 128;     // entries per sub-list (2048 per query; more: the per-batch scan behind takes over)
@@ -185,9 +186,9 @@ struct vs_index {
         int32_t* cand_i = nullptr;
         char* slab = nullptr;       // per batch: probes [32][kMaxNprobe] | coarse scores [32][nlist padded]
         long long slab_stride = 0, off_scores = 0;
-    } wide[2];                      // two scratch sets: consecutive launch groups of one call run on two streams
-    hipStream_t wide_stream[2] = {};
-    hipEvent_t wide_fork = nullptr, wide_join[2] = {};
+    } wide[kWideLanesMax];          // scratch sets: consecutive launch groups of one call run on different streams
+    hipStream_t wide_stream[kWideLanesMax] = {};
+    hipEvent_t wide_fork = nullptr, wide_join[kWideLanesMax] = {};
     hipStream_t ivf_stream[8] = {};
     hipEvent_t ivf_fork = nullptr, ivf_join[8] = {};
     int64_t n_units_max = 0;
@@ -293,7 +294,7 @@ void free_all(vs_index* h) {
             for (void* w : wd)
                 if (w) (void)hipFree(w);
         }
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < kWideLanesMax; ++i) {
             if (h->wide_stream[i]) (void)hipStreamDestroy(h->wide_stream[i]);
             if (h->wide_join[i]) (void)hipEventDestroy(h->wide_join[i]);
         }
@@ -2258,25 +2259,26 @@ int vs_ivf_search_dev_multi(vs_index* h, const float* queries_dev, int n_batches
         return rc ? rc : order_end(h, user);
     }
     if (ivf_multi_ok(h, k) && g_ivf_wide && g_ivf_wide_lanes > 1 && n_batches > kMaxMulti) {
-        // Launch groups of kMaxMulti batches alternate between two streams with a scratch set each: a group is a chain of
+        // Launch groups of kMaxMulti batches are dealt to two (VSEARCH_IVF_WIDE_LANES) streams with a scratch set each: a group is a chain of
         // dependent kernels, several of them small (coarse, pick, bounds + plan), and the next group's small kernels fill
         // the device beside the current group's scan and ranking.
+        const int lanes = std::min({g_ivf_wide_lanes, kWideLanesMax, (n_batches + kMaxMulti - 1) / kMaxMulti});
         if (!h->wide_fork) {
             HIPCHK(hipEventCreateWithFlags(&h->wide_fork, hipEventDisableTiming));
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < kWideLanesMax; ++i) {
                 HIPCHK(hipStreamCreateWithFlags(&h->wide_stream[i], hipStreamNonBlocking));
                 HIPCHK(hipEventCreateWithFlags(&h->wide_join[i], hipEventDisableTiming));
             }
         }
         HIPCHK(hipEventRecord(h->wide_fork, user));
-        for (int i = 0; i < 2; ++i) HIPCHK(hipStreamWaitEvent(h->wide_stream[i], h->wide_fork, 0));
+        for (int i = 0; i < lanes; ++i) HIPCHK(hipStreamWaitEvent(h->wide_stream[i], h->wide_fork, 0));
         int g = 0;
         for (int b0 = 0; b0 < n_batches && !rc; b0 += kMaxMulti, ++g) {
             const int nb = std::min(kMaxMulti, n_batches - b0);
-            rc = ivf_group_wide_dev(h, g & 1, queries_dev + (size_t)b0 * B * vs::kDim, nb, B, k, nprobe, dists_dev + (size_t)b0 * B * k,
-                                    ids_dev + (size_t)b0 * B * k, h->wide_stream[g & 1]);
+            rc = ivf_group_wide_dev(h, g % lanes, queries_dev + (size_t)b0 * B * vs::kDim, nb, B, k, nprobe, dists_dev + (size_t)b0 * B * k,
+                                    ids_dev + (size_t)b0 * B * k, h->wide_stream[g % lanes]);
         }
-        for (int i = 0; i < 2; ++i) {  // (also after an error: the user's stream must not run ahead of what was enqueued)
+        for (int i = 0; i < lanes; ++i) {  // (also after an error: the user's stream must not run ahead of what was enqueued)
             HIPCHK(hipEventRecord(h->wide_join[i], h->wide_stream[i]));
             HIPCHK(hipStreamWaitEvent(user, h->wide_join[i], 0));
         }
