@@ -168,8 +168,8 @@ struct vs_index {
     int mb_nbk = 0;  // per-query score-block minima (32 scores per block) of the list scan
     long long mb_off_lq = 0, mb_off_lbase = 0, mb_off_qoff = 0, mb_off_probes = 0, mb_off_gd = 0, mb_off_gp = 0, mb_off_units = 0,
               mb_off_cand = 0, mb_off_scores = 0;
-    // wide IVF pipeline (super-batches of 8 batches share one list-major pass): slot tables, zeroed counters, plans,
-    // bounds, prepared queries, candidate sink
+    // wide IVF pipeline (a launch group of up to 32 batches shares one list-major pass): slot tables, zeroed counters,
+    // plans, bounds, prepared queries, candidate sink
     struct IvfWide {
         int32_t* lq = nullptr;      // [n_sb][nlist][kIvfWideQ]
         int32_t* zero = nullptr;    // one zeroed block per launch group: plan words (pair counters, record count) | slow [1024] | overflow (16) | list counters [16][1024]
@@ -1002,9 +1002,10 @@ int ensure_ivf_wide(vs_index* h, int lane) {
     return VS_OK;
 }
 
-// nb <= kMaxMulti independent batches through the wide pipeline: query preparation, coarse (MFMA) + pick per batch,
-// bounds, then per super-batch of 8 batches ONE list-major pass with candidates to the sink; binning, ranking, and the
-// exact slow path for queries without a bound (or for everybody if a candidate buffer overflowed).
+// nb <= kMaxMulti independent batches (one launch group) through the wide pipeline on scratch lane `lane`: one memset,
+// coarse (MFMA, also prepares the byte queries) + pick (also fills the lists' slot tables), bounds and plan in one
+// launch, ONE list-major pass with candidates to the sink (binned by the scan's own waves), and the ranking launch
+// (merge, or the exact slow path for queries without a bound / for everybody if a candidate buffer overflowed).
 int ivf_group_wide_dev(vs_index* h, int lane, const float* q_dev, int nb, int B, int k, int nprobe, float* out_d, int32_t* out_i, hipStream_t s) {
     int rc = ensure_ivf_wide(h, lane);
     if (rc) return rc;

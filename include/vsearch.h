@@ -204,8 +204,9 @@ VS_API int vs_ivf_search_dev(vs_index* h, const float* queries_dev, int B, int k
 
 /* The batch loop of main_ivf.cpp:150-214 with the queries already on the device: n_batches independent
  * batches [n_batches][B][dim] -> [n_batches][B][k].  Every kernel of the pipeline is launched once for a
- * group of up to 32 batches (blockIdx.y = batch, per-batch scratch slabs), so the latency-bound steps
- * (coarse + probe pick, grouping, selection) fill the GPU and the host enqueues six operations per group. */
+ * launch group of up to 32 batches (1024 queries share ONE list-major pass over the probed lists), and the
+ * groups of a call are dealt to two internal streams that fork from and join `stream`: pass as many batches
+ * per call as there are (128 batches per call: 13.6 M QPS at nlist 1024 / nprobe 32; 32 per call: 10.9 M). */
 VS_API int vs_ivf_search_dev_multi(vs_index* h, const float* queries_dev, int n_batches, int B, int k, int nprobe,
                                    int32_t* ids_dev, float* dists_dev, void* stream);
 
