@@ -515,3 +515,78 @@ def test_c5_shape_eight_list_shards(gpu_pkg):
         assert sorted(a[i].tolist()) == sorted(b[i].tolist())
     gt, _ = oracle.search_bf(base, q, k)
     assert oracle.recall(b[:, :1], gt[:, :1], 1) >= 0.91
+
+
+def test_wide_groups_on_two_streams_hot_lists(gpu_pkg):
+    """A call of more than 32 batches: the launch groups (32 + 32 + 6 batches) run on two internal streams with a
+    scratch lane each.  Few lists, so every list is probed by hundreds of a group's queries: the plan splits their
+    records by slot range and the scan's loop over more than four column blocks runs.  Must equal the same batches
+    sent group by group (one stream), on repeated calls, and the oracle."""
+    import torch
+    dev = torch.device("cuda:0")
+    base, cents, vr, off, r2o = _make_index(gpu_pkg, n=30000, nlist=16, seed=21)
+    nb, k, nprobe = 70, 5, 4
+    q = gpu_pkg.synth_sift(32 * nb, seed=78)
+    qd = torch.from_numpy(q).to(dev)
+    s = torch.cuda.current_stream().cuda_stream
+    with gpu_pkg.IVFIndex(vectors_reordered=vr, centroids=cents, cluster_offsets=off, reorder_to_original=r2o) as ivf:
+        want_i = torch.zeros((nb * 32, k), dtype=torch.int32, device=dev)
+        want_d = torch.zeros((nb * 32, k), dtype=torch.float32, device=dev)
+        for b0 in range(0, nb, 32):
+            n = min(32, nb - b0)
+            ivf.search_dev_multi(qd.data_ptr() + b0 * 32 * 128 * 4, n, 32, k, nprobe, want_i.data_ptr() + b0 * 32 * k * 4,
+                                 want_d.data_ptr() + b0 * 32 * k * 4, s)
+        torch.cuda.synchronize()
+        for _ in range(3):
+            got_i = torch.full((nb * 32, k), -7, dtype=torch.int32, device=dev)
+            got_d = torch.zeros((nb * 32, k), dtype=torch.float32, device=dev)
+            ivf.search_dev_multi(qd.data_ptr(), nb, 32, k, nprobe, got_i.data_ptr(), got_d.data_ptr(), s)
+            torch.cuda.synchronize()
+            assert torch.equal(got_d, want_d) and torch.equal(got_i, want_i)
+    sub = np.r_[0:64, 32 * 40:32 * 40 + 64, 32 * 69:32 * 70]  # queries of all three groups
+    oi, od, _ = oracle.ivf_search(vr, off, r2o, cents, q[sub], k, nprobe)
+    gd = want_d.cpu().numpy()[sub]
+    same = np.array([np.array_equal(gd[i], od[i]) for i in range(len(sub))])
+    assert same.mean() >= 0.97  # (probe sets can differ by a last-bit coarse tie, see test_matches_oracle_ivf)
+    ex = oracle.exact_int_dists(q[sub], base)
+    assert np.array_equal(np.take_along_axis(ex, want_i.cpu().numpy()[sub].astype(np.int64), 1).astype(np.float32), gd)
+
+
+def test_wide_slow_path_duplicates_and_tiny_lists(gpu_pkg):
+    """Queries the wide pipeline cannot bound or whose candidates do not fit their lists go through the exact slow path
+    inside the ranking launch: (i) thousands of identical rows (every one of them is under the bound: the sub-lists
+    overflow), (ii) lists with fewer than k rows as the two nearest (no bound at all)."""
+    import torch
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(5)
+    base = gpu_pkg.synth_sift(12000, seed=33)
+    base[2000:8000] = base[1999]                      # 6000 copies of one row
+    cents = base[rng.choice(12000, 24, replace=False)].copy()
+    cents[0] = base[1999]
+    # eight far-away centroids with two rows each: lists with fewer than k rows
+    far = (base[:16].reshape(8, 2, 128).mean(1) * 0 + np.arange(8)[:, None] * 3 + 200).astype(np.float32)
+    far_rows = np.repeat(far, 2, axis=0) + rng.integers(0, 2, (16, 128)).astype(np.float32)
+    base = np.concatenate([base, np.clip(far_rows, 0, 255)]).astype(np.float32)
+    cents = np.concatenate([cents, far]).astype(np.float32)
+    d = (base ** 2).sum(1)[:, None] - 2 * base @ cents.T + (cents ** 2).sum(1)[None]
+    a = d.argmin(1)
+    vr, off, r2o = gpu_pkg.ivf_layout_from_assignment(base, a, len(cents))
+    k, nprobe, nb = 5, 3, 4
+    q = gpu_pkg.synth_sift(32 * nb, seed=34)
+    q[:40] = np.clip(base[1999] + rng.integers(-2, 3, (40, 128)), 0, 255)   # next to the duplicates
+    q[40:60] = np.clip(far[rng.integers(0, 8, 20)] + rng.integers(0, 2, (20, 128)), 0, 255)  # next to the tiny lists
+    qd = torch.from_numpy(q).to(dev)
+    s = torch.cuda.current_stream().cuda_stream
+    oi, od, _ = oracle.ivf_search(vr, off, r2o, cents, q, k, nprobe)
+    with gpu_pkg.IVFIndex(vectors_reordered=vr, centroids=cents, cluster_offsets=off, reorder_to_original=r2o) as ivf:
+        got_i = torch.full((nb * 32, k), -7, dtype=torch.int32, device=dev)
+        got_d = torch.zeros((nb * 32, k), dtype=torch.float32, device=dev)
+        ivf.search_dev_multi(qd.data_ptr(), nb, 32, k, nprobe, got_i.data_ptr(), got_d.data_ptr(), s)
+        torch.cuda.synchronize()
+    gi, gd = got_i.cpu().numpy(), got_d.cpu().numpy()
+    same = np.array([np.array_equal(gd[i], od[i]) for i in range(len(q))])
+    assert same.mean() >= 0.97, np.nonzero(~same)[0][:10]
+    ex = oracle.exact_int_dists(q, base)
+    ok = gi >= 0
+    assert np.array_equal(np.where(ok, np.take_along_axis(ex, np.maximum(gi, 0).astype(np.int64), 1).astype(np.float32), np.inf), gd)
+    assert all(len(set(r[r >= 0])) == (r >= 0).sum() for r in gi)   # no row twice
