@@ -331,7 +331,8 @@ struct IvfWideParams {
     const int32_t* invalid;   // [n_batches] (pre-set to 0) a query of the batch is not byte valued
     const int32_t* probes;    // batch b's [B][nprobe] at (char*)probes + b * probes_batch_bytes
     long long probes_batch_bytes;
-    int32_t* lq;              // [n_sb][nlist][kIvfWideQ] query slots ((batch % 32) * 32 + q: local to the super-batch) probing each list
+    int32_t* lq;              // [n_sb][nlist][kIvfWideQ] slot tables: 128 * ((batch % 32) * 32 + q) of the queries probing each list
+                              //   (= where the scan's LDS keeps the query), padded to a multiple of 16 entries with the dummy slot
     int32_t* zero;            // [n_sb][ivf_wide_plan_words(nlist)] (pre-set to 0): list c's pair counter at word c * kIvfWideCntStride
                               //   (a 128-byte line each: the pick kernel's atomics come from all XCDs), the super-batch's record
                               //   count at word nlist * kIvfWideCntStride

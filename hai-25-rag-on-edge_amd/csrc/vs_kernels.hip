@@ -1904,8 +1904,9 @@ __device__ __forceinline__ void merge_compact_body(const MergeParams& p, const M
 
     // Many candidates (a loose bound on a few queries): the kout-th smallest of the first 256 bounds the answer; whatever
     // is not above it (usually a few dozen entries) is copied aside and ranked by one wave like a short list.
-    __shared__ float cd2[1024];
-    __shared__ int ci2[1024];
+    constexpr int kKeep = 512;  // (with the 32 KB of cd/ci this keeps the kernel at 4 workgroups per CU: 1024 queries resident at once)
+    __shared__ float cd2[kKeep];
+    __shared__ int ci2[kKeep];
     __shared__ float s_thr_d;
     __shared__ int s_thr_i, s_keep;
     bool filtered = false;
@@ -1951,14 +1952,14 @@ __device__ __forceinline__ void merge_compact_body(const MergeParams& p, const M
             const int id = ci[e];
             if (!lex_lt(td, ti, d, id)) {  // (d, id) <= (td, ti)
                 const int pos = atomicAdd(&s_keep, 1);
-                if (pos < 1024) {
+                if (pos < kKeep) {
                     cd2[pos] = d;
                     ci2[pos] = id;
                 }
             }
         }
         __syncthreads();
-        filtered = s_keep <= 1024;  // else: masses of ties at the threshold -> the workgroup-wide rounds below
+        filtered = s_keep <= kKeep;  // else: masses of ties at the threshold -> the workgroup-wide rounds below
     }
     if (filtered) {
         const int S = s_keep;
@@ -2505,7 +2506,8 @@ __global__ __launch_bounds__(256) void ivf_pick_kernel(const float* __restrict__
         if (c >= 0) {
             const int sb = (int)blockIdx.y / kIvfWideBatches;
             const int slot = atomicAdd(grp.w_cnt + sb * ivf_wide_plan_words(nlist) + (int64_t)c * kIvfWideCntStride, 1);  // < w_q: once per query
-            grp.w_lq[((int64_t)sb * nlist + c) * grp.w_q + slot] = ((int)blockIdx.y % kIvfWideBatches) * kMaxBatch + b;  // the query's slot in its super-batch
+            // the table holds the byte offset of the query's 128 staged bytes in the scan's LDS (slot in the launch group * 128)
+            grp.w_lq[((int64_t)sb * nlist + c) * grp.w_q + slot] = (((int)blockIdx.y % kIvfWideBatches) * kMaxBatch + b) * kDim;
         }
         PICK_STAMP(5);
         return;
@@ -3857,7 +3859,14 @@ __device__ __forceinline__ void ivf_plan_body(const IvfWideParams& p, const int 
 #pragma unroll
         for (int i = 0; i < CPT; ++i) {
             const int c = tid + kPlanThreads * i;
-            if (c < p.nlist) cnt_s[c] = min(n[i], kIvfWideQ);
+            if (c < p.nlist) {
+                const int nq = min(n[i], kIvfWideQ);
+                cnt_s[c] = nq;
+                // the scan takes a list's slot table 16 entries at a time without looking at the count: the last block
+                // is filled up with the dummy slot (one workgroup does it; the entries are stale otherwise)
+                if (slice == 0)
+                    for (int sl = nq; sl < ((nq + 15) & ~15); ++sl) p.lq[((int64_t)sb * p.nlist + c) * kIvfWideQ + sl] = kIvfWideQ * kDim;
+            }
             cand += (long long)min(n[i], kIvfWideQ) * len[i];
         }
     }
@@ -3981,12 +3990,26 @@ __global__ __launch_bounds__(256) void ivf_tau_plan_kernel(const IvfWideParams p
 //    enters as the MFMA's C operand straight from an array that holds it (`nrh`), and the hot path is the maximum of
 //    the 8 results against th >> 1.
 //  - the distance itself (qt + ro - 2 acc) is completed when the wave bins its candidates at the end;
-//  - rows past the chunk end are poisoned in the C operand (only a chunk's last unit pays), dead lanes of a column block
-//    point at a dummy query slot whose bound admits nothing;
+//  - rows past the chunk end are poisoned in the C operand (only a chunk's last unit pays); a list's slot table is
+//    padded to a multiple of 16 entries with a dummy query slot whose bound admits nothing (the plan does it), so a
+//    column block never looks at the list's count;
+//  - the slot table holds LDS byte offsets (slot * 128), a slot's bytes are kept as four 32-byte units [MFMA 1 | MFMA 2]
+//    per lane group, swizzled by slot, and the per-query words sit in front of the query bytes: the B operands of a
+//    column block cost 3 vector instructions of address arithmetic and their bound 2 (10 in all beside the 4 MFMAs);
 //  - a record's fields are scalars, its rows are read unclamped (the arrays are padded) at scalar base + one lane offset,
 //    the first four column blocks are straight-line code on slots fetched with the rows, and two register sets
 //    alternate instead of being copied.
-constexpr int kIvfWideThreads = 1024;  // 16 waves, one workgroup per CU (its LDS holds the super-batch's queries)
+#ifndef VS_WIDE_WAVES
+#define VS_WIDE_WAVES 16
+#endif
+#ifndef VS_WIDE_SETS
+#define VS_WIDE_SETS 2
+#endif
+// One workgroup per CU (its LDS holds the group's queries): 16 waves, two register sets each (a record being scored,
+// the next record's rows in flight).  Three sets (two records in flight) fit the 128 registers too and were measured:
+// + 1.7 % on one stream, nothing on two.  The loop is bound by instruction issue, not by what a wave has in flight.
+constexpr int kIvfWideThreads = 64 * VS_WIDE_WAVES;
+constexpr int kIvfWideSets = VS_WIDE_SETS;
 constexpr int kIvfWideWaves = kIvfWideThreads / 64;
 constexpr int kIvfWideSlots = kIvfWideQ + 1;  // + the dummy slot
 constexpr int kIvfWideLds = kIvfWideSlots * kDim + 4 * kIvfWideSlots * 4;  // query bytes + four per-query words
@@ -3995,11 +4018,13 @@ __global__ __launch_bounds__(kIvfWideThreads) void ivf_scan_wide_kernel(const Iv
     typedef int i32x4 __attribute__((ext_vector_type(4)));
     typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
     extern __shared__ __attribute__((aligned(16))) char wide_smem[];
-    int* q8_s = reinterpret_cast<int*>(wide_smem);                          // [slot][128 bytes]
-    int* qt_s = reinterpret_cast<int*>(wide_smem + kIvfWideSlots * kDim);   // [slot]
-    int* thh_s = qt_s + kIvfWideSlots;                                      // int8 path: acc > thh  <=>  d < ti (see above)
-    float* tau_s = reinterpret_cast<float*>(thh_s + kIvfWideSlots);
+    // (the per-query words first: their LDS addresses then fit the 16-bit offset field of the read instructions)
+    int* thh_s = reinterpret_cast<int*>(wide_smem);                         // [slot] int8 path: acc > thh  <=>  d < ti (see above)
+    int* qt_s = thh_s + kIvfWideSlots;
+    float* tau_s = reinterpret_cast<float*>(qt_s + kIvfWideSlots);
     float* qn_s = tau_s + kIvfWideSlots;
+    constexpr int kQ8Off = 4 * kIvfWideSlots * 4;                           // 16400: 16-byte aligned
+    int* q8_s = reinterpret_cast<int*>(wide_smem + kQ8Off);                 // [slot][128 bytes]
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, g = lane >> 4;
@@ -4019,10 +4044,13 @@ __global__ __launch_bounds__(kIvfWideThreads) void ivf_scan_wide_kernel(const Iv
     VS_STAMP(0);
     // everything the staging needs is requested in one go (a kernel start is a chain of cold round trips otherwise)
     const int n_units = p.zero[sb * ivf_wide_plan_words(p.nlist) + (int64_t)p.nlist * kIvfWideCntStride];
-    int4 rv0 = recs[min(u, p.units_cap - 1)], rv1 = recs[min(u + nw, p.units_cap - 1)];
+    constexpr int NS = kIvfWideSets, DEPTH = NS - 1;  // register sets; records whose rows are in flight beside the current one
+    int4 rv[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) rv[i] = recs[min(u + i * nw, p.units_cap - 1)];
     int inv = 0;
     for (int b = b0; b < b1; ++b) inv |= p.invalid[b];
-    constexpr int PER = kIvfWideQ * 8 / kIvfWideThreads;
+    constexpr int PER = (kIvfWideQ * 8 + kIvfWideThreads - 1) / kIvfWideThreads;
     int4 v[PER];
     {
         const int4* src = reinterpret_cast<const int4*>(p.q8 + (int64_t)qbase * kDim);
@@ -4044,17 +4072,19 @@ __global__ __launch_bounds__(kIvfWideThreads) void ivf_scan_wide_kernel(const Iv
         const int ti = (int)ceilf(fminf(fmaxf(t0, -67108864.f), 67108864.f));
         thh_s[s] = live ? (qt - ti) >> 1 : kIvfWideDeadThr;
     }
-    // 16-byte segment s of slot ql sits at segment s ^ (ql & 7) of the slot's 128 bytes: the B-operand gather below reads
-    // the same segment of 16 arbitrary slots at once, which unswizzled is a 16-way bank conflict
+    // A slot's 128 bytes are kept as four 32-byte units, unit g = [bytes 16g.. | bytes 64+16g..] = what lane group g feeds
+    // the two MFMAs of a column block (one address, two reads), and unit g sits at position g ^ (slot & 3): the B-operand
+    // gather reads the same unit of 16 arbitrary slots at once, which unswizzled is a 16-way bank conflict.
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
-        const int i = tid + j * kIvfWideThreads;
-        reinterpret_cast<int4*>(q8_s)[i ^ ((i >> 3) & 7)] = v[j];
+        const int i = tid + j * kIvfWideThreads;  // 16-byte segment i & 7 of slot i >> 3
+        if (i < kIvfWideQ * 8) reinterpret_cast<int4*>(q8_s)[(i & ~7) + ((((i & 3) ^ ((i >> 3) & 3))) << 1) + ((i >> 2) & 1)] = v[j];
     }
     if (tid < 8) reinterpret_cast<int4*>(q8_s)[kIvfWideQ * 8 + tid] = make_int4(0, 0, 0, 0);
     const bool i8 = p.vecs_t8 && p.metric == 0 && inv == 0;
-    if (u >= n_units) rv0 = make_int4(0, 0, 0, 0);
-    if (u + nw >= n_units) rv1 = make_int4(0, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < NS; ++i)
+        if (u + i * nw >= n_units) rv[i] = make_int4(0, 0, 0, 0);
     if ((int)blockIdx.x >= n_units) return;  // workgroup-uniform: not even wave 0 has a record (nothing to bin either)
 
     struct Rec {
@@ -4076,6 +4106,7 @@ __global__ __launch_bounds__(kIvfWideThreads) void ivf_scan_wide_kernel(const Iv
     constexpr int PF = 4;  // column blocks whose query slots are fetched together with the unit's rows
     constexpr int NT = kIvfWideTiles;
     const unsigned loff = (unsigned)(16 * lane);  // the lane's bytes inside one half of a tile: a load is 1 KB in one piece
+    const unsigned g32 = 32u * (unsigned)g;
     auto issue = [&](const Rec& rc, i32x4 (&a0)[NT], i32x4 (&a1)[NT], i32x4 (&nr)[NT], int (&qlp)[PF]) __attribute__((always_inline)) {
         const int8_t* rows = p.vecs_t8 + (int64_t)rc.r0 * kDim;  // r0 is a multiple of 32 (rows past the chunk end: poisoned below)
         const int32_t* nrp = p.nrh_t + rc.r0;
@@ -4092,13 +4123,18 @@ __global__ __launch_bounds__(kIvfWideThreads) void ivf_scan_wide_kernel(const Iv
         for (int i = 0; i < PF; ++i) qlp[i] = lqn[16 * i + r];
     };
     if (i8) {
-        i32x4 A0[NT], A1[NT], AN[NT], B0[NT], B1[NT], BN[NT];
-        int AQ[PF], BQ[PF];
-        Rec ra = unpack(rv0), rb;
-        issue(ra, A0, A1, AN, AQ);  // the first record's rows travel while the queries are stored
+        i32x4 SA0[NS][NT], SA1[NS][NT], SN[NS][NT];
+        int SQ[NS][PF];
+        Rec SR[NS];
+        // the first records' rows travel while the queries are stored
+#pragma unroll
+        for (int i = 0; i < DEPTH; ++i) {
+            SR[i] = unpack(rv[i]);
+            issue(SR[i], SA0[i], SA1[i], SN[i], SQ[i]);
+        }
         __syncthreads();
         VS_STAMP(1);
-        int4 rvn = rv1;
+        int4 rvn = rv[DEPTH];
         auto compute = [&](const Rec& rc, const i32x4 (&a0)[NT], const i32x4 (&a1)[NT], i32x4 (&nr)[NT], const int (&qlc)[PF]) __attribute__((always_inline)) {
             if (rc.r0 + kIvfWideUnit > rc.r_end) {  // wave-uniform, a chunk's last unit: rows past its end can never pass
 #pragma unroll
@@ -4107,11 +4143,12 @@ __global__ __launch_bounds__(kIvfWideThreads) void ivf_scan_wide_kernel(const Iv
                     for (int j = 0; j < 4; ++j)
                         if (rc.r0 + 16 * t + 4 * g + j >= rc.r_end) nr[t][j] = -(1 << 28);
             }
-            auto block = [&](const int ql) __attribute__((always_inline)) {
-                const int o0 = ql * 32 + 4 * (g ^ (ql & 7));
-                const i32x4 bq0 = *reinterpret_cast<const i32x4*>(q8_s + o0);
-                const i32x4 bq1 = *reinterpret_cast<const i32x4*>(q8_s + (o0 ^ 16));
-                const int thh = thh_s[ql];
+            // (e: byte offset of the slot's staged bytes, as the slot table holds it; 10 vector instructions beside the MFMAs)
+            auto block = [&](const unsigned e) __attribute__((always_inline)) {
+                const unsigned a = ((g32 ^ ((e >> 2) & 0x60u)) + e);  // unit g ^ (slot & 3) of the slot
+                const i32x4 bq0 = *reinterpret_cast<const i32x4*>(wide_smem + kQ8Off + a);
+                const i32x4 bq1 = *reinterpret_cast<const i32x4*>(wide_smem + kQ8Off + a + 16);
+                const int thh = *reinterpret_cast<const int*>(wide_smem + (e >> 5));
                 i32x4 acc[NT];
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
@@ -4135,7 +4172,7 @@ __global__ __launch_bounds__(kIvfWideThreads) void ivf_scan_wide_kernel(const Iv
                                 const int pos = wbase + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
                                 // (slot, acc, row of the lane group's first value, lane group): sink_bin_wave's hook below
                                 // completes row and distance (no per-value lane constants here: they would be spilled)
-                                if (pass && pos < p.sink.wcap) wbuf[pos] = make_int4(ql, acc[t][j], rc.r0 + 16 * t + j, g);
+                                if (pass && pos < p.sink.wcap) wbuf[pos] = make_int4((int)e, acc[t][j], rc.r0 + 16 * t + j, g);
                                 wbase += __popcll(mask);
                             }
                         }
@@ -4143,10 +4180,10 @@ __global__ __launch_bounds__(kIvfWideThreads) void ivf_scan_wide_kernel(const Iv
             };
 #pragma unroll
             for (int i = 0; i < PF; ++i)
-                if (16 * i < rc.nq) block(16 * i + r < rc.nq ? qlc[i] : kIvfWideQ);  // wave-uniform
-            if (rc.nq > 16 * PF) {  // only when the plan had to use a wider split
+                if (16 * i < rc.nq) block((unsigned)qlc[i]);  // wave-uniform (the table's last block is padded with the dummy slot)
+            if (rc.nq > 16 * PF) {  // a list probed by more than 64 of the group's queries
                 const int32_t* lqc = lq + (int64_t)rc.c * kIvfWideQ + rc.q0;
-                for (int cb = 16 * PF; cb < rc.nq; cb += 16) block(cb + r < rc.nq ? lqc[cb + r] : kIvfWideQ);
+                for (int cb = 16 * PF; cb < rc.nq; cb += 16) block((unsigned)lqc[cb + r]);
             }
         };
         auto next_record = [&](int idx) __attribute__((always_inline)) {
@@ -4155,19 +4192,22 @@ __global__ __launch_bounds__(kIvfWideThreads) void ivf_scan_wide_kernel(const Iv
 #endif
             return idx < n_units ? recs[idx] : make_int4(0, 0, 0, 0);  // (a zero record reads rows 0.. and no slots: harmless)
         };
-        for (;;) {
-            rb = unpack(rvn);
-            rvn = next_record(u + 2 * nw);
-            issue(rb, B0, B1, BN, BQ);
-            compute(ra, A0, A1, AN, AQ);
-            u += nw;
-            if (u >= n_units) break;
-            ra = unpack(rvn);
-            rvn = next_record(u + 2 * nw);
-            issue(ra, A0, A1, AN, AQ);
-            compute(rb, B0, B1, BN, BQ);
-            u += nw;
-            if (u >= n_units) break;
+        // software pipeline over the wave's records: set ph holds the current record, the other sets the next DEPTH ones
+        // (rows requested DEPTH steps ahead); the set just scored is refilled
+        for (bool more = true; more;) {
+#pragma unroll
+            for (int ph = 0; ph < NS; ++ph) {
+                if (!more) break;
+                constexpr int dummy = 0;
+                (void)dummy;
+                const int nx = (ph + DEPTH) % NS;
+                SR[nx] = unpack(rvn);  // record u + DEPTH * nw
+                rvn = next_record(u + (DEPTH + 1) * nw);
+                issue(SR[nx], SA0[nx], SA1[nx], SN[nx], SQ[nx]);
+                compute(SR[ph], SA0[ph], SA1[ph], SN[ph], SQ[ph]);
+                u += nw;
+                more = u < n_units;
+            }
         }
         VS_STAMP(2);
 #ifdef VS_STAMPS
@@ -4175,9 +4215,9 @@ __global__ __launch_bounds__(kIvfWideThreads) void ivf_scan_wide_kernel(const Iv
 #endif
         // the wave's candidates go to the per-query lists here (no binning launch); an entry's distance is qt + ro - 2 acc
         sink_bin_wave(p.sink, wb, wbase, lane, [&](const int4& c) {
-            const int row = c.z + 4 * c.w;
-            const int d = qt_s[c.x] + (p.rterm_t[row] & 1) - 2 * c.y;
-            return make_int4(qbase + c.x, __builtin_bit_cast(int, (float)d), row, 0);
+            const int row = c.z + 4 * c.w, slot = c.x >> 7;
+            const int d = qt_s[slot] + (p.rterm_t[row] & 1) - 2 * c.y;
+            return make_int4(qbase + slot, __builtin_bit_cast(int, (float)d), row, 0);
         }
 #ifdef VS_STAMPS
         , p.diag
@@ -4187,7 +4227,7 @@ __global__ __launch_bounds__(kIvfWideThreads) void ivf_scan_wide_kernel(const Iv
         return;
     }
     __syncthreads();
-    int4 rec = rv0;
+    int4 rec = rv[0];
     for (; u < n_units; u += nw) {
         const Rec rc = unpack(rec);
         const int td = p.tdelta ? p.tdelta[rc.c] : 0;  // the record is in padded rows, so are the candidates
@@ -4205,7 +4245,7 @@ __global__ __launch_bounds__(kIvfWideThreads) void ivf_scan_wide_kernel(const Iv
             for (int cb = 0; cb < nq; cb += 16) {
                 const int sq = cb + r;
                 const bool live = sq < nq;
-                const int ql = live ? lqc[sq] : 0;
+                const int ql = live ? lqc[sq] >> 7 : 0;  // (the table holds slot * 128)
                 const int qg = qbase + ql;
                 const float* qsrc = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.q) + (long long)(qg >> 5) * p.q_batch_bytes) + (qg & 31) * kDim;
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
