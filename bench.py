@@ -497,6 +497,36 @@ def main():
         ivf_info = ivf_leg(NPROBE)
         if not args.no_extras:
             ivf8_info = ivf_leg(8)
+        if world > 1 and not args.no_extras:
+            # N > 1, the other way to use N GPUs for an index that fits one of them (1 M rows are 0.2 % of a GPU's HBM):
+            # every rank holds the WHOLE index and serves its own share of the batches (queries are independent: no
+            # data-path collective; the shares' results are all-gathered at the end of the region).  The cluster-sharded
+            # leg above replicates everything but the list scan on every rank, and the scan is a third of a launch group.
+            full_ivf = pkg.IVFIndex(vectors_reordered=vr, centroids=cents_h, cluster_offsets=off, reorder_to_original=r2o, device=local_rank)
+            share_max = (steps + world - 1) // world
+            rep_i = torch.zeros((max(share_max, 1) * BATCH, K), dtype=torch.int32, device=dev)
+            rep_d = torch.zeros((max(share_max, 1) * BATCH, K), dtype=torch.float32, device=dev)
+            all_i = torch.zeros((world * rep_i.numel(),), dtype=torch.int32, device=dev)
+            all_d = torch.zeros((world * rep_d.numel(),), dtype=torch.float32, device=dev)
+
+            def rep_step(i, n):
+                if i != n - 1:
+                    return
+                share = len(range(rank, n, world))   # this rank's batches of the n steps
+                done = 0
+                while done < share:
+                    nb = min(share - done, n_qbatches)
+                    full_ivf.search_dev_multi(q_dev.data_ptr(), nb, BATCH, K, NPROBE, rep_i.data_ptr() + done * BATCH * K * 4,
+                                              rep_d.data_ptr() + done * BATCH * K * 4, sptr)
+                    done += nb
+                all_gather(all_i.view(torch.float32), rep_i.view(-1).view(torch.float32))
+                all_gather(all_d, rep_d.view(-1))
+
+            rreg = timed(rep_step, steps, warmup)
+            ivf_info["replicas"] = {"metric": "ivf_qps, every rank holds the whole index and serves steps / N batches (results all-gathered)",
+                                    "value": round(steps * BATCH / median(rreg), 1), "nprobe": NPROBE, "n_gpus": world}
+            log(f"IVF nprobe={NPROBE}, replicas: {ivf_info['replicas']['value']:.0f} QPS on {world} GPUs")
+            full_ivf.close()
         if world == 1 and not args.no_extras:
             tm = pkg.Timing()
             ivf.searchBatch(queries, n_queries, K, NPROBE)
