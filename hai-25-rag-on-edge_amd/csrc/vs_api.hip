@@ -40,6 +40,8 @@ constexpr int kMaxNprobe = 256;
 constexpr int kSlotWords = 32 * vs::kIvfSlots;  // per-batch slot minima of the IVF list scan (in the zeroed block)
 constexpr int kMaxLanes = 4;
 constexpr int kMaxMulti = 32;  // batches per persistent scan launch
+constexpr int kIvfHostGroups = 4;  // launch groups per chunk of the host-buffer IVF call
+constexpr int64_t kIvfHostChunk = (int64_t)kIvfHostGroups * kMaxMulti * 32;
 constexpr int kWideLanesMax = 4;  // streams (and scratch sets) the launch groups of one wide IVF call may be dealt to
 constexpr int kWideWaveCap = 1024;  // entries per wave buffer of the wide int8 scan (expected fill: about 100 per launch)
 constexpr int kWideSub = 16;      // sub-lists per query of the streaming scans' candidate lists
@@ -219,6 +221,16 @@ struct vs_index {
         int64_t q0 = -1, n = 0;    // the chunk in flight in this slot (q0 < 0: free)
     } pipe[2];
     hipStream_t s_h2d = nullptr, s_d2h = nullptr;
+    // vs_ivf_search through the wide pipeline: larger chunks (up to kIvfHostGroups launch groups each, dealt to the two
+    // lanes), ONE upload and ONE download per chunk -- every hipMemcpyAsync costs the host tens of microseconds
+    struct IvfHostSlot {
+        float* pin_q = nullptr;   // [kIvfHostChunk][128]
+        float* pin_out = nullptr; // dists [n][k] | ids [n][k] of one chunk
+        float* d_q = nullptr;
+        float* d_out = nullptr;   // same layout on the device
+        hipEvent_t ev_h2d = nullptr, ev_comp[2] = {nullptr, nullptr}, ev_d2h = nullptr;
+        int64_t q0 = -1, n = 0;
+    } ihs[2];
     // tie resolver (flagged queries of vs_bf_search): distances to the first kTieDense rows, bound, filtered candidates
     float* d_tie_dense = nullptr;  // [32][kTieDense]
     float* d_tie_tau = nullptr;    // [32]
@@ -299,6 +311,15 @@ void free_all(vs_index* h) {
             if (h->wide_join[i]) (void)hipEventDestroy(h->wide_join[i]);
         }
         if (h->wide_fork) (void)hipEventDestroy(h->wide_fork);
+    }
+    for (auto& S : h->ihs) {
+        if (S.pin_q) (void)hipHostFree(S.pin_q);
+        if (S.pin_out) (void)hipHostFree(S.pin_out);
+        if (S.d_q) (void)hipFree(S.d_q);
+        if (S.d_out) (void)hipFree(S.d_out);
+        hipEvent_t evs[] = {S.ev_h2d, S.ev_comp[0], S.ev_comp[1], S.ev_d2h};
+        for (hipEvent_t e : evs)
+            if (e) (void)hipEventDestroy(e);
     }
     for (auto& ps : h->prof_slot)
         for (auto e : ps.ev) (void)hipEventDestroy(e);
@@ -1124,6 +1145,16 @@ int ivf_group_wide_dev(vs_index* h, int lane, const float* q_dev, int nb, int B,
 #endif
     HIPCHK(vs::launch_ivf_wide_rank(m, kIvfWideSubCap, (int64_t)kWideSub * kIvfWideSubCap, wp, s));
     stage_mark(h, 3, s);
+    return VS_OK;
+}
+
+int ensure_wide_streams(vs_index* h) {
+    if (h->wide_fork) return VS_OK;
+    for (int i = 0; i < kWideLanesMax; ++i) {
+        HIPCHK(hipStreamCreateWithFlags(&h->wide_stream[i], hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&h->wide_join[i], hipEventDisableTiming));
+    }
+    HIPCHK(hipEventCreateWithFlags(&h->wide_fork, hipEventDisableTiming));
     return VS_OK;
 }
 
@@ -2264,13 +2295,7 @@ int vs_ivf_search_dev_multi(vs_index* h, const float* queries_dev, int n_batches
         // dependent kernels, several of them small (coarse, pick, bounds + plan), and the next group's small kernels fill
         // the device beside the current group's scan and ranking.
         const int lanes = std::min({g_ivf_wide_lanes, kWideLanesMax, (n_batches + kMaxMulti - 1) / kMaxMulti});
-        if (!h->wide_fork) {
-            HIPCHK(hipEventCreateWithFlags(&h->wide_fork, hipEventDisableTiming));
-            for (int i = 0; i < kWideLanesMax; ++i) {
-                HIPCHK(hipStreamCreateWithFlags(&h->wide_stream[i], hipStreamNonBlocking));
-                HIPCHK(hipEventCreateWithFlags(&h->wide_join[i], hipEventDisableTiming));
-            }
-        }
+        if ((rc = ensure_wide_streams(h))) return rc;
         HIPCHK(hipEventRecord(h->wide_fork, user));
         for (int i = 0; i < lanes; ++i) HIPCHK(hipStreamWaitEvent(h->wide_stream[i], h->wide_fork, 0));
         int g = 0;
@@ -2342,6 +2367,88 @@ int vs_ivf_search(vs_index* h, const float* queries_host, int64_t nq, int k, int
         // main_ivf.cpp:150-214 collapsed into a call); a ragged tail batch gets its own launches.  Two chunks in flight,
         // copies on their own streams (see vs_bf_search).
         const bool multi = ivf_multi_ok(h, k);
+        if (multi && g_ivf_wide && nq > 0) {
+            // ---- wide pipeline: chunks of up to kIvfHostGroups launch groups, two in flight; a chunk is one upload, its
+            // groups on the two lanes, one download (the split below exists because the host, not the device, is the
+            // limit of this call: one hipMemcpyAsync costs about as much host time as a launch group's seven launches)
+            if ((rc = ensure_wide_streams(h))) return rc;
+            for (auto& S : h->ihs)
+                if (!S.pin_q) {
+                    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&S.pin_q), (size_t)kIvfHostChunk * vs::kDim * sizeof(float), hipHostMallocDefault));
+                    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&S.pin_out), (size_t)kIvfHostChunk * 64 * 2 * sizeof(float), hipHostMallocDefault));
+                    if ((rc = dev_alloc(&S.d_q, (size_t)kIvfHostChunk * vs::kDim))) return rc;
+                    if ((rc = dev_alloc(&S.d_out, (size_t)kIvfHostChunk * 64 * 2))) return rc;
+                    HIPCHK(hipEventCreateWithFlags(&S.ev_h2d, hipEventDisableTiming));
+                    HIPCHK(hipEventCreateWithFlags(&S.ev_comp[0], hipEventDisableTiming));
+                    HIPCHK(hipEventCreateWithFlags(&S.ev_comp[1], hipEventDisableTiming));
+                    HIPCHK(hipEventCreateWithFlags(&S.ev_d2h, hipEventDisableTiming));
+                }
+            HIPCHK(hipEventRecord(h->wide_fork, h->stream));  // (behind the memset above)
+            for (int i = 0; i < 2; ++i) HIPCHK(hipStreamWaitEvent(h->wide_stream[i], h->wide_fork, 0));
+            const int64_t group_q = (int64_t)kMaxMulti * h->batch;
+            // at least two chunks per call where there is enough work, so that the second upload runs beside the first groups
+            const int64_t wchunk = std::min<int64_t>(kIvfHostChunk / 32 * h->batch, std::max<int64_t>(group_q, (nq / 2 + group_q - 1) / group_q * group_q));
+            int next_lane = 0;
+            auto enqueue_w = [&](vs_index::IvfHostSlot& S, int64_t q0, int64_t n) -> int {
+                const double t0 = now_ms();
+                S.q0 = q0;
+                S.n = n;
+                std::memcpy(S.pin_q, queries_host + q0 * vs::kDim, (size_t)n * vs::kDim * sizeof(float));
+                HIPCHK(hipMemcpyAsync(S.d_q, S.pin_q, (size_t)n * vs::kDim * sizeof(float), hipMemcpyHostToDevice, h->s_h2d));
+                HIPCHK(hipEventRecord(S.ev_h2d, h->s_h2d));
+                tm.h2d_ms += now_ms() - t0;
+                float* od = S.d_out;
+                int32_t* oi = reinterpret_cast<int32_t*>(S.d_out + (size_t)n * k);
+                bool used[2] = {false, false};
+                for (int64_t g0 = 0; g0 < n; g0 += group_q) {
+                    const int64_t gn = std::min<int64_t>(group_q, n - g0);
+                    const int full = (int)(gn / h->batch), rem = (int)(gn % h->batch);
+                    const int lane = next_lane;
+                    next_lane ^= 1;
+                    const hipStream_t cs = h->wide_stream[lane];
+                    if (!used[lane]) HIPCHK(hipStreamWaitEvent(cs, S.ev_h2d, 0));
+                    used[lane] = true;
+                    int r2 = VS_OK;
+                    if (full) r2 = ivf_group_wide_dev(h, lane, S.d_q + (size_t)g0 * vs::kDim, full, h->batch, k, nprobe, od + (size_t)g0 * k, oi + (size_t)g0 * k, cs);
+                    if (!r2 && rem) {  // the call's ragged tail: one more group of a single short batch
+                        const size_t o = (size_t)g0 + (size_t)full * h->batch;
+                        r2 = ivf_group_wide_dev(h, lane, S.d_q + o * vs::kDim, 1, rem, k, nprobe, od + o * k, oi + o * k, cs);
+                    }
+                    if (r2) return r2;
+                }
+                for (int lane = 0; lane < 2; ++lane)
+                    if (used[lane]) {
+                        HIPCHK(hipEventRecord(S.ev_comp[lane], h->wide_stream[lane]));
+                        HIPCHK(hipStreamWaitEvent(h->s_d2h, S.ev_comp[lane], 0));
+                    }
+                HIPCHK(hipMemcpyAsync(S.pin_out, S.d_out, (size_t)n * k * 2 * sizeof(float), hipMemcpyDeviceToHost, h->s_d2h));
+                HIPCHK(hipEventRecord(S.ev_d2h, h->s_d2h));
+                return VS_OK;
+            };
+            auto retire_w = [&](vs_index::IvfHostSlot& S) -> int {
+                if (S.q0 < 0) return VS_OK;
+                const double t0 = now_ms();
+                HIPCHK(hipEventSynchronize(S.ev_d2h));
+                tm.d2h_ms += now_ms() - t0;
+                const float* hd = S.pin_out;
+                const int32_t* hi = reinterpret_cast<const int32_t*>(S.pin_out + (size_t)S.n * k);
+                for (int64_t i = 0; i < S.n * k; ++i) {
+                    const int32_t id = hi[i];
+                    ids[S.q0 * k + i] = id;
+                    dists[S.q0 * k + i] = id >= 0 ? hd[i] : inf;
+                }
+                S.q0 = -1;
+                return VS_OK;
+            };
+            int c = 0;
+            for (int64_t q0 = 0; q0 < nq; q0 += wchunk, ++c) {
+                vs_index::IvfHostSlot& S = h->ihs[c & 1];
+                if ((rc = retire_w(S))) return rc;
+                if ((rc = enqueue_w(S, q0, std::min<int64_t>(wchunk, nq - q0)))) return rc;
+            }
+            if ((rc = retire_w(h->ihs[c & 1]))) return rc;
+            if ((rc = retire_w(h->ihs[(c + 1) & 1]))) return rc;
+        }
         const int64_t chunk = (int64_t)(multi ? kMaxMulti : 1) * h->batch;
         auto enqueue = [&](vs_index::PipeSlot& S, int64_t q0, int64_t n) -> int {
             const double t0 = now_ms();
@@ -2388,7 +2495,7 @@ int vs_ivf_search(vs_index* h, const float* queries_host, int64_t nq, int k, int
             return VS_OK;
         };
         int c = 0;
-        for (int64_t q0 = 0; q0 < nq; q0 += chunk, ++c) {
+        for (int64_t q0 = 0; q0 < nq && !(multi && g_ivf_wide); q0 += chunk, ++c) {
             vs_index::PipeSlot& S = h->pipe[c & 1];
             if ((rc = retire(S))) return rc;
             if ((rc = enqueue(S, q0, std::min<int64_t>(chunk, nq - q0)))) return rc;
