@@ -68,10 +68,11 @@ int main(int argc, char* argv[]) {
         std::vector<double> latencies;
         const size_t num_queries = (size_t)nq;
         auto total_start = std::chrono::high_resolution_clock::now();
-        // The reference calls searchBatch once per model batch (main_ivf.cpp:150-189).  Here up to 32 batches go down in
-        // one call (the index still processes them BATCH_SIZE queries at a time, every kernel launched once for the group);
-        // a query's latency entry is its batch's share of the call.
-        const size_t per_call = (size_t)std::min(std::max(BATCH_SIZE, 1), 32) * 32;
+        // The reference calls searchBatch once per model batch (main_ivf.cpp:150-189).  Here up to 128 batches go down in
+        // one call (the index still processes them BATCH_SIZE queries at a time: every kernel is launched once per group of
+        // 32 batches, the groups of a call run on two streams, and a call is two uploads and two downloads; sharded: one
+        // group = one all-gather per call); a query's latency entry is its batch's share of the call.
+        const size_t per_call = (size_t)std::min(std::max(BATCH_SIZE, 1), 32) * (ranks.world > 1 ? 32 : 128);
         for (size_t i = 0; i < num_queries; i += per_call) {
             const size_t cur = std::min(per_call, num_queries - i);
             std::vector<float> batch(queries.begin() + (long)(i * query_dim), queries.begin() + (long)((i + cur) * query_dim));
