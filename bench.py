@@ -475,7 +475,7 @@ def main():
                 ach = ib / ks_launch / 1e9 if ks_launch > 0 else None
                 itraffic = None
                 ipath = os.path.join(ROOT, "profiles", "traffic_ivf_list_scan.json")
-                if os.path.exists(ipath) and n_rows == N_BASE and i8_rows and nprobe == NPROBE and set(window) == {32}:
+                if os.path.exists(ipath) and n_rows == N_BASE and i8_rows and nprobe == NPROBE and 32 in window:  # (PMC figure of a 32-batch launch)
                     itraffic = json.load(open(ipath)).get("hbm_bytes_per_launch_32_batches")
                 frac = round(ach / HBM_PEAK_GBS, 4) if ach else None
                 info["roofline"] = {"bound": "hbm", "achieved": round(ach, 1) if ach else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
