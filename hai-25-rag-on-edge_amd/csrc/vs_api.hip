@@ -591,6 +591,13 @@ int g_i8_wide = [] {
     return v >= 8 ? 8 : (v >= 4 ? 4 : 0);
 }();
 
+// tuning knob (VSEARCH_F32_PAIR=0): the fp32 streaming scan makes one pass over the rows per batch (HBM bound) instead of
+// one per two batches (MFMA bound)
+int g_f32_pair = [] {
+    const char* e = getenv("VSEARCH_F32_PAIR");
+    return e ? atoi(e) : 1;
+}();
+
 // tuning knob (VSEARCH_STREAM=0): seeded launches use the per-batch scan kernels (lane lists + workgroup merge) instead of
 // the streaming scans
 int g_stream = [] {
@@ -740,6 +747,7 @@ int bf_launch(vs_index* h, vs_index::Lane& L, const float* q_dev, int nb, int B,
             sp.metric = h->metric;
             sp.id_offset = (int32_t)h->id_offset;
             sp.sink = sink;
+            sp.batches_per_pass = (g_f32_pair && nb >= 2) ? 2 : 1;
             const int sgrid = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(h->num_cus, vs::kSlotStride), tiles_total));
             HIPCHK(vs::launch_scan_f32_stream(sp, sgrid, s));
             prof_end(h, 0, s);

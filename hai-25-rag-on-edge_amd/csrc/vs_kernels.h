@@ -144,6 +144,7 @@ struct StreamParams {
     int n_batches, nq_valid, metric;
     int32_t id_offset;
     CandSink sink;
+    int batches_per_pass;    // 1 (HBM bound) or 2 (two batches share a pass over the rows: MFMA bound)
 };
 hipError_t launch_scan_f32_stream(const StreamParams& p, int grid, hipStream_t s);
 

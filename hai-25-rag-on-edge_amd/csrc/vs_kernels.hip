@@ -1187,7 +1187,13 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_i8w_kernel(const WidePar
 // ------------------------------------------------------------------------------------------------
 // Streaming fp32 scan (see StreamParams): scan_kernel's fp32 data path and arithmetic, the wide int8 scan's organisation.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kScanThreads, 2) void scan_f32s_kernel(const StreamParams p) {
+// NB = batches per pass over the rows.  NB = 1: one batch per pass, HBM bound (516 MB per batch).  NB = 2: two batches
+// (four 16-query column blocks) share a pass; a tile is then 128 MFMAs for its 8 KB and the kernel is MFMA bound --
+// the same FMA chain per (row, query), so the same bits.  The B operands of four column blocks are 128 registers:
+// NB = 2 runs at two waves per SIMD with up to 256 registers each.
+template <int NB>
+__global__ __launch_bounds__(kScanThreads, NB == 1 ? 2 : 1) void scan_f32s_kernel(const StreamParams p) {
+    constexpr int NH = 2 * NB;  // 16-query column blocks per pass
     constexpr int TR = kTileRows;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* lds_ticket = reinterpret_cast<int*>(smem + kRingBytes);
@@ -1197,7 +1203,8 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_f32s_kernel(const Stream
     const int tiles_total = (int)((p.n_rows + TR - 1) / TR);
     const int G = (int)gridDim.x;
     const int T = (tiles_total - (int)blockIdx.x + G - 1) / G;  // tiles of this workgroup per batch (grid <= tiles_total)
-    const int total = T * p.n_batches;                            // tickets of this workgroup
+    const int n_pass = (p.n_batches + NB - 1) / NB;
+    const int total = T * n_pass;                                 // tickets of this workgroup
     if (threadIdx.x == 0) lds_ticket[0] = 2 * kScanWaves;
     __syncthreads();  // the only barrier of the kernel
 
@@ -1240,7 +1247,7 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_f32s_kernel(const Stream
     int dec_pass = 0, dec_base = 0;
     auto tile_of = [&](int tk, int& pass_out) __attribute__((always_inline)) -> int {
         if (tk >= total) {
-            pass_out = p.n_batches;
+            pass_out = n_pass;
             return (int)blockIdx.x;  // past the end: the DMA still goes out (queue accounting), to a tile nobody uses
         }
         while (tk - dec_base >= T) {
@@ -1256,16 +1263,17 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_f32s_kernel(const Stream
     // s_waitcnt of its own in front of their first use (it would be vmcnt(0): a drain of the tile queue in every
     // step); the hand-counted waits of the tile loop cover them.  A padding query (main.cpp:206-211) reads row 0 and
     // is masked where candidates are taken: its MFMA column influences nothing else.
-    f32x4 qf[2][8];
-    float qn[2], tau[2];
-    int qglob[2];
-    bool live[2];
-    auto load_pass = [&](int batch) __attribute__((always_inline)) {
-        const float* qb = p.q + (int64_t)batch * p.q_batch_stride;
+    f32x4 qf[NH][8];
+    float qn[NH], tau[NH];
+    int qglob[NH];
+    bool live[NH];
+    auto load_pass = [&](int pass) __attribute__((always_inline)) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int qrow = 16 * h + r;
-            live[h] = qrow < p.nq_valid;
+        for (int h = 0; h < NH; ++h) {
+            const int batch = min(pass * NB + h / 2, p.n_batches - 1);  // (a pass of the last, odd batch: its second half is dead)
+            const float* qb = p.q + (int64_t)batch * p.q_batch_stride;
+            const int qrow = 16 * (h & 1) + r;
+            live[h] = qrow < p.nq_valid && pass * NB + h / 2 < p.n_batches;
             qglob[h] = batch * kMaxBatch + (live[h] ? qrow : 0);
             const float* src = qb + (live[h] ? qrow : 0) * kDim + 4 * g;
 #pragma unroll
@@ -1308,17 +1316,28 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_f32s_kernel(const Stream
         const f32x4 bn = *reinterpret_cast<const f32x4*>(src + fa_n);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         issue_tile(tile_new, sl);  // the slot is refilled as soon as its fragments sit in registers
-        f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+        f32x4 acc[NH];
 #pragma unroll
-        for (int c = 0; c < 8; ++c)
+        for (int h = 0; h < NH; ++h) acc[h] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (NB == 1 || (pass_cur + 1) * NB <= p.n_batches) {  // wave-uniform
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int c = 0; c < 8; ++c)
 #pragma unroll
-                for (int h = 0; h < 2; ++h) acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][i], qf[h][c][i], acc[h], 0, 0, 0);
-        float d[2][4];
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int h = 0; h < NH; ++h) acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][i], qf[h][c][i], acc[h], 0, 0, 0);
+        } else {  // the pass of a last, odd batch: its second half is dead, so are its MFMAs
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][i], qf[h][c][i], acc[h], 0, 0, 0);
+        }
+        float d[NH][4];
         bool any = false;
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+        for (int h = 0; h < NH; ++h)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 // cpu_baseline.cpp:241  dist = qn + bn - 2*dot  (gcc contracts to fnmadd(2, dot, qn+bn))
@@ -1329,7 +1348,7 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_f32s_kernel(const Stream
         if (__ballot(any)) {  // rare: a few hundred rows per query per million
             const int row_t = tile_cur * TR + 4 * g;
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
+            for (int h = 0; h < NH; ++h)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int row = row_t + j;
@@ -1360,15 +1379,18 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_f32s_kernel(const Stream
 }
 
 hipError_t launch_scan_f32_stream(const StreamParams& p, int grid, hipStream_t s) {
-    static bool attr_set[64] = {};
+    static bool attr_set[64][2] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-    if (!attr_set[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(scan_f32s_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kWideLds);
+    const int v = p.batches_per_pass == 2 ? 1 : 0;
+    const void* fn = v ? reinterpret_cast<const void*>(scan_f32s_kernel<2>) : reinterpret_cast<const void*>(scan_f32s_kernel<1>);
+    if (!attr_set[dev][v]) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kWideLds);
         if (e != hipSuccess) return e;
-        attr_set[dev] = true;
+        attr_set[dev][v] = true;
     }
-    hipLaunchKernelGGL(scan_f32s_kernel, dim3(grid), dim3(kScanThreads), kWideLds, s, p);
+    if (v) hipLaunchKernelGGL(scan_f32s_kernel<2>, dim3(grid), dim3(kScanThreads), kWideLds, s, p);
+    else hipLaunchKernelGGL(scan_f32s_kernel<1>, dim3(grid), dim3(kScanThreads), kWideLds, s, p);
     return hipGetLastError();
 }
 
