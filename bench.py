@@ -279,7 +279,10 @@ def main():
     achieved = algo_bytes / kern_avg_s / 1e9 if kern_avg_s > 0 else 0.0
     # launches of at least two batches share a pass over the rows between two batches (VSEARCH_F32_PAIR, default on): a
     # tile is then 128 MFMAs for 8 KB and the kernel is bound by the fp32 MFMA pipe, not by HBM
-    pair = os.environ.get("VSEARCH_F32_PAIR", "1") != "0" and S >= 2
+    # (the library's rule, vs_api.hip bf_launch: shards with at least 96 tiles of 16 rows per workgroup and pass)
+    n_cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    pair_env = int(os.environ.get("VSEARCH_F32_PAIR", "1") or 1)
+    pair = S >= 2 and min(steps, S) >= 2 and (pair_env > 1 or (pair_env == 1 and ((rows_local + 15) // 16) // max(min(n_cus, 256), 1) >= 96))
     mfma_tflops = 2.0 * BATCH * rows_local * DIM / max(kern_per_batch_s, 1e-12) / 1e12
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic_bf_scan.json")

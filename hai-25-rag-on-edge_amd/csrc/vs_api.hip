@@ -40,6 +40,7 @@ constexpr int kMaxNprobe = 256;
 constexpr int kSlotWords = 32 * vs::kIvfSlots;  // per-batch slot minima of the IVF list scan (in the zeroed block)
 constexpr int kMaxLanes = 4;
 constexpr int kMaxMulti = 32;  // batches per persistent scan launch
+constexpr int kPairMinTiles = 96;   // tiles per workgroup and pass from which the fp32 streaming scan pairs batches
 constexpr int kIvfHostGroups = 4;  // launch groups per chunk of the host-buffer IVF call
 constexpr int64_t kIvfHostChunk = (int64_t)kIvfHostGroups * kMaxMulti * 32;
 constexpr int kWideLanesMax = 4;  // streams (and scratch sets) the launch groups of one wide IVF call may be dealt to
@@ -114,6 +115,8 @@ struct vs_index {
         float* part_d = nullptr;    // [kMaxMulti][32][kSlotStride][16]
         int32_t* part_i = nullptr;
         float* seed_qnorm = nullptr; // [kMaxMulti][32]   scratch of launch_seed
+        float* qfrag = nullptr;      // [kMaxMulti][2][8][64][4] queries in MFMA B-fragment order (fp32 streaming scan)
+        int8_t* q8frag = nullptr;    // [kMaxMulti][2][2][64][16] byte queries in B-fragment order (wide int8 scan)
         float* seed_wmin = nullptr;  // [kMaxMulti][kSeedWaves][32]
         float* tau0 = nullptr;       // [kMaxMulti][32]   bounds of the current multi-batch launch
         // wide int8 scan (several batches per pass over the rows): prepared queries + per-query candidate lists
@@ -272,6 +275,8 @@ void free_all(vs_index* h) {
         if (L.part_d) (void)hipFree(L.part_d);
         if (L.part_i) (void)hipFree(L.part_i);
         if (L.seed_qnorm) (void)hipFree(L.seed_qnorm);
+        if (L.qfrag) (void)hipFree(L.qfrag);
+        if (L.q8frag) (void)hipFree(L.q8frag);
         if (L.seed_wmin) (void)hipFree(L.seed_wmin);
         if (L.tau0) (void)hipFree(L.tau0);
         void* wide[] = {L.q8, L.qterm, L.wcnt, L.wcand_d, L.wcand_i, L.wbuf};
@@ -459,6 +464,8 @@ int alloc_scratch(vs_index* h) {
             vs_index::Lane& L = h->lane[i];
             if ((rc = dev_alloc(&L.slots, nslot))) return rc;
             if ((rc = dev_alloc(&L.seed_qnorm, (size_t)kMaxMulti * 32))) return rc;
+            if ((rc = dev_alloc(&L.qfrag, (size_t)kMaxMulti * 4096))) return rc;
+            if ((rc = dev_alloc(&L.q8frag, (size_t)kMaxMulti * 4096))) return rc;
             if ((rc = dev_alloc(&L.seed_wmin, (size_t)kMaxMulti * vs::kSeedWaves * 32))) return rc;
             if ((rc = dev_alloc(&L.tau0, (size_t)kMaxMulti * 32))) return rc;
             if ((rc = dev_alloc(&L.done, kMaxMulti))) return rc;
@@ -592,7 +599,7 @@ int g_i8_wide = [] {
 }();
 
 // tuning knob (VSEARCH_F32_PAIR=0): the fp32 streaming scan makes one pass over the rows per batch (HBM bound) instead of
-// one per two batches (MFMA bound)
+// one per two batches (MFMA bound); 2 = pair on shards of any size (default 1: from kPairMinTiles tiles per workgroup on)
 int g_f32_pair = [] {
     const char* e = getenv("VSEARCH_F32_PAIR");
     return e ? atoi(e) : 1;
@@ -683,8 +690,10 @@ int bf_launch(vs_index* h, vs_index::Lane& L, const float* q_dev, int nb, int B,
         sp.qnorm = L.seed_qnorm;
         sp.wmin = L.seed_wmin;
         sp.tau0 = L.tau0;
+        sp.qfrag = L.qfrag;
         if (i8_seed) {  // queries as bytes + constant terms + the "not byte valued" verdict: int8 seed and wide int8 scan
             sp.q8 = L.q8;
+            sp.q8frag = L.q8frag;
             sp.qterm = L.qterm;
             sp.invalid = invalid;
         }
@@ -721,6 +730,7 @@ int bf_launch(vs_index* h, vs_index::Lane& L, const float* q_dev, int nb, int B,
             wp.rterm = h->d_rterm;
             wp.n_rows = h->n_rows;
             wp.q8 = L.q8;
+            wp.q8frag = L.q8frag;
             wp.qterm = L.qterm;
             wp.tau0 = L.tau0;
             wp.invalid = invalid;
@@ -740,6 +750,7 @@ int bf_launch(vs_index* h, vs_index::Lane& L, const float* q_dev, int nb, int B,
             sp.n_rows = h->n_rows;
             sp.q = q_dev;
             sp.q_batch_stride = (int64_t)B * vs::kDim;
+            sp.qfrag = L.qfrag;
             sp.qnorm = L.seed_qnorm;
             sp.tau0 = L.tau0;
             sp.n_batches = nb;
@@ -747,8 +758,10 @@ int bf_launch(vs_index* h, vs_index::Lane& L, const float* q_dev, int nb, int B,
             sp.metric = h->metric;
             sp.id_offset = (int32_t)h->id_offset;
             sp.sink = sink;
-            sp.batches_per_pass = (g_f32_pair && nb >= 2) ? 2 : 1;
             const int sgrid = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(h->num_cus, vs::kSlotStride), tiles_total));
+            // two batches per pass pay where a workgroup has many tiles per pass (1 M rows: 244, + 14 %); on a small shard
+            // (125 K rows: 30 tiles) the per-pass operand fetch and drain weigh more than the halved traffic saves (- 15 %)
+            sp.batches_per_pass = (nb >= 2 && (g_f32_pair > 1 || (g_f32_pair == 1 && tiles_total / sgrid >= kPairMinTiles))) ? 2 : 1;
             HIPCHK(vs::launch_scan_f32_stream(sp, sgrid, s));
             prof_end(h, 0, s);
         }

@@ -82,6 +82,12 @@ struct SeedParams {
     int8_t* q8;              // [n_batches][32][128]
     int32_t* qterm;          // [n_batches][32]
     int32_t* invalid;        // [n_batches]
+    // optional: the queries in MFMA B-fragment order for the fp32 streaming scan, qfrag[batch][h][c][lane] = the four floats
+    // Q[16 h + (lane & 15)][16 c + 4 (lane >> 4) ..] (zeros for padding queries): a wave's operand load is then 1 KB in one
+    // piece (as fragments straight from the row-major queries it is 64 pieces 512 bytes apart per instruction, and eight
+    // waves entering a pass kept a CU's address unit busy for 8 us)
+    float* qfrag;            // [n_batches][2][8][64][4]
+    int8_t* q8frag;          // [n_batches][2][2][64][16] the byte queries likewise: (h, half, lane) -> bytes [64 half + 16 (lane >> 4) ..] of query 16 h + (lane & 15)
 };
 hipError_t launch_seed(const SeedParams& p, hipStream_t s);
 
@@ -120,6 +126,7 @@ struct WideParams {
     const int32_t* rterm;    // [n_rows + 64]
     int64_t n_rows;
     const int8_t* q8;        // [n_batches][32][128] from launch_seed
+    const int8_t* q8frag;    // [n_batches][2][2][64][16] the same in B-fragment order (SeedParams::q8frag)
     const int32_t* qterm;    // [n_batches][32]
     const float* tau0;       // [n_batches][32]
     const int32_t* invalid;  // [n_batches]
@@ -139,6 +146,7 @@ struct StreamParams {
     int64_t n_rows;
     const float* q;          // [n_batches][nq_valid][128] raw queries
     int64_t q_batch_stride;
+    const float* qfrag;      // [n_batches][2][8][64][4] the same queries in B-fragment order (launch_seed)
     const float* qnorm;      // [n_batches][32] from launch_seed
     const float* tau0;       // [n_batches][32]
     int n_batches, nq_valid, metric;

@@ -1065,9 +1065,10 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_i8w_kernel(const WidePar
             const int qrow = 16 * (h % p.bpb) + r;
             const bool live = batch < p.n_batches && qrow < p.nq_valid;
             const int bq = live ? batch * kMaxBatch + qrow : 0;
-            const int8_t* src = p.q8 + (int64_t)bq * kDim;
-            qb[h][0] = *reinterpret_cast<const i32x4*>(src + 16 * g);
-            qb[h][1] = *reinterpret_cast<const i32x4*>(src + 64 + 16 * g);
+            // fragment order (launch_seed): 1 KB per instruction in one piece (a dead block reads batch 0's: masked by thr)
+            const int8_t* src = p.q8frag + (((int64_t)(live ? batch : 0) * 2 + (h % p.bpb)) * 2 * 64 + lane) * 16;
+            qb[h][0] = *reinterpret_cast<const i32x4*>(src);
+            qb[h][1] = *reinterpret_cast<const i32x4*>(src + 64 * 16);
             qt[h] = p.qterm[bq];
             const float t0 = p.tau0[bq];
             const bool dead = !live || p.invalid[live ? batch : 0] != 0;
@@ -1271,14 +1272,14 @@ __global__ __launch_bounds__(kScanThreads, NB == 1 ? 2 : 1) void scan_f32s_kerne
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
             const int batch = min(pass * NB + h / 2, p.n_batches - 1);  // (a pass of the last, odd batch: its second half is dead)
-            const float* qb = p.q + (int64_t)batch * p.q_batch_stride;
             const int qrow = 16 * (h & 1) + r;
             live[h] = qrow < p.nq_valid && pass * NB + h / 2 < p.n_batches;
             qglob[h] = batch * kMaxBatch + (live[h] ? qrow : 0);
-            const float* src = qb + (live[h] ? qrow : 0) * kDim + 4 * g;
+            // fragment order (launch_seed): 1 KB per instruction in one piece
+            const float* src = p.qfrag + (((int64_t)batch * 2 + (h & 1)) * 8 * 64 + lane) * 4;
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
-                const float* pc = src + 16 * c;
+                const float* pc = src + c * 64 * 4;
                 asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(qf[h][c]) : "v"(pc) : "memory");
             }
             const float* pn = p.qnorm + qglob[h];
@@ -1463,12 +1464,37 @@ __global__ __launch_bounds__(256) void seed_qnorm_kernel(const SeedParams p) {
 #pragma unroll
     for (int u = 1; u < 8; ++u) sum = sum + __shfl(acc, b8 + u);
     if (j == 0) p.qnorm[batch * kMaxBatch + row] = sum;
+    if (p.qfrag) {  // B-fragment order for the fp32 streaming scan (see SeedParams)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = tid + 256 * u;  // (h, c, lane)
+            const int fl = idx & 63, c = (idx >> 6) & 7, hh = idx >> 9;
+            const int qrow = 16 * hh + (fl & 15);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (qrow < p.nq_valid) v = *reinterpret_cast<const f32x4*>(qb + qrow * kDim + 16 * c + 4 * (fl >> 4));
+            *reinterpret_cast<f32x4*>(p.qfrag + ((int64_t)batch * 1024 + idx) * 4) = v;
+        }
+    }
     if (p.q8) {
         part += __shfl_xor(part, 1);
         part += __shfl_xor(part, 2);
         part += __shfl_xor(part, 4);
         if (j == 0) p.qterm[batch * kMaxBatch + row] = (int)sum - 256 * part - 4194304;
         if (!q_ok) p.invalid[batch] = 1;  // same value from every thread that sees a bad element
+    }
+    if (p.q8frag) {  // the byte queries in B-fragment order (see SeedParams): thread = (h, half, lane), 16 bytes each
+        const int fl = tid & 63, half = (tid >> 6) & 1, hh = tid >> 7;
+        const int qrow = 16 * hh + (fl & 15);
+        int w[4] = {0, 0, 0, 0};
+        if (qrow < p.nq_valid) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const f32x4 x = *reinterpret_cast<const f32x4*>(qb + qrow * kDim + 64 * half + 16 * (fl >> 4) + 4 * v);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w[v] |= (((int)x[e] - 128) & 0xff) << (8 * e);
+            }
+        }
+        *reinterpret_cast<int4*>(p.q8frag + ((int64_t)batch * 256 + tid) * 16) = make_int4(w[0], w[1], w[2], w[3]);
     }
 }
 
