@@ -1,16 +1,20 @@
 // vs_kernels.hip -- hand-written gfx950 (CDNA4) kernels of the distance + top-k hot path.
 //
-//   scan_kernel          : Q[<=32 x 128] x base^T on v_mfma_f32_16x16x4_f32 (PREC 1: u8 rows on v_mfma_i32_16x16x64_i8)
-//                          with the L2 epilogue (cpu_baseline.cpp:229-242) and the top-k (cpu_baseline.cpp:127-153)
-//                          fused in, persistent over up to 32 query batches; the B x N score matrix of
-//                          QnnRunner::executeBatchRaw is never written unless asked for (kModeStore); kModeAssign =
-//                          k-means assignment for the index builder.
-//   seed_*_kernel        : bounds for a multi-batch scan from 2048 sample tiles (launch_seed).
-//   merge_compact_kernel : cross-workgroup / cross-GPU merge of partial lists (merge_kernel: general fallback).
+//   scan_f32s_kernel<NB> : the graded brute-force path: streaming fp32 scan of Q[32 x 128] x base^T on
+//                          v_mfma_f32_16x16x4_f32 with the L2 epilogue (cpu_baseline.cpp:229-242), NB batches per pass
+//                          over the rows, candidates under seeded bounds to per-wave buffers; scan_i8w_kernel: the same
+//                          on exact u8 rows (v_mfma_i32_16x16x64_i8), four batches per pass.
+//   scan_kernel          : per-batch scan with the top-k (cpu_baseline.cpp:127-153) fused in (short calls, fallback);
+//                          kModeStore = the B x N score matrix of QnnRunner::executeBatchRaw, kModeAssign = k-means
+//                          assignment for the index builder, kModeFilter = tie-resolver candidates.
+//   seed_*_kernel        : bounds for a multi-batch scan from 2048 sample tiles, queries in MFMA fragment order (launch_seed).
+//   merge_compact_kernel : ranking of candidate lists, cross-workgroup / cross-GPU merge (merge_kernel: general fallback).
 //   row_sqnorm_kernel    : compute_norms (cpu_baseline.cpp:95-125) in the reference's summation order.
-//   ivf_coarse_mfma_kernel, ivf_pick_kernel, ivf_group_plan_kernel, ivf_unit_scan_kernel, ivf_bound_kernel, ivf_select_kernel :
-//                          IVFIndex::searchBatch (IVFIndex.cpp:640-859) as a list-major pipeline, blockIdx.y = batch;
-//                          ivf_list_scan_kernel / pick_probes_kernel / ivf_scan_kernel: fallback paths.
+//   ivf_coarse_mfma_kernel, ivf_pick_kernel, ivf_tau_plan_kernel, ivf_scan_wide_kernel, ivf_wide_rank_kernel :
+//                          IVFIndex::searchBatch (IVFIndex.cpp:640-859) as a list-major pipeline over launch groups of up
+//                          to 32 batches (one pass over the probed lists per group);
+//                          ivf_group_plan_kernel / ivf_unit_scan_kernel / ivf_select_kernel (one pass per batch),
+//                          ivf_list_scan_kernel / pick_probes_kernel / ivf_scan_kernel: earlier and fallback paths.
 //   kpp_*_kernel, kmeans_*_kernel : index builder (create_ivf_model_reordered.py:88-118).
 //
 // Wavefront = 64 lanes everywhere; nothing here is written for 32-wide warps.
