@@ -189,6 +189,7 @@ struct vs_index {
         int n_waves = 0;
         float* cand_d = nullptr;    // [1024][16][kIvfWideSubCap]
         int32_t* cand_i = nullptr;
+        bool dirty = false;         // the zeroed block may hold a failed call's counts: memset before the next group
         char* slab = nullptr;       // per batch: probes [32][kMaxNprobe] | coarse scores [32][nlist padded]
         long long slab_stride = 0, off_scores = 0;
     } wide[kWideLanesMax];          // scratch sets: consecutive launch groups of one call run on different streams
@@ -1029,6 +1030,7 @@ int ensure_ivf_wide(vs_index* h, int lane) {
     W.zero_words = (size_t)n_sb_max * vs::ivf_wide_plan_words(h->nlist) + nq + 64 + nq * kWideSub;
     if ((rc = dev_alloc(&W.lq, (size_t)n_sb_max * h->nlist * vs::kIvfWideQ))) return rc;
     if ((rc = dev_alloc(&W.zero, W.zero_words))) return rc;
+    HIPCHK(hipMemset(W.zero, 0, W.zero_words * sizeof(int32_t)));
     W.units_cap = (int)std::min<int64_t>(2 * h->n_units_max + 4096, 0x7fffffff / 16);
     if ((rc = dev_alloc(&W.units, (size_t)n_sb_max * W.units_cap * 4))) return rc;
     if ((rc = dev_alloc(&W.tau, nq))) return rc;
@@ -1059,7 +1061,10 @@ int ivf_group_wide_dev(vs_index* h, int lane, const float* q_dev, int nb, int B,
     int32_t* const z_ovf = z_slow + nq;                               // [16]: word 0 = overflow
     int32_t* const invalid = z_ovf + 16;                              // [32] batches with a query that is not byte valued
     int32_t* const z_cnt = z_ovf + 64;                                // [1024][16]
-    HIPCHK(hipMemsetAsync(W.zero, 0, W.zero_words * sizeof(int32_t), s));
+    // The zeroed block is left zeroed by the group's last kernel (ivf_wide_rank_kernel): a memset only after a call that
+    // did not get as far as that launch.
+    if (W.dirty) HIPCHK(hipMemsetAsync(W.zero, 0, W.zero_words * sizeof(int32_t), s));
+    W.dirty = true;
     vs::IvfMulti mb{};
     mb.slab = W.slab_stride;
     mb.q = (long long)B * vs::kDim * sizeof(float);
@@ -1076,6 +1081,7 @@ int ivf_group_wide_dev(vs_index* h, int lane, const float* q_dev, int nb, int B,
     grp.w_q8 = W.q8;
     grp.w_qterm = W.qterm;
     grp.w_invalid = invalid;
+    grp.w_overflow = z_ovf;
     grp.w_cnt = z_plan;
     grp.w_lq = W.lq;
     grp.w_q = vs::kIvfWideQ;
@@ -1165,6 +1171,11 @@ int ivf_group_wide_dev(vs_index* h, int lane, const float* q_dev, int nb, int B,
     m.dbg = g_dbg ? g_dbg + 8192 * 16 : nullptr;
 #endif
     HIPCHK(vs::launch_ivf_wide_rank(m, kIvfWideSubCap, (int64_t)kWideSub * kIvfWideSubCap, wp, s));
+#ifdef VS_STAMPS
+    W.dirty = (wp.diag & 128) != 0;
+#else
+    W.dirty = false;
+#endif
     stage_mark(h, 3, s);
     return VS_OK;
 }

@@ -240,6 +240,7 @@ struct IvfGroup {
     int32_t* w_cnt;                  // [nlist] (pre-set to 0) queries of the GROUP probing each list
     int32_t* w_lq;                   // [nlist][w_q] their slots (batch * 32 + q)
     int w_q;
+    int32_t* w_overflow;      // optional [1]: cleared by the coarse kernel (the wide pipeline's candidate-buffer overflow word)
     int32_t* dbg;             // diagnostic builds (-DVS_STAMPS) only: time stamps of the pick kernel
 };
 

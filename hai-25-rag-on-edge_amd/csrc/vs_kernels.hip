@@ -2413,7 +2413,10 @@ __global__ __launch_bounds__(256) void ivf_coarse_mfma_kernel(const float* __res
                 grp.w_qnorm[qslot] = row < B ? sum : 0.f;
                 grp.w_qterm[qslot] = (int)sum - 256 * part - 4194304;
             }
-            if (!q_ok) grp.w_invalid[blockIdx.y] = 1;
+            // (written as 0 or 1, never left over from the previous group: nobody has to clear it)
+            const int bad = __syncthreads_or(q_ok ? 0 : 1);  // (workgroup-uniform branch: every thread is here)
+            if (tid == 0) grp.w_invalid[blockIdx.y] = bad ? 1 : 0;
+            if (tid == 0 && blockIdx.y == 0 && grp.w_overflow) grp.w_overflow[0] = 0;  // the previous group's verdict has been read
         }
     }
     __syncthreads();
@@ -4464,6 +4467,21 @@ __global__ __launch_bounds__(256) void ivf_wide_rank_kernel(const MergeParams m,
     __shared__ int ci[kCompactCap];
     if (p.sink.overflow[0] || p.slow[qg]) ivf_wide_slow_body(p, qg, cd, ci);  // workgroup-uniform
     else merge_compact_body(m, L, cd, ci);
+    // Last kernel of the launch group: it leaves the group's counters zeroed for the next group (no memset launch per
+    // group).  Every workgroup clears what belongs to its query and a share of the lists' pair counters.
+    __syncthreads();
+#ifdef VS_STAMPS
+    if (p.diag & 128) return;  // diagnostics read the counters afterwards (the API then memsets before every group)
+#endif
+    const int tid = threadIdx.x;
+    if (tid < p.sink.nsub) p.sink.cnt[(int64_t)tid * p.sink.cnt_sub_stride + qg] = 0;
+    if (tid == 0) p.slow[qg] = 0;
+    const int sb = (q / p.B) / kIvfWideBatches;
+    for (int c = q + tid * (int)gridDim.x; c < p.nlist; c += 256 * (int)gridDim.x)
+        p.zero[sb * ivf_wide_plan_words(p.nlist) + (int64_t)c * kIvfWideCntStride] = 0;
+    // (the words every workgroup reads: `overflow` is cleared by the next group's coarse kernel, the batches' "not byte
+    // valued" flags are written as 0 or 1 there; a counter of finished workgroups here would be one contended atomic
+    // per query and cost more than the memset it saves -- measured)
 }
 
 hipError_t launch_ivf_wide_rank(const MergeParams& m, int64_t stride_g, int64_t stride_q, const IvfWideParams& p, hipStream_t s) {
