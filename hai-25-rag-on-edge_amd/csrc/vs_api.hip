@@ -1936,7 +1936,7 @@ static int ivf_create_impl(const float* vectors, int64_t n_rows, int dim, const 
             for (int c = 0; c < nlist; ++c) {
                 toff[c] = (int32_t)t;
                 tdelta[c] = (int32_t)t - loc_off[c];
-                t += ((int64_t)(loc_off[c + 1] - loc_off[c]) + 31) & ~31ll;
+                t += ((int64_t)(loc_off[c + 1] - loc_off[c]) + vs::kIvfWideUnit - 1) / vs::kIvfWideUnit * vs::kIvfWideUnit;
             }
             toff[nlist] = (int32_t)t;
             if (t + 64 >= (1ll << 31)) {  // (padded rows are int32 like rows)

@@ -314,6 +314,10 @@ hipError_t launch_ivf_select(const IvfSelectParams& p, int B, hipStream_t s, int
 constexpr int kIvfWideBatches = 32;  // = a whole launch group: every resident list is read once per 1024 queries
 constexpr int kIvfWideQ = kIvfWideBatches * kMaxBatch;  // query slots per super-batch
 constexpr int kIvfTauRows = 256;                         // rows of the nearest list that seed a query's bound
+#ifndef VS_WIDE_UNIT
+#define VS_WIDE_UNIT 32
+#endif
+constexpr int kIvfWideUnit = VS_WIDE_UNIT;  // rows per unit of the wide scan's plan (lists are padded to multiples of it)
 constexpr int kIvfWideCntStride = 32;
 constexpr long long ivf_wide_plan_words(int nlist) { return (long long)nlist * kIvfWideCntStride + 16; }
 struct IvfWideParams {

@@ -3868,8 +3868,7 @@ __device__ __forceinline__ void ivf_tau_body(const IvfWideParams& p, const int w
 // the list's query table: (first row, chunk end, list, first slot | end slot << 16).  S = 256 (a record costs between 1
 // and 16 column blocks beside its rows; every further record of a unit reads the unit's rows again) unless the plan would
 // not fit `units_cap`, then the next power of two that does (1024 = no split always fits).
-constexpr int kIvfWideUnit = 32;  // rows per unit: two 16-row MFMA tiles
-constexpr int kIvfWideTiles = kIvfWideUnit / 16;
+constexpr int kIvfWideTiles = kIvfWideUnit / 16;  // 16-row MFMA tiles per unit
 constexpr int kIvfWideSplits = 3;  // S = 256 << i
 constexpr int kPlanThreads = 256, kPlanWaves = kPlanThreads / 64, kPlanClasses = 16;
 __device__ __forceinline__ void ivf_plan_body(const IvfWideParams& p, const int sb, const int slice, const int nsl) {
