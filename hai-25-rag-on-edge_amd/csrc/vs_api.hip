@@ -596,7 +596,7 @@ int g_seed_i8 = [] {
 int g_i8_wide = [] {
     const char* e = getenv("VSEARCH_I8_WIDE");
     const int v = e ? atoi(e) : 8;
-    return v >= 8 ? 8 : (v >= 4 ? 4 : 0);
+    return v >= 12 ? 12 : (v >= 8 ? 8 : (v >= 4 ? 4 : 0));
 }();
 
 // tuning knob (VSEARCH_F32_PAIR=0): the fp32 streaming scan makes one pass over the rows per batch (HBM bound) instead of

@@ -987,7 +987,7 @@ __device__ __forceinline__ void sink_bin_wave(const CandSink& p, int wb, int n, 
 constexpr int kWideLds = kRingBytes + 64;
 
 template <int NQH>
-__global__ __launch_bounds__(kScanThreads, 2) void scan_i8w_kernel(const WideParams p) {
+__global__ __launch_bounds__(kScanThreads, NQH <= 8 ? 2 : 1) void scan_i8w_kernel(const WideParams p) {
     typedef int i32x4 __attribute__((ext_vector_type(4)));
     constexpr int TR = 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1061,7 +1061,7 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_i8w_kernel(const WidePar
     // per-pass state: B operands of the NQH column blocks, the queries' constant terms and integer bounds.
     // d = qt + rt - 2 acc < tau  <=>  2 acc - rt > qt - tau =: thr  (the hot loop never forms d)
     i32x4 qb[NQH][2];
-    int qt[NQH], thr[NQH], thr2[NQH], qglob[NQH];
+    int qt[NQH], thr[NQH];  // (thr >> 1 and the query's global index are formed where they are used: registers)
     auto load_pass = [&](int pass) __attribute__((always_inline)) {
 #pragma unroll
         for (int h = 0; h < NQH; ++h) {
@@ -1079,9 +1079,7 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_i8w_kernel(const WidePar
             // d < tau0 for integer d  <=>  d < ceil(tau0)  (tau0 is next_up of an integer-valued float, or +inf; distances
             // are below 2^24, so any bound from 2^26 on admits everything)
             const int ti = (int)ceilf(fminf(fmaxf(t0, -67108864.f), 67108864.f));
-            thr[h] = dead ? 0x7fffffff : qt[h] - ti;
-            thr2[h] = dead ? 0x7fffffff : (thr[h] >> 1);  // floor: an odd thr is lowered by one (see the hot loop)
-            qglob[h] = bq;
+            thr[h] = dead ? 0x7fffffff : qt[h] - ti;  // (the hot loop compares with thr >> 1: floor, an odd thr is lowered by one)
         }
     };
 
@@ -1135,7 +1133,7 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_i8w_kernel(const WidePar
             int emax = max(max(acc[0][0], acc[0][1]), max(acc[0][2], acc[0][3]));
 #pragma unroll
             for (int rg = 1; rg < 4; ++rg) emax = max(max(emax, acc[rg][0]), max(max(acc[rg][1], acc[rg][2]), acc[rg][3]));
-            hit |= emax > thr2[h] ? (1u << h) : 0u;
+            hit |= emax > (thr[h] >> 1) ? (1u << h) : 0u;
         }
         // wave-uniform union of the hit bits (DPP or-reduction)
         unsigned um = hit;
@@ -1165,7 +1163,8 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_i8w_kernel(const WidePar
                             if (pass && pos < p.sink.wcap) {
                                 // the integer the fp32 path computes exactly: ||q||^2 + ||b||^2 - 2 q.b
                                 const int d = qt[h] + rtv[rg][j] - 2 * acc[j];
-                                wbuf[pos] = make_int4(qglob[h], __builtin_bit_cast(int, (float)d), row + p.id_offset, 0);
+                                // (a block that hits is live: its query is batch pass * NB + h / bpb, row 16 (h % bpb) + r)
+                                wbuf[pos] = make_int4((pass_cur * NB + h / p.bpb) * kMaxBatch + 16 * (h % p.bpb) + r, __builtin_bit_cast(int, (float)d), row + p.id_offset, 0);
                             }
                             wbase += __popcll(mask);
                         }
@@ -1400,20 +1399,22 @@ hipError_t launch_scan_f32_stream(const StreamParams& p, int grid, hipStream_t s
 }
 
 hipError_t launch_scan_i8_wide(const WideParams& p, int grid, int nqh, hipStream_t s) {
-    static bool attr_set[64][2] = {};
+    static bool attr_set[64][3] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     auto k4 = scan_i8w_kernel<4>;
     auto k8 = scan_i8w_kernel<8>;
-    const int which = nqh == 8 ? 1 : 0;
-    if (nqh != 4 && nqh != 8) return hipErrorInvalidValue;
+    auto k12 = scan_i8w_kernel<12>;
+    const int which = nqh == 12 ? 2 : nqh == 8 ? 1 : 0;
+    if (nqh != 4 && nqh != 8 && nqh != 12) return hipErrorInvalidValue;
+    const void* fn = which == 2 ? reinterpret_cast<const void*>(k12) : which ? reinterpret_cast<const void*>(k8) : reinterpret_cast<const void*>(k4);
     if (!attr_set[dev][which]) {
-        hipError_t e = hipFuncSetAttribute(which ? reinterpret_cast<const void*>(k8) : reinterpret_cast<const void*>(k4),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, kWideLds);
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kWideLds);
         if (e != hipSuccess) return e;
         attr_set[dev][which] = true;
     }
-    if (which) hipLaunchKernelGGL(k8, dim3(grid), dim3(kScanThreads), kWideLds, s, p);
+    if (which == 2) hipLaunchKernelGGL(k12, dim3(grid), dim3(kScanThreads), kWideLds, s, p);
+    else if (which) hipLaunchKernelGGL(k8, dim3(grid), dim3(kScanThreads), kWideLds, s, p);
     else hipLaunchKernelGGL(k4, dim3(grid), dim3(kScanThreads), kWideLds, s, p);
     return hipGetLastError();
 }
