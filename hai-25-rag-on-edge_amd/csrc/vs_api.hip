@@ -80,6 +80,11 @@ struct vs_index {
     // int8 data path: only when every base value is an integer in [0, 255]
     int8_t* d_vecs_u8 = nullptr;   // [n_rows][128] bytes (x - 128)
     int32_t* d_rterm = nullptr;    // [n_rows + 64] ||b||^2 - 256 * sum(b - 128)
+    // the seed's sample tiles, compact and in MFMA fragment order (SeedParams::sample_*; brute-force indexes)
+    float* d_seed_f32 = nullptr;
+    float* d_seed_bnorm = nullptr;
+    int8_t* d_seed_u8 = nullptr;
+    int32_t* d_seed_rterm = nullptr;
     // wide IVF scan: the byte rows once more, every list padded to a multiple of 32 rows ("padded rows") and stored as
     // 16-row MFMA tiles of 2 KB, [half of the row][16-byte chunk][row][16 bytes] -- a wave's A-operand load is then 1 KB
     // of consecutive bytes (from the row-major copy the same load touches 16 B in each of 64 places)
@@ -287,7 +292,7 @@ void free_all(vs_index* h) {
         if (L.s) (void)hipStreamDestroy(L.s);
     }
     if (h->fork) (void)hipEventDestroy(h->fork);
-    void* ptrs[] = {h->d_vecs, h->d_norm, h->d_vecs_u8, h->d_rterm, h->d_vecs_t8, h->d_nrh_t, h->d_rterm_t, h->d_r2o_t, h->d_tdelta, h->d_chunk_trow0, h->d_invalid, h->d_centroids, h->d_cnorm, h->d_offsets, h->d_r2o, h->d_q,
+    void* ptrs[] = {h->d_vecs, h->d_norm, h->d_vecs_u8, h->d_rterm, h->d_seed_f32, h->d_seed_bnorm, h->d_seed_u8, h->d_seed_rterm, h->d_vecs_t8, h->d_nrh_t, h->d_rterm_t, h->d_r2o_t, h->d_tdelta, h->d_chunk_trow0, h->d_invalid, h->d_centroids, h->d_cnorm, h->d_offsets, h->d_r2o, h->d_q,
                     h->d_out_d, h->d_out_i,
                     h->d_flags, h->d_scores, h->d_probes, h->d_ipart_d, h->d_ipart_i, h->d_cand,
                     h->d_chunk_list, h->d_chunk_row0, h->d_chunk_rows, h->d_lcnt, h->d_lq, h->d_lbase, h->d_qoff,
@@ -677,9 +682,13 @@ int bf_launch(vs_index* h, vs_index::Lane& L, const float* q_dev, int nb, int B,
         vs::SeedParams sp{};
         sp.base = h->d_vecs;
         sp.bnorm = h->d_norm;
+        sp.sample_f32 = h->d_seed_f32;
+        sp.sample_bnorm = h->d_seed_bnorm;
         if (i8_seed) {  // exact int8 copy of the rows: 16x cheaper seed
             sp.base_u8 = h->d_vecs_u8;
             sp.rterm = h->d_rterm;
+            sp.sample_u8 = h->d_seed_u8;
+            sp.sample_rterm = h->d_seed_rterm;
         }
         sp.n_rows = h->n_rows;
         sp.q = q_dev;
@@ -1634,6 +1643,22 @@ static int bf_create_impl(const float* base_host, int64_t n_rows, int dim, int m
     if (metric == VS_METRIC_L2 && (rc = build_u8_copy(h, base_host, n_rows))) {
         free_all(h);
         return rc;
+    }
+    if ((n_rows + vs::kTileRows - 1) / vs::kTileRows >= 2 * vs::kSeedWaves) {  // shards on which launches are seeded (bf_launch)
+        auto sample = [&]() -> int {
+            int r2;
+            if ((r2 = dev_alloc(&h->d_seed_f32, (size_t)vs::kSeedWaves * 2048)) || (r2 = dev_alloc(&h->d_seed_bnorm, (size_t)vs::kSeedWaves * 16))) return r2;
+            if (h->d_vecs_u8 && ((r2 = dev_alloc(&h->d_seed_u8, (size_t)vs::kSeedWaves * 2048)) || (r2 = dev_alloc(&h->d_seed_rterm, (size_t)vs::kSeedWaves * 16))))
+                return r2;
+            HIPCHK(vs::launch_seed_sample(h->d_vecs, h->d_norm, h->d_vecs_u8, h->d_rterm, n_rows, h->d_seed_f32, h->d_seed_bnorm,
+                                          h->d_seed_u8, h->d_seed_rterm, nullptr));
+            HIPCHK(hipDeviceSynchronize());
+            return VS_OK;
+        };
+        if ((rc = sample())) {
+            free_all(h);
+            return rc;
+        }
     }
     *out = h;
     return VS_OK;

@@ -64,6 +64,13 @@ constexpr int kSeedWaves = 2048;  // sample tiles
 struct SeedParams {
     const float* base;       // [n_rows (+pad)][128]
     const float* bnorm;
+    // optional (launch_seed_sample): the kSeedWaves sample tiles once more, compact and in MFMA A-fragment order -- the seed
+    // reads 1 KB per load instruction out of 4 MB (bytes) / 16 MB (fp32) that stay in L2, instead of 64 pieces per
+    // instruction scattered over the whole shard (which made the address unit, not the arithmetic, set its 24 us)
+    const float* sample_f32;     // [kSeedWaves][8][64][4]   fp32 tile: chunk c, lane (r, g) -> row r, floats 16 c + 4 g ..
+    const float* sample_bnorm;   // [kSeedWaves][16]
+    const int8_t* sample_u8;     // [kSeedWaves][2][64][16]  byte tile: half, lane (r, g) -> row r, bytes 64 half + 16 g ..
+    const int32_t* sample_rterm; // [kSeedWaves][16]
     const int8_t* base_u8;   // optional exact int8 copy (x - 128) + row terms: the seed then runs on v_mfma_i32_16x16x64_i8
     const int32_t* rterm;    //   (16x fewer MFMA cycles) for batches whose queries are byte valued too (q8 / qterm / invalid below are then required)
     int64_t n_rows;
@@ -90,6 +97,9 @@ struct SeedParams {
     int8_t* q8frag;          // [n_batches][2][2][64][16] the byte queries likewise: (h, half, lane) -> bytes [64 half + 16 (lane >> 4) ..] of query 16 h + (lane & 15)
 };
 hipError_t launch_seed(const SeedParams& p, hipStream_t s);
+// gathers the sample tiles of a shard into the compact arrays above (once, at index creation); u8 outputs optional
+hipError_t launch_seed_sample(const float* base, const float* bnorm, const int8_t* base_u8, const int32_t* rterm, int64_t n_rows,
+                              float* sample_f32, float* sample_bnorm, int8_t* sample_u8, int32_t* sample_rterm, hipStream_t s);
 
 // Wide exact-int8 brute-force scan: ONE pass over the byte rows serves NQH 16-query column blocks = NQH / bpb query
 // batches (bpb = 1 for batches of <= 16 queries, else 2), with the bounds of launch_seed in force from the first tile.

@@ -1536,12 +1536,20 @@ __device__ __forceinline__ void seed_body_f32(const SeedParams& p, int batch, in
         bool ok[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int64_t tile = seed_tile(tiles_total, chunk * kSeedTilesPerWave + t0 + u);
+            const int smp = chunk * kSeedTilesPerWave + t0 + u;
+            const int64_t tile = seed_tile(tiles_total, smp);
             ok[u] = tile < tiles_total;  // wave-uniform
             row0[u] = (ok[u] ? tile : 0) * kTileRows;
+            if (p.sample_f32) {  // compact copy in fragment order (1 KB per instruction)
+                const float* sp = p.sample_f32 + ((int64_t)smp * 8 * 64 + (16 * g + r)) * 4;
 #pragma unroll
-            for (int c = 0; c < 8; ++c) a[u][c] = *reinterpret_cast<const f32x4*>(p.base + (row0[u] + r) * kDim + 16 * c + 4 * g);
-            bn[u] = *reinterpret_cast<const f32x4*>(p.bnorm + row0[u] + 4 * g);  // padded by 64
+                for (int c = 0; c < 8; ++c) a[u][c] = *reinterpret_cast<const f32x4*>(sp + c * 64 * 4);
+                bn[u] = *reinterpret_cast<const f32x4*>(p.sample_bnorm + smp * 16 + 4 * g);
+            } else {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) a[u][c] = *reinterpret_cast<const f32x4*>(p.base + (row0[u] + r) * kDim + 16 * c + 4 * g);
+                bn[u] = *reinterpret_cast<const f32x4*>(p.bnorm + row0[u] + 4 * g);  // padded by 64
+            }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -1585,13 +1593,21 @@ __device__ __forceinline__ void seed_body_i8(const SeedParams& p, int batch, int
         bool ok[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int64_t tile = seed_tile(tiles_total, chunk * kSeedTilesPerWave + t0 + u);
+            const int smp = chunk * kSeedTilesPerWave + t0 + u;
+            const int64_t tile = seed_tile(tiles_total, smp);
             ok[u] = tile < tiles_total;  // wave-uniform
             row0[u] = (ok[u] ? tile : 0) * kTileRows;
             // A fragments: bytes k = 16 g .. 16 g + 15 and 64 + 16 g .. of row row0 + r
-            a0[u] = *reinterpret_cast<const i32x4*>(p.base_u8 + (row0[u] + r) * kDim + 16 * g);
-            a1[u] = *reinterpret_cast<const i32x4*>(p.base_u8 + (row0[u] + r) * kDim + 64 + 16 * g);
-            rt[u] = *reinterpret_cast<const i32x4*>(p.rterm + row0[u] + 4 * g);  // padded by 64
+            if (p.sample_u8) {  // compact copy in fragment order (1 KB per instruction)
+                const int8_t* sp = p.sample_u8 + ((int64_t)smp * 2 * 64 + (16 * g + r)) * 16;
+                a0[u] = *reinterpret_cast<const i32x4*>(sp);
+                a1[u] = *reinterpret_cast<const i32x4*>(sp + 64 * 16);
+                rt[u] = *reinterpret_cast<const i32x4*>(p.sample_rterm + smp * 16 + 4 * g);
+            } else {
+                a0[u] = *reinterpret_cast<const i32x4*>(p.base_u8 + (row0[u] + r) * kDim + 16 * g);
+                a1[u] = *reinterpret_cast<const i32x4*>(p.base_u8 + (row0[u] + r) * kDim + 64 + 16 * g);
+                rt[u] = *reinterpret_cast<const i32x4*>(p.rterm + row0[u] + 4 * g);  // padded by 64
+            }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -1653,6 +1669,41 @@ __global__ __launch_bounds__(1024) void seed_tau_kernel(const SeedParams p) {
         }
         if (lane == 0) p.tau0[batch * kMaxBatch + q] = kth < VS_INF ? next_up(kth) : VS_INF;
     }
+}
+
+// Gathers sample tile blockIdx.x of the shard into the compact, fragment-ordered arrays of SeedParams (index creation).
+__global__ __launch_bounds__(256) void seed_sample_kernel(const float* __restrict__ base, const float* __restrict__ bnorm,
+                                                          const int8_t* __restrict__ base_u8, const int32_t* __restrict__ rterm,
+                                                          int64_t n_rows, float* sample_f32, float* sample_bnorm, int8_t* sample_u8,
+                                                          int32_t* sample_rterm) {
+    const int smp = blockIdx.x, tid = threadIdx.x;
+    const int64_t tiles_total = (n_rows + kTileRows - 1) / kTileRows;
+    const int64_t tile = seed_tile(tiles_total, smp);
+    const int64_t row0 = (tile < tiles_total ? tile : 0) * kTileRows;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {  // fp32: (c, lane) -> row r = lane & 15, floats 16 c + 4 (lane >> 4) ..
+        const int idx = tid + 256 * u, fl = idx & 63, c = idx >> 6;
+        const int64_t row = min(row0 + (fl & 15), n_rows - 1);  // (rows past the end are masked by the seed itself)
+        *reinterpret_cast<f32x4*>(sample_f32 + ((int64_t)smp * 512 + idx) * 4) =
+            *reinterpret_cast<const f32x4*>(base + row * kDim + 16 * c + 4 * (fl >> 4));
+    }
+    if (tid < 16) sample_bnorm[smp * 16 + tid] = bnorm[min(row0 + tid, n_rows - 1)];
+    if (sample_u8) {
+        if (tid < 128) {  // bytes: (half, lane) -> row r, bytes 64 half + 16 (lane >> 4) ..
+            const int fl = tid & 63, half = tid >> 6;
+            const int64_t row = min(row0 + (fl & 15), n_rows - 1);
+            *reinterpret_cast<int4*>(sample_u8 + ((int64_t)smp * 128 + tid) * 16) =
+                *reinterpret_cast<const int4*>(base_u8 + row * kDim + 64 * half + 16 * (fl >> 4));
+        }
+        if (tid < 16) sample_rterm[smp * 16 + tid] = rterm[min(row0 + tid, n_rows - 1)];
+    }
+}
+
+hipError_t launch_seed_sample(const float* base, const float* bnorm, const int8_t* base_u8, const int32_t* rterm, int64_t n_rows,
+                              float* sample_f32, float* sample_bnorm, int8_t* sample_u8, int32_t* sample_rterm, hipStream_t s) {
+    hipLaunchKernelGGL(seed_sample_kernel, dim3(kSeedWaves), dim3(256), 0, s, base, bnorm, base_u8, rterm, n_rows, sample_f32,
+                       sample_bnorm, base_u8 ? sample_u8 : nullptr, sample_rterm);
+    return hipGetLastError();
 }
 
 hipError_t launch_seed(const SeedParams& p, hipStream_t s) {
