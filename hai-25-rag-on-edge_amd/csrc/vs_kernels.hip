@@ -1000,10 +1000,12 @@ __global__ __launch_bounds__(kScanThreads, NQH <= 8 ? 2 : 1) void scan_i8w_kerne
     const int T = (tiles_total - (int)blockIdx.x + G - 1) / G;  // tiles of this workgroup per pass (grid <= tiles_total)
     const int NB = NQH / p.bpb;                                  // batches per pass
     const int n_pass = (p.n_batches + NB - 1) / NB;
-    const int total = T * n_pass;                                // tickets of this workgroup
-    if (threadIdx.x == 0) lds_ticket[0] = 2 * kScanWaves;
-    __syncthreads();
-
+    (void)lds_ticket;
+    // a wave takes whole passes (or the m-th part of passes where they do not deal evenly to the 8 waves): see
+    // scan_f32s_kernel.  No shared ticket, no barrier.
+    const int low = n_pass & -n_pass;
+    const int m_log = low >= kScanWaves ? 0 : (low == 4 ? 1 : (low == 2 ? 2 : 3));
+    const int n_units = n_pass << m_log;
     char* ring = smem + wave * (kDepth * kSlotBytes);
     unsigned voff[8];
 #pragma unroll
@@ -1036,26 +1038,21 @@ __global__ __launch_bounds__(kScanThreads, NQH <= 8 ? 2 : 1) void scan_i8w_kerne
         fa[c] = (unsigned)(wave * (kDepth * kSlotBytes) + row_in * 128 + ((((c & 1) * 4 + g) ^ ((row_in >> 1) & 7)) << 4));
     }
     const unsigned fa_n = (unsigned)(wave * (kDepth * kSlotBytes) + 8192 + 16 * g);
-    const unsigned ticket_addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) int*)lds_ticket;
-    auto next_ticket = [&]() -> int {
-        int tk = 0;
-        if (lane == 0)
-            asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(tk) : "v"(ticket_addr), "v"(1) : "memory");
-        return __builtin_amdgcn_readfirstlane(tk);
-    };
-    // ticket -> (pass, tile): tickets of a wave only grow, so the pass is tracked incrementally (no division per tile)
-    int dec_pass = 0, dec_base = 0;
-    auto tile_of = [&](int tk, int& pass_out) __attribute__((always_inline)) -> int {
-        if (tk >= total) {
-            pass_out = n_pass;
-            return (int)blockIdx.x;  // past the end: the DMA still goes out (queue accounting), to a tile nobody uses
+    int it_u = wave - kScanWaves, it_n = 0, it_end = 0, it_pass = 0;
+    auto next_tile = [&](int& pass_out) __attribute__((always_inline)) -> int {
+        while (it_n >= it_end) {
+            it_u += kScanWaves;
+            if (it_u >= n_units) {
+                pass_out = n_pass;
+                return (int)blockIdx.x;  // past the end: the DMA still goes out (queue accounting), to a tile nobody uses
+            }
+            it_pass = it_u >> m_log;
+            const int part = it_u & ((1 << m_log) - 1);
+            it_n = (int)(((long long)part * T) >> m_log);
+            it_end = (int)(((long long)(part + 1) * T) >> m_log);
         }
-        while (tk - dec_base >= T) {
-            dec_base += T;
-            ++dec_pass;
-        }
-        pass_out = dec_pass;
-        return (int)blockIdx.x + (tk - dec_base) * G;
+        pass_out = it_pass;
+        return (int)blockIdx.x + (it_n++) * G;
     };
 
     // per-pass state: B operands of the NQH column blocks, the queries' constant terms and integer bounds.
@@ -1085,9 +1082,9 @@ __global__ __launch_bounds__(kScanThreads, NQH <= 8 ? 2 : 1) void scan_i8w_kerne
 
     int4* wbuf = p.sink.wbuf + ((int64_t)blockIdx.x * kScanWaves + wave) * p.sink.wcap;
     int wbase = 0;  // wave-uniform fill of the private candidate buffer
-    int tk_cur = wave, tk_nxt = wave + kScanWaves, pass_cur, pass_nxt;
-    int tile_cur = tile_of(tk_cur, pass_cur);
-    int tile_nxt = tile_of(tk_nxt, pass_nxt);
+    int pass_cur, pass_nxt;
+    int tile_cur = next_tile(pass_cur);
+    int tile_nxt = next_tile(pass_nxt);
     issue_tile(tile_cur, 0);
     issue_tile(tile_nxt, 1);
     int have_pass = -1;
@@ -1098,9 +1095,8 @@ __global__ __launch_bounds__(kScanThreads, NQH <= 8 ? 2 : 1) void scan_i8w_kerne
             have_pass = pass_cur;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // operands are here (and so are both staged tiles)
         }
-        const int tk_new = next_ticket();
         int pass_new;
-        const int tile_new = tile_of(tk_new, pass_new);
+        const int tile_new = next_tile(pass_new);
         asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
         const char* src = smem + sl * kSlotBytes;
         i32x4 a0[4], a1[4], rtv[4];
@@ -1172,16 +1168,14 @@ __global__ __launch_bounds__(kScanThreads, NQH <= 8 ? 2 : 1) void scan_i8w_kerne
                 }
             }
         }
-        tk_cur = tk_nxt;
         tile_cur = tile_nxt;
         pass_cur = pass_nxt;
-        tk_nxt = tk_new;
         tile_nxt = tile_new;
         pass_nxt = pass_new;
     };
-    while (tk_cur < total) {
+    while (pass_cur < n_pass) {
         step(0);
-        if (tk_cur >= total) break;
+        if (pass_cur >= n_pass) break;
         step(1);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // retire the tail prefetches before the wave ends
@@ -1208,10 +1202,15 @@ __global__ __launch_bounds__(kScanThreads, NB == 1 ? 2 : 1) void scan_f32s_kerne
     const int G = (int)gridDim.x;
     const int T = (tiles_total - (int)blockIdx.x + G - 1) / G;  // tiles of this workgroup per batch (grid <= tiles_total)
     const int n_pass = (p.n_batches + NB - 1) / NB;
-    const int total = T * n_pass;                                 // tickets of this workgroup
-    if (threadIdx.x == 0) lds_ticket[0] = 2 * kScanWaves;
-    __syncthreads();  // the only barrier of the kernel
-
+    (void)lds_ticket;
+    // Work of a wave = whole passes, not tiles dealt one by one: a pass costs its operand fetch and a drain on entry (1.3 us
+    // with one batch per pass, 6.6 us with two), so a wave should enter as few passes as possible.  The workgroup's passes
+    // are cut into `m` parts of its T tiles each, m the smallest number for which the units (pass, part) deal evenly to
+    // the 8 waves (m = 8 / gcd(n_pass, 8): 16 passes -> a wave takes 2 whole passes instead of entering all 16).  No shared
+    // ticket, no barrier: waves never meet.
+    const int low = n_pass & -n_pass;                                   // lowest set bit of n_pass
+    const int m_log = low >= kScanWaves ? 0 : (low == 4 ? 1 : (low == 2 ? 2 : 3));
+    const int n_units = n_pass << m_log;
     char* ring = smem + wave * (kDepth * kSlotBytes);
     unsigned voff[8];
 #pragma unroll
@@ -1241,25 +1240,22 @@ __global__ __launch_bounds__(kScanThreads, NB == 1 ? 2 : 1) void scan_f32s_kerne
 #pragma unroll
     for (int c = 0; c < 8; ++c) fa[c] = (unsigned)(wave * (kDepth * kSlotBytes) + r * 512 + (((4 * c + g) ^ r) << 4));
     const unsigned fa_n = (unsigned)(wave * (kDepth * kSlotBytes) + 8192 + 16 * g);
-    const unsigned ticket_addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) int*)lds_ticket;
-    auto next_ticket = [&]() -> int {
-        int tk = 0;
-        if (lane == 0)
-            asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(tk) : "v"(ticket_addr), "v"(1) : "memory");
-        return __builtin_amdgcn_readfirstlane(tk);
-    };
-    int dec_pass = 0, dec_base = 0;
-    auto tile_of = [&](int tk, int& pass_out) __attribute__((always_inline)) -> int {
-        if (tk >= total) {
-            pass_out = n_pass;
-            return (int)blockIdx.x;  // past the end: the DMA still goes out (queue accounting), to a tile nobody uses
+    // this wave's position: unit it_u (= pass * m + part), tile index it_n of the workgroup's T inside [.., it_end)
+    int it_u = wave - kScanWaves, it_n = 0, it_end = 0, it_pass = 0;
+    auto next_tile = [&](int& pass_out) __attribute__((always_inline)) -> int {
+        while (it_n >= it_end) {  // (also skips empty parts: T < m)
+            it_u += kScanWaves;
+            if (it_u >= n_units) {
+                pass_out = n_pass;
+                return (int)blockIdx.x;  // past the end: the DMA still goes out (queue accounting), to a tile nobody uses
+            }
+            it_pass = it_u >> m_log;
+            const int part = it_u & ((1 << m_log) - 1);
+            it_n = (int)(((long long)part * T) >> m_log);
+            it_end = (int)(((long long)(part + 1) * T) >> m_log);
         }
-        while (tk - dec_base >= T) {
-            dec_base += T;
-            ++dec_pass;
-        }
-        pass_out = dec_pass;
-        return (int)blockIdx.x + (tk - dec_base) * G;
+        pass_out = it_pass;
+        return (int)blockIdx.x + (it_n++) * G;
     };
 
     // per-batch state: the 32 queries as B operands (qf[h][c][i] = Q[16 h + r][16 c + 4 g + i]), their norms and bounds.
@@ -1294,9 +1290,9 @@ __global__ __launch_bounds__(kScanThreads, NB == 1 ? 2 : 1) void scan_f32s_kerne
 
     int4* wbuf = p.sink.wbuf + ((int64_t)blockIdx.x * kScanWaves + wave) * p.sink.wcap;
     int wbase = 0;  // wave-uniform fill of the private candidate buffer
-    int tk_cur = wave, tk_nxt = wave + kScanWaves, pass_cur, pass_nxt;
-    int tile_cur = tile_of(tk_cur, pass_cur);
-    int tile_nxt = tile_of(tk_nxt, pass_nxt);
+    int pass_cur, pass_nxt;
+    int tile_cur = next_tile(pass_cur);
+    int tile_nxt = next_tile(pass_nxt);
     issue_tile(tile_cur, 0);
     issue_tile(tile_nxt, 1);
     int have_pass = -1;
@@ -1309,9 +1305,8 @@ __global__ __launch_bounds__(kScanThreads, NB == 1 ? 2 : 1) void scan_f32s_kerne
             have_pass = pass_cur;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // operands are here (and so are both staged tiles)
         }
-        const int tk_new = next_ticket();
         int pass_new;
-        const int tile_new = tile_of(tk_new, pass_new);
+        const int tile_new = next_tile(pass_new);
         asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
         const char* src = smem + sl * kSlotBytes;
         f32x4 a[8];
@@ -1366,16 +1361,14 @@ __global__ __launch_bounds__(kScanThreads, NB == 1 ? 2 : 1) void scan_f32s_kerne
                     }
                 }
         }
-        tk_cur = tk_nxt;
         tile_cur = tile_nxt;
         pass_cur = pass_nxt;
-        tk_nxt = tk_new;
         tile_nxt = tile_new;
         pass_nxt = pass_new;
     };
-    while (tk_cur < total) {
+    while (pass_cur < n_pass) {
         step(0);
-        if (tk_cur >= total) break;
+        if (pass_cur >= n_pass) break;
         step(1);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // retire the tail prefetches before the wave ends
