@@ -53,6 +53,16 @@ class Timing(C.Structure):
     ]
 
 
+class Q8Encodings(C.Structure):
+    """vs_q8_encodings: QNN scale-offset encodings, real = scale * (q + offset) (QnnRunner.cpp:490-508)."""
+    _fields_ = [
+        ("input_scale", C.c_float),
+        ("weight_scale", C.c_float),
+        ("weight_offset", C.c_int32),
+        ("output_scale", C.c_float),
+    ]
+
+
 def hip_runtime_dir() -> str:
     """Directory of the ROCm HIP runtime the stand-alone CLIs load (tests run them as child processes)."""
     return os.environ.get("ROCM_PATH", "/opt/rocm") + "/lib"
@@ -140,6 +150,17 @@ def lib():
         "vs_bf_search_sharded": (i32, [vp, vp, vp, i64, i32, vp, vp, C.POINTER(Timing)]),
         "vs_ivf_search_sharded": (i32, [vp, vp, vp, i64, i32, i32, vp, vp, C.POINTER(i64), C.POINTER(Timing)]),
         "vs_ivf_search_dev_sharded": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp]),
+        "vs_q8_create": (i32, [vp, i64, i32, C.POINTER(Q8Encodings), i32, i64, C.POINTER(vp)]),
+        "vs_q8_destroy": (None, [vp]),
+        "vs_q8_num_docs": (i64, [vp]),
+        "vs_q8_dim": (i32, [vp]),
+        "vs_q8_batch": (i32, [vp]),
+        "vs_q8_output_scale": (C.c_float, [vp]),
+        "vs_q8_get_encodings": (i32, [vp, C.POINTER(Q8Encodings)]),
+        "vs_q8_execute_dev": (i32, [vp, vp, i32, vp, i64, vp]),
+        "vs_q8_execute": (i32, [vp, vp, i32, vp]),
+        "vs_q8_search_dev": (i32, [vp, vp, i32, i32, i32, vp, vp, vp]),
+        "vs_q8_search": (i32, [vp, vp, i64, i32, vp, vp]),
         "vs_prof_enable": (i32, [vp, i32]),
         "vs_prof_read": (i32, [vp, i32, C.POINTER(C.c_double), C.POINTER(i64)]),
         "vs_prof_read_launches": (i32, [vp, i32, vp, i64, C.POINTER(i64)]),
@@ -330,6 +351,80 @@ class BruteForceIndex(_Index):
     def scores_dev(self, q_ptr: int, B: int, scores_ptr: int, ld: int, stream: int):
         """QnnRunner::executeBatchRaw analogue: raw [B, ld] score matrix on the device."""
         _check(lib().vs_bf_scores_dev(self._h, q_ptr, B, scores_ptr, ld, stream))
+
+
+class Q8Runner:
+    """The reference's device runner with its UFIXED_POINT_8 I/O (QnnRunner.h:18-55): the database is baked in at
+    construction, ``executeBatchRaw`` returns the raw uint8 [B, N] inner-product scores, ``search`` adds
+    find_top_k_int8 (main.cpp:30-57).  Method names follow QnnRunner."""
+
+    def __init__(self, base, input_scale=None, weight_scale=None, weight_offset: int = 0, output_scale=None,
+                 device: int = 0, id_offset: int = 0):
+        self._h = C.c_void_p()
+        base = _f32c(base)
+        if base.ndim != 2:
+            raise ValueError("base must be [N, d]")
+        enc = None
+        if input_scale is not None or weight_scale is not None or output_scale is not None:
+            if input_scale is None or weight_scale is None or output_scale is None:
+                raise ValueError("give all three scales or none (None = the runner's hard-coded encodings)")
+            enc = C.byref(Q8Encodings(input_scale, weight_scale, weight_offset, output_scale))
+        _check(lib().vs_q8_create(_p(base), base.shape[0], base.shape[1], enc, device, id_offset, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().vs_q8_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def getNumDocs(self) -> int:
+        return int(lib().vs_q8_num_docs(self._h))
+
+    def getDim(self) -> int:
+        return int(lib().vs_q8_dim(self._h))
+
+    def getBatchSize(self) -> int:
+        return int(lib().vs_q8_batch(self._h))
+
+    def getOutputScale(self) -> float:
+        return float(lib().vs_q8_output_scale(self._h))
+
+    def encodings(self) -> Q8Encodings:
+        e = Q8Encodings()
+        _check(lib().vs_q8_get_encodings(self._h, C.byref(e)))
+        return e
+
+    def executeBatchRaw(self, batch_queries) -> np.ndarray:
+        """executeBatchRaw + getRawOutputBuffer (QnnRunner.cpp:608-645): uint8 [B, N]."""
+        q = _f32c(batch_queries).reshape(-1, self.getDim())
+        out = np.empty((q.shape[0], self.getNumDocs()), dtype=np.uint8)
+        _check(lib().vs_q8_execute(self._h, _p(q), q.shape[0], _p(out)))
+        return out
+
+    def execute_dev(self, q_ptr: int, B: int, scores_ptr: int, ld: int, stream: int):
+        _check(lib().vs_q8_execute_dev(self._h, q_ptr, B, scores_ptr, ld, stream))
+
+    def search(self, queries, k: int):
+        """The harness loop of main.cpp:201-251: ids [nq, k], uint8 scores [nq, k] (score * getOutputScale() = float)."""
+        q = _f32c(queries).reshape(-1, self.getDim())
+        ids = np.empty((q.shape[0], k), dtype=np.int32)
+        top = np.empty((q.shape[0], k), dtype=np.uint8)
+        _check(lib().vs_q8_search(self._h, _p(q), q.shape[0], k, _p(ids), _p(top)))
+        return ids, top
+
+    def search_dev(self, q_ptr: int, n_batches: int, B: int, k: int, ids_ptr: int, scores_ptr: int, stream: int):
+        _check(lib().vs_q8_search_dev(self._h, q_ptr, n_batches, B, k, ids_ptr, scores_ptr, stream))
 
 
 class IVFIndex(_Index):

@@ -149,6 +149,60 @@ VS_API int vs_bf_search_dev_multi(vs_index* h, const float* queries_dev, int n_b
 VS_API int vs_bf_scores_dev(vs_index* h, const float* queries_dev, int B,
                             float* scores_dev, int64_t ld, void* stream);
 
+/* ------------------------------------------- quantised score path (UFIXED_POINT_8) */
+/* The reference's device runner with its uint8 I/O (qidk_bruteforce/android/app/main/jni):
+ * QnnRunner ctor (QnnRunner.h:20) bakes the database into the graph as uint8 weights;
+ * executeBatchRaw (QnnRunner.cpp:608-645) quantises a [B x d] batch with
+ * quantize_buffer_neon (QnnRunner.cpp:13-55: q8 = sat_u8(trunc(x / input_scale + 0.5)),
+ * offset 0), runs the graph and leaves the raw uint8 [B x N] inner-product scores in
+ * its output buffer (getRawOutputBuffer, QnnRunner.h:37); the harness takes the k
+ * largest per query (find_top_k_int8, main.cpp:30-57) and prints score * output_scale
+ * (main.cpp:244-246).  Here: real = scale * (q + offset) for all three tensors (QNN's
+ * scale-offset encoding, QnnRunner.cpp:490-508; input and output offsets are 0 there),
+ *   ip      = sum_t q8[t] * (w8[t] + weight_offset)                      (int32, exact)
+ *   score8  = sat_u8(trunc(ip * ((input_scale * weight_scale) / output_scale) + 0.5))
+ * with every product and sum rounded separately in fp32 (no fused multiply-add), the
+ * rounding rule of the reference's own quantiser.  What the closed QNN converter / HTP
+ * runtime do inside the graph (weight encoding, accumulator requantisation) is not in the
+ * reference: results are checked against oracle/ (vo_q8_*), parity unpinned.
+ * Equal scores are returned in ascending id order (the reference: whatever its C++
+ * library's heap leaves). */
+typedef struct vs_q8 vs_q8; /* opaque: quantised database, I/O buffers, stream */
+typedef struct vs_q8_encodings {
+    float input_scale;     /* QnnRunner.cpp:490  0.6627451181411743  */
+    float weight_scale;    /* database tensor (inside the reference's model blob) */
+    int32_t weight_offset; /* <= 0, real = scale * (q + offset) */
+    float output_scale;    /* QnnRunner.cpp:507  1013.43121337890625 */
+} vs_q8_encodings;
+
+/* enc == NULL: the runner's hard-coded input / output scales and weight_scale =
+ * max(database) / 255, offset 0.  id_offset as in vs_bf_create. */
+VS_API int vs_q8_create(const float* base_host, int64_t n_rows, int dim, const vs_q8_encodings* enc,
+                        int device, int64_t id_offset, vs_q8** out);
+VS_API void vs_q8_destroy(vs_q8* h);
+VS_API int64_t vs_q8_num_docs(const vs_q8* h);     /* QnnRunner::getNumDocs   (QnnRunner.h:52) */
+VS_API int vs_q8_dim(const vs_q8* h);              /* QnnRunner::getDim       (QnnRunner.h:50) */
+VS_API int vs_q8_batch(const vs_q8* h);            /* QnnRunner::getBatchSize (QnnRunner.h:48): 32 = the largest B */
+VS_API float vs_q8_output_scale(const vs_q8* h);   /* QnnRunner::getOutputScale (QnnRunner.h:41) */
+VS_API int vs_q8_get_encodings(const vs_q8* h, vs_q8_encodings* out);
+
+/* executeBatchRaw + getRawOutputBuffer: scores_dev[b*ld + j] = score8(query b, row j),
+ * 1 <= B <= 32, ld >= rows (16-byte stores when ld and scores_dev are multiples of 16). */
+VS_API int vs_q8_execute_dev(vs_q8* h, const float* queries_dev, int B, uint8_t* scores_dev,
+                             int64_t ld, void* stream);
+/* The same through host buffers: scores_host is [B x rows], dense. Blocking. */
+VS_API int vs_q8_execute(vs_q8* h, const float* queries_host, int B, uint8_t* scores_host);
+
+/* executeBatchRaw + find_top_k_batch_parallel (main.cpp:59-71) for n_batches batches of B
+ * queries: ids_dev [n_batches*B x k] (-1 where the database has fewer than k rows),
+ * scores_dev [n_batches*B x k] uint8, largest first.  k <= 16. */
+VS_API int vs_q8_search_dev(vs_q8* h, const float* queries_dev, int n_batches, int B, int k,
+                            int32_t* ids_dev, uint8_t* scores_dev, void* stream);
+/* Host-buffer form: the harness loop of main.cpp:201-251 (batches of 32, the last one
+ * short). Blocking. */
+VS_API int vs_q8_search(vs_q8* h, const float* queries_host, int64_t nq, int k, int32_t* ids,
+                        uint8_t* scores);
+
 /* ---------------------------------------------------------------------- IVF */
 /* IVFIndex ctor (IVFIndex.cpp:154-177): reads ivf_config.json, cluster_offsets.npy,
  * vectors_reordered.npy, reorder_to_original.npy (reordered mode) and

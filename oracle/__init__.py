@@ -63,6 +63,14 @@ def lib():
         L.vo_recall.restype = C.c_double
         L.vo_recall.argtypes = [_i32p, C.c_int, _i32p, C.c_int, C.c_int]
         L.vo_num_threads.restype = C.c_int
+        L.vo_q8_quantize.restype = None
+        L.vo_q8_quantize.argtypes = [_f32p, C.c_void_p, C.c_int64, C.c_float]
+        L.vo_q8_quantize_weights.restype = None
+        L.vo_q8_quantize_weights.argtypes = [_f32p, C.c_void_p, C.c_int64, C.c_float, C.c_int]
+        L.vo_q8_scores.restype = None
+        L.vo_q8_scores.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_void_p]
+        L.vo_q8_topk.restype = C.c_int
+        L.vo_q8_topk.argtypes = [C.c_void_p, C.c_int64, C.c_int, _i32p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -177,6 +185,58 @@ def recall(pred: np.ndarray, gt: np.ndarray, k: int) -> float:
 
 def num_threads() -> int:
     return int(lib().vo_num_threads())
+
+
+# ---------------------------------------------------------------------------
+# UFIXED_POINT_8 score path (QnnRunner.cpp:13-55, 490-521, 608-645; main.cpp:30-57).
+# Parity unpinned: the NPU graph between quantiser and top-k is not in the reference.
+# ---------------------------------------------------------------------------
+Q8_INPUT_SCALE = np.float32(0.6627451181411743)      # QnnRunner.cpp:490
+Q8_OUTPUT_SCALE = np.float32(1013.4312133789062500)  # QnnRunner.cpp:507
+
+
+def q8_quantize(x: np.ndarray, scale: float) -> np.ndarray:
+    """quantize_buffer_neon (QnnRunner.cpp:13-55) with inv_scale = 1.0f / scale (:619)."""
+    x = _f32(x)
+    out = np.empty(x.shape, dtype=np.uint8)
+    inv = np.float32(1.0) / np.float32(scale)
+    lib().vo_q8_quantize(x.reshape(-1), out.ctypes.data, x.size, inv)
+    return out
+
+
+def q8_quantize_weights(x: np.ndarray, scale: float, offset: int = 0) -> np.ndarray:
+    x = _f32(x)
+    out = np.empty(x.shape, dtype=np.uint8)
+    inv = np.float32(1.0) / np.float32(scale)
+    lib().vo_q8_quantize_weights(x.reshape(-1), out.ctypes.data, x.size, inv, int(offset))
+    return out
+
+
+def q8_mult(input_scale, weight_scale, output_scale) -> np.float32:
+    return (np.float32(input_scale) * np.float32(weight_scale)) / np.float32(output_scale)
+
+
+def q8_scores(base: np.ndarray, queries: np.ndarray, input_scale, weight_scale, weight_offset, output_scale) -> np.ndarray:
+    """uint8 [B x N] score matrix of executeBatchRaw (QnnRunner.cpp:608-645) as restated in vs_oracle.c."""
+    w8 = q8_quantize_weights(base, weight_scale, weight_offset)
+    q8 = q8_quantize(queries, input_scale)
+    B, d = q8.shape
+    out = np.empty((B, w8.shape[0]), dtype=np.uint8)
+    lib().vo_q8_scores(q8.ctypes.data, w8.ctypes.data, B, w8.shape[0], d, int(weight_offset),
+                       q8_mult(input_scale, weight_scale, output_scale), out.ctypes.data)
+    return out
+
+
+def q8_topk(scores: np.ndarray, k: int):
+    """find_top_k_int8 (main.cpp:36-57) per row of a uint8 score matrix; equal scores in ascending id order."""
+    scores = np.ascontiguousarray(scores, dtype=np.uint8)
+    B, n = scores.shape
+    ids = np.empty((B, k), dtype=np.int32)
+    top = np.empty((B, k), dtype=np.uint8)
+    L = lib()
+    for b in range(B):
+        L.vo_q8_topk(scores[b].ctypes.data, n, k, ids[b], top[b].ctypes.data)
+    return ids, top
 
 
 # ---------------------------------------------------------------------------

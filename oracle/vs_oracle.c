@@ -11,15 +11,18 @@
  * product (libvsearch_hip.so) never links or loads it.
  *
  * PARITY PIN STATUS
- *   exact path : pinned by the reference outputs recorded during the survey
- *                (tests/golden/ref_*.txt, provenance in tests/golden/PROVENANCE.md)
- *                and by an independent int64 recomputation (oracle/exact_int.py).
- *                The reference itself is NOT rebuilt by this repo: it needs
- *                <cblas.h>, which this image lacks, and stand-in headers are
- *                not allowed (see DESIGN.md "Oracle").
+ *   exact path : "parity unpinned" by the rules: the reference holds no golden
+ *                vectors, and it is NOT rebuilt by this repo (it needs <cblas.h>,
+ *                which this image lacks; stand-in headers are not allowed, see
+ *                DESIGN.md "Oracle").  What agrees with this file: the outputs of
+ *                the survey's stand-in-header build (tests/golden/ref_*.txt,
+ *                PROVENANCE.md), the two tie probes quoted in SURVEY.md
+ *                Appendix A, and an independent int64 recomputation
+ *                (oracle.exact_int_dists).
  *   IVF path   : "parity unpinned" -- the reference IVF code cannot be compiled
  *                (arm_neon.h, QNN SDK, broken definition at IVFIndex.cpp:498) and
  *                holds no golden vectors.  Pinned only by nprobe==nlist == exact.
+ *   uint8 path : "parity unpinned" (vo_q8_*, see there).
  *
  * Third-party arithmetic: the reference's dot products come from OpenBLAS
  * cblas_sgemm (un-vendored, version unpinned, cpu/cpu_baseline.cpp:229-237).
@@ -321,6 +324,64 @@ VO_API double vo_recall(const int* pred, int npred, const int* gt, int ngt, int 
         for (int j = 0; j < kg; ++j)
             if (pred[i] == gt[j]) { hits++; break; }
     return (double)hits / (double)k;
+}
+
+/* ------------------------------------------ UFIXED_POINT_8 score path (qidk) */
+/* PARITY UNPINNED: the reference's quantised scores come out of a QNN graph on
+ * the phone's HTP (closed converter + runtime; weight encoding and accumulator
+ * requantisation are not in the reference, and it holds no recorded scores).
+ * Restated from what IS in the reference: the input quantiser and the I/O
+ * encodings (QnnRunner.cpp:13-55, 490-521), the top-k over raw uint8 scores
+ * (main.cpp:30-57), with the quantiser's rounding rule applied to the output. */
+
+/* QnnRunner.cpp:13-55 quantize_buffer_neon: vmulq_n_f32 (one rounding), vaddq_f32
+ * 0.5 (a second one), vcvtq_s32_f32 (towards zero), saturating narrow to uint8. */
+static inline uint8_t vo_q8_one(float x, float inv_scale) {
+    volatile float p = x * inv_scale; /* no fused multiply-add: the NEON body has none */
+    float v = p + 0.5f;
+    if (!(v > 0.0f)) return 0; /* negatives and NaN -> 0 (:52-53) */
+    if (v >= 255.0f) return 255;
+    return (uint8_t)(int32_t)v;
+}
+VO_API void vo_q8_quantize(const float* src, uint8_t* dst, int64_t count, float inv_scale) {
+    for (int64_t i = 0; i < count; ++i) dst[i] = vo_q8_one(src[i], inv_scale);
+}
+/* Database tensor, QNN scale-offset encoding real = scale * (q + offset), offset <= 0. */
+VO_API void vo_q8_quantize_weights(const float* src, uint8_t* dst, int64_t count, float inv_scale, int offset) {
+    for (int64_t i = 0; i < count; ++i) {
+        int q = (int)vo_q8_one(src[i], inv_scale) - offset;
+        dst[i] = (uint8_t)(q < 0 ? 0 : (q > 255 ? 255 : q));
+    }
+}
+/* The graph: out[b][j] = sat_u8(trunc(ip * mult + 0.5)), ip = sum_t q8[b][t] * (w8[j][t] + w_off)
+ * in int32, mult = (input_scale * weight_scale) / output_scale (fp32, computed by the caller). */
+VO_API void vo_q8_scores(const uint8_t* q8, const uint8_t* w8, int B, int64_t n, int d, int w_off, float mult,
+                         uint8_t* out) {
+#pragma omp parallel for schedule(static)
+    for (int64_t j = 0; j < n; ++j)
+        for (int b = 0; b < B; ++b) {
+            int32_t ip = 0;
+            for (int t = 0; t < d; ++t) ip += (int32_t)q8[(size_t)b * d + t] * ((int32_t)w8[(size_t)j * d + t] + w_off);
+            out[(size_t)b * n + j] = vo_q8_one((float)ip, mult);
+        }
+}
+/* main.cpp:36-57 find_top_k_int8: a row replaces the smallest kept score only if its score is
+ * strictly larger (:45); ordered by score, largest first (:53-56).  The reference leaves the
+ * order (and, at the cut, the choice) among equal scores to its C++ library's heap; here rows
+ * are visited in ascending order and equal scores keep ascending row order. */
+VO_API int vo_q8_topk(const uint8_t* scores, int64_t n, int k, int32_t* ids, uint8_t* top) {
+    int cnt = 0;
+    for (int64_t j = 0; j < n; ++j) {
+        const uint8_t s = scores[j];
+        if (cnt == k && !(s > top[k - 1])) continue;
+        int pos = cnt < k ? cnt : k - 1;
+        while (pos > 0 && top[pos - 1] < s) { top[pos] = top[pos - 1]; ids[pos] = ids[pos - 1]; --pos; }
+        top[pos] = s;
+        ids[pos] = (int32_t)j;
+        if (cnt < k) ++cnt;
+    }
+    for (int i = cnt; i < k; ++i) { ids[i] = -1; top[i] = 0; }
+    return cnt;
 }
 
 VO_API int vo_num_threads(void) {

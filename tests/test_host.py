@@ -171,6 +171,25 @@ def test_argument_validation(pkg):
     assert np.array_equal(vr, v[r2o])
 
 
+def test_q8_argument_validation(pkg):
+    L = pkg.lib()
+    h = C.c_void_p(None)
+    base = np.zeros((8, 128), dtype=np.float32)
+    bp = base.ctypes.data_as(C.c_void_p)
+    assert L.vs_q8_create(None, 8, 128, None, 0, 0, C.byref(h)) == -1
+    assert L.vs_q8_create(bp, 8, 64, None, 0, 0, C.byref(h)) == -5  # dim != 128
+    if pkg.device_count() == 0:
+        assert L.vs_q8_create(bp, 8, 128, None, 0, 0, C.byref(h)) == -3  # no device: no runner, no CPU fallback
+        with pytest.raises(pkg.VSearchError) as e:
+            pkg.Q8Runner(base, 1.0, 1.0, 0, 1.0)
+        assert e.value.status == -3
+    else:
+        bad = pkg.Q8Encodings(1.0, 1.0, 3, 1.0)  # weight_offset > 0
+        assert L.vs_q8_create(bp, 8, 128, C.byref(bad), 0, 0, C.byref(h)) == -1
+    assert L.vs_q8_execute(None, bp, 1, bp) == -1 and L.vs_q8_search(None, bp, 1, 5, bp, bp) == -1
+    assert L.vs_q8_num_docs(None) == 0 and L.vs_q8_batch(None) == 0
+
+
 def test_sweep_metrics_parser_reads_the_cli_layout():
     """scripts/sweep_ivf.py parses the metrics.txt layout that cli_ivf.cpp writes into the CSV
     columns of the reference's sweep (qidk_ivf/scripts/run_all_ivf.sh:62)."""

@@ -120,3 +120,29 @@ def test_ivf_oracle_full_probe_equals_exact():
     r = oracle.recall(ids8, ids, 5)
     assert 0.0 <= r <= 1.0
     assert oracle.recall(ids, ids, 5) == 1.0
+
+
+def test_q8_quantiser_known_answers_and_numpy_recomputation():
+    """quantize_buffer_neon (QnnRunner.cpp:13-55) by hand: x / 0.6627451 + 0.5, towards zero, saturated to [0, 255];
+    then the whole uint8 score path against a numpy recomputation with separately rounded fp32 products and sums."""
+    x = np.array([0.0, 0.33, 0.34, 1.0, -3.0, 200.0, 1e9, np.nan, 0.6627451 * 2.5, 168.8, 169.1], dtype=np.float32)
+    assert oracle.q8_quantize(x, oracle.Q8_INPUT_SCALE).tolist() == [0, 0, 1, 2, 0, 255, 255, 0, 3, 255, 255]
+    assert oracle.q8_quantize_weights(np.array([-2.0, 0.0, 2.0, 300.0], dtype=np.float32), 1.0, -3).tolist() == [3, 3, 5, 255]
+    rng = np.random.default_rng(5)
+    base = (rng.random((700, 128)) * 90).astype(np.float32)
+    q = (rng.random((9, 128)) * 170).astype(np.float32)
+    i_s, w_s, off, o_s = 0.6627451, 0.4, -7, 3000.0
+    got = oracle.q8_scores(base, q, i_s, w_s, off, o_s)
+    inv_i, inv_w = np.float32(1) / np.float32(i_s), np.float32(1) / np.float32(w_s)
+    q8 = np.clip(np.trunc(q * inv_i + np.float32(0.5)), 0, 255).astype(np.int64)
+    w8 = np.clip(np.clip(np.trunc(base * inv_w + np.float32(0.5)), 0, 255).astype(np.int64) - off, 0, 255)
+    ip = q8 @ (w8 + off).T
+    mult = (np.float32(i_s) * np.float32(w_s)) / np.float32(o_s)
+    want = np.clip(np.trunc(ip.astype(np.float32) * mult + np.float32(0.5)), 0, 255).astype(np.uint8)
+    assert np.array_equal(got, want) and len(np.unique(want)) > 10
+    ids, top = oracle.q8_topk(got, 6)
+    for b in range(len(q)):
+        order = np.lexsort((np.arange(got.shape[1]), -got[b].astype(np.int64)))[:6]
+        assert ids[b].tolist() == order.tolist() and top[b].tolist() == got[b][order].tolist()
+    ids, top = oracle.q8_topk(got[:, :4], 6)  # fewer rows than k (IVFIndex.cpp:457 clamps likewise): (-1, 0) tail
+    assert np.all(ids[:, 4:] == -1) and np.all(top[:, 4:] == 0)
