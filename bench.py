@@ -15,7 +15,7 @@ N = 1  : config "SIFT-1M brute-force batch=32 on 1xMI355X" (BASELINE.json config
 N > 1  : the same base row-sharded over the ranks (strong scaling); every rank scans its shard for
          the same queries, the per-shard top-(k+1) lists are exchanged with ONE RCCL all-gather per
          group of `--coll-every` steps and merged on the device (the only collective the path has).
-Extras on the same JSON line: "ivf" (nlist=1024 nprobe=32, configs[3]/[4]), "ivf_nprobe8", "bf_int8",
+Extras on the same JSON line: "ivf" (nlist=1024 nprobe=32, configs[3]/[4]), "ivf_nprobe8", "bf_int8", "q8_runner",
 "host_api" (vs_bf_search / vs_ivf_search on host buffers: upload, download and reference tie order
 inside the timed region -- SURVEY 8(d)'s QPS definition), "siftsmall_b1", "sift1m_b1" (configs[1]).
 
@@ -402,6 +402,74 @@ def main():
         b1_info["siftsmall_b1"]["note"] = "5 MB base: cache resident, launch-latency bound (SURVEY 8(d)): absolute us are the figure"
         bfs.close()
 
+    # ---------------------------------------------------------------- UFIXED_POINT_8 score path (second half)
+    q8_info = None
+    if world == 1 and not args.no_extras:
+        try:
+            in_s = float(queries.max()) / 255.0
+            w_s = float(shard.max()) / 255.0
+            samp = shard[:: max(1, rows_local // 4096)].astype(np.float64)
+            o_s = 1.05 * float((queries[:64].astype(np.float64) @ samp.T).max()) / 255.0  # min-max calibration on a sample
+            qr = pkg.Q8Runner(shard, in_s, w_s, 0, o_s, device=local_rank)
+            n_pad = (rows_local + 63) // 64 * 64
+            sc = torch.empty((BATCH * n_pad,), dtype=torch.uint8, device=dev)
+            q8_i = torch.empty((S * BATCH, K), dtype=torch.int32, device=dev)
+            q8_t = torch.empty((S * BATCH, K), dtype=torch.uint8, device=dev)
+
+            def q8_exec(i, n):
+                qr.execute_dev(q_dev.data_ptr() + (i % n_qbatches) * BATCH * DIM * 4, BATCH, sc.data_ptr(), n_pad, sptr)
+
+            def q8_search(i, n):
+                if i % S != S - 1 and i != n - 1:
+                    return
+                gs = i % S + 1
+                qr.search_dev(q_dev.data_ptr() + ((i - gs + 1) % n_qbatches) * BATCH * DIM * 4, gs, BATCH, K, q8_i.data_ptr(),
+                              q8_t.data_ptr(), sptr)
+
+            # kernel time by HIP events on the stream the launches go to (torch's current stream)
+            for i in range(8):
+                q8_exec(i, 8)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            nrun = 64
+            e0.record(stream)
+            for i in range(nrun):
+                q8_exec(i, nrun)
+            e1.record(stream)
+            torch.cuda.synchronize()
+            ex_us = e0.elapsed_time(e1) * 1e3 / nrun
+            reg = timed(q8_search, steps, warmup, repeats=5)
+            el = median(reg)
+            b_q8 = rows_local * DIM + 4 * rows_local + BATCH * rows_local + 4 * BATCH * DIM  # u8 rows + row terms in, u8 scores out
+            # the check of what was just timed: the last batch's ids must be the top-k of its own score matrix
+            q8_exec((steps - 1), steps)
+            torch.cuda.synchronize()
+            raw = sc.view(BATCH, n_pad)[:, :rows_local].cpu().numpy()
+            want_top = -np.sort(-raw.astype(np.int16), axis=1)[:, :K]
+            got_i = q8_i.cpu().numpy()[(steps - 1) % S * BATCH:][:BATCH] - r0
+            assert np.array_equal(q8_t.cpu().numpy()[(steps - 1) % S * BATCH:][:BATCH].astype(np.int16), want_top), "q8 top-k scores"
+            assert np.array_equal(np.take_along_axis(raw, got_i.astype(np.int64), 1).astype(np.int16), want_top), "q8 top-k ids"
+            q8_info = {"metric": "QPS, same workload through the UFIXED_POINT_8 runner (QnnRunner::executeBatchRaw + find_top_k_int8): "
+                                 "uint8 queries x uint8 database, int8 MFMA, raw uint8 [B x N] score matrix written, top-k over it",
+                       "value": round(steps * BATCH / el, 1), "ms_per_step": round(el / steps * 1e3, 5),
+                       "score_matrix_us_per_batch": round(ex_us, 2),
+                       "encodings": {"input_scale": in_s, "weight_scale": w_s, "weight_offset": 0, "output_scale": o_s},
+                       "distinct_scores_in_last_batch": int(len(np.unique(raw))),
+                       "roofline": {"bound": "hbm", "achieved": round(b_q8 / (ex_us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                                    "unit": "GB/s", "frac": round(b_q8 / (ex_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                                    "kernel": "q8_scores_kernel<2>", "kernel_us": round(ex_us, 2),
+                                    "algorithmic_bytes_per_launch": b_q8,
+                                    "note": "kernel_us = quantiser launch + score kernel per batch (HIP events over 64 batches); "
+                                            "the 128 MB of uint8 rows stay in the 256 MB Infinity Cache between batches, the "
+                                            "32 MB score matrix is written per batch: HBM peak is the reference roof"},
+                       "parity": "unpinned (the NPU graph is not in the reference); bit-exact against oracle.q8_* in tests/test_gpu_q8.py"}
+            log(f"q8 runner: {q8_info['value']:.0f} QPS with top-k, score matrix {ex_us:.1f} us per batch "
+                f"({q8_info['roofline']['achieved']:.0f} GB/s of {b_q8 / 1e6:.0f} MB)")
+            qr.close()
+            del sc
+        except Exception as e:  # an extra: it must not cost the headline line
+            log(f"q8 leg failed: {type(e).__name__}: {e}")
+            q8_info = {"error": f"{type(e).__name__}: {e}"}
+
     # ---------------------------------------------------------------- IVF extras
     ivf_info = None
     ivf8_info = None
@@ -634,6 +702,7 @@ def main():
             "ivf_nprobe8": ivf8_info,
             "bf_int8": int8_info,
             "host_api": host_info,
+            "q8_runner": q8_info,
         }
         line.update(b1_info)
         print(json.dumps(line), flush=True)

@@ -19,8 +19,9 @@
 //                               the row -> MFMA-row assignment is chosen so that a lane ends up with 16 CONSECUTIVE rows
 //                               of one query: one 16-byte store per lane and column block.  HBM bound: N*128 bytes in,
 //                               B*N bytes out per batch.
-//   q8_topk_chunk_kernel        per (16384-row chunk, query): threshold by bisection over the byte value with SWAR
-//                               compares, then the entries above it and the lowest-numbered entries equal to it
+//   q8_topk_chunk_kernel        per (16384-row chunk, query): a lower bound of the cut from the 256 per-thread maxima,
+//                               the few entries above it ranked in LDS; long runs of equal scores: bisection over the
+//                               byte value with SWAR compares, lowest-numbered entries at the cut first
 //   q8_topk_final_kernel        per query: k rounds of "largest key below the previous one" over the chunks' candidates
 // Order of equal scores: ascending row number (the reference's order among equal uint8 scores is whatever its C++
 // library's heap leaves, main.cpp:36-57).
@@ -51,6 +52,7 @@ namespace {
 
 constexpr int kDim = 128;
 constexpr int kBatch = 32;
+constexpr int kGroup = 32;          // batches whose queries one quantiser launch prepares
 constexpr int kGroupRows = 64;      // rows a wave scores per step
 constexpr int kChunkRows = 16384;   // rows per top-k chunk (256 threads x 64 bytes)
 constexpr int kCand = 16;           // candidate slots per (chunk, query); k <= 16
@@ -58,6 +60,7 @@ constexpr int kIpBias = 128 * 128 * kDim;  // sum over t of 128 * 128
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned long long u64;
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
 // sat_u8(trunc(v)) for a value that already carries its +0.5: NaN and negatives -> 0 (QnnRunner.cpp:52-53)
 __device__ __forceinline__ unsigned q8_sat(float v) {
@@ -67,10 +70,12 @@ __device__ __forceinline__ unsigned q8_sat(float v) {
 
 __global__ __launch_bounds__(64) void q8_quantize_queries_kernel(const float* __restrict__ q, int B, float inv_scale, int w_off,
                                                                  int8_t* __restrict__ q8, int32_t* __restrict__ cq) {
-    const int b = blockIdx.x, l = threadIdx.x;
+    const int nb = blockIdx.x >> 5, b = blockIdx.x & 31, l = threadIdx.x;  // batch, row of the batch
+    q8 += (size_t)nb * kBatch * kDim;
+    cq += nb * kBatch;
     unsigned u0 = 0, u1 = 0;
     if (b < B) {  // rows past B are the zero padding of main.cpp:206-211
-        const float2 x = *reinterpret_cast<const float2*>(q + (size_t)b * kDim + 2 * l);
+        const float2 x = *reinterpret_cast<const float2*>(q + ((size_t)nb * B + b) * kDim + 2 * l);
         u0 = q8_sat(__fadd_rn(__fmul_rn(x.x, inv_scale), 0.5f));  // vmulq_n_f32 then vaddq_f32: two roundings
         u1 = q8_sat(__fadd_rn(__fmul_rn(x.y, inv_scale), 0.5f));
     }
@@ -111,8 +116,8 @@ __global__ __launch_bounds__(256) void q8_scores_kernel(const int8_t* __restrict
         i32x4 a0[4], a1[4], rw[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            a0[t] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(ap + (size_t)(4 * t) * kDim));
-            a1[t] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(ap + (size_t)(4 * t) * kDim + 64));
+            a0[t] = *reinterpret_cast<const i32x4*>(ap + (size_t)(4 * t) * kDim);
+            a1[t] = *reinterpret_cast<const i32x4*>(ap + (size_t)(4 * t) * kDim + 64);
             rw[t] = *reinterpret_cast<const i32x4*>(wterm + row0 + 16 * g + 4 * t);
         }
 #pragma unroll
@@ -136,7 +141,7 @@ __global__ __launch_bounds__(256) void q8_scores_kernel(const int8_t* __restrict
             if (qi < B && r < n_rows) {
                 uint8_t* dst = out + (size_t)qi * ld + r;
                 if (aligned && r + 16 <= n_rows) {
-                    __builtin_nontemporal_store(word, reinterpret_cast<i32x4*>(dst));
+                    *reinterpret_cast<i32x4*>(dst) = word;
                 } else {
                     const int n = n_rows - r < 16 ? (int)(n_rows - r) : 16;
                     for (int j = 0; j < n; ++j) dst[j] = (uint8_t)(((unsigned)word[j >> 2] >> (8 * (j & 3))) & 0xffu);
@@ -154,6 +159,15 @@ __device__ __forceinline__ unsigned ge_bytes_acc(unsigned x, unsigned m4, unsign
     return __builtin_amdgcn_udot4(ge, 0x01010101u, acc, false);
 }
 
+// bytes of the thread's 16 words that are >= mid (mid in 1..255)
+__device__ __forceinline__ int count_ge(const unsigned (&w)[16], int mid) {
+    const unsigned m4 = 0x01010101u * (unsigned)mid, m7 = m4 & 0x7f7f7f7fu, nm = ~m4;
+    unsigned a = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) a = ge_bytes_acc(w[j], m4, m7, nm, a);
+    return (int)(a >> 7);
+}
+
 __device__ __forceinline__ int block_sum_256(int v, int* sh) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -163,97 +177,22 @@ __device__ __forceinline__ int block_sum_256(int v, int* sh) {
     return sh[0] + sh[1] + sh[2] + sh[3];
 }
 
-// scores: [B][ld] bytes (ld a multiple of 16, buffer 16-byte aligned); cand: [B][n_chunks][kCand] keys
-// key = score << 32 | (0xffffffff - row): larger key = better (score descending, then row ascending); 0 = empty
-__global__ __launch_bounds__(256) void q8_topk_chunk_kernel(const uint8_t* __restrict__ scores, int64_t ld, int64_t n_rows, int k,
-                                                            int n_chunks, u64* __restrict__ cand) {
-    __shared__ int sh[4];
-    __shared__ int sh_scan[4];
-    __shared__ u64 list[kCand];
-    __shared__ int s_cnt;
-    const int chunk = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-    const int64_t r0 = (int64_t)chunk * kChunkRows + (int64_t)tid * 64;
-    const int64_t left = n_rows - r0;
-    const int nvalid = left <= 0 ? 0 : (left < 64 ? (int)left : 64);
-    unsigned w[16];
-    {
-        const uint8_t* src = scores + (size_t)b * ld + r0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (16 * j < nvalid) v = *reinterpret_cast<const uint4*>(src + 16 * j);  // ld is padded to 64: whole pieces exist
-            w[4 * j] = v.x, w[4 * j + 1] = v.y, w[4 * j + 2] = v.z, w[4 * j + 3] = v.w;
-        }
-        // bytes past the last row count as score 0 with the highest row numbers: they are taken last and cut by n_take
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int rem = nvalid - 4 * j;
-            if (rem < 4) w[j] = rem <= 0 ? 0u : (w[j] & ((1u << (8 * rem)) - 1u));
-        }
-    }
-    if (tid < kCand) list[tid] = 0;
-    if (tid == 0) s_cnt = 0;
-    const int64_t chunk_left = n_rows - (int64_t)chunk * kChunkRows;
-    const int chunk_rows = chunk_left < kChunkRows ? (int)chunk_left : kChunkRows;  // >= 1: the grid covers n_rows
-    const int n_take = k < chunk_rows ? k : chunk_rows;
-    // t = the largest byte value with at least n_take entries >= t (0 if even value 1 has fewer)
-    int lo = 0, hi = 256, cnt_hi = 0;
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        const unsigned m4 = 0x01010101u * (unsigned)mid, m7 = m4 & 0x7f7f7f7fu, nm = ~m4;
-        unsigned a = 0;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) a = ge_bytes_acc(w[j], m4, m7, nm, a);
-        const int cnt = block_sum_256((int)(a >> 7), sh);
-        if (cnt >= n_take) lo = mid;
-        else hi = mid, cnt_hi = cnt;
-    }
-    const int t = lo;
-    const int need_eq = n_take - cnt_hi;  // entries equal to t still to take, lowest rows first
-    // entries equal to t per thread -> exclusive scan over the block (threads are in row order)
-    int c_eq = 0;
-#pragma unroll
-    for (int j = 0; j < 16; ++j)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) c_eq += (int)((w[j] >> (8 * i)) & 0xffu) == t && (4 * j + i) < nvalid;
-    int incl = c_eq;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int up = __shfl_up(incl, o);
-        if ((tid & 63) >= o) incl += up;
-    }
-    if ((tid & 63) == 63) sh_scan[tid >> 6] = incl;
-    __syncthreads();
-    int base = incl - c_eq;
-    for (int wv = 0; wv < (tid >> 6); ++wv) base += sh_scan[wv];
-    // emit
-    for (int j = 0; j < 16; ++j) {
-        for (int i = 0; i < 4; ++i) {
-            const int e = 4 * j + i;
-            if (e >= nvalid) break;
-            const int v = (int)((w[j] >> (8 * i)) & 0xffu);
-            bool take = v > t;
-            if (v == t && base < need_eq) take = true, ++base;
-            if (take) {
-                const int pos = atomicAdd(&s_cnt, 1);
-                if (pos < kCand) list[pos] = ((u64)v << 32) | (u64)(0xffffffffu - (unsigned)(r0 + e));
-            }
-        }
-    }
-    __syncthreads();
-    if (tid < kCand) cand[((size_t)b * n_chunks + chunk) * kCand + tid] = list[tid];
-}
-
-__global__ __launch_bounds__(256) void q8_topk_final_kernel(const u64* __restrict__ cand, int n_chunks, int k, int32_t id_offset,
-                                                            int32_t* __restrict__ ids, uint8_t* __restrict__ out_scores) {
+// one workgroup: the k largest of n keys
+__device__ void q8_topk_merge(const u64* src, int n, int k, int32_t id_offset, int32_t* ids, uint8_t* out_scores) {
     __shared__ u64 shm[4];
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const u64* src = cand + (size_t)b * n_chunks * kCand;
-    const int n = n_chunks * kCand;
+    const int tid = threadIdx.x;
+    constexpr int kOwn = 8;  // keys a thread keeps in registers (2048 per query = 2 M rows); more: re-read per round
+    u64 own[kOwn];
+#pragma unroll
+    for (int j = 0; j < kOwn; ++j)
+        own[j] = tid + 256 * j < n ? src[tid + 256 * j] : 0;
     u64 prev = ~0ull;
     for (int r = 0; r < k; ++r) {
         u64 best = 0;
-        for (int i = tid; i < n; i += 256) {
+#pragma unroll
+        for (int j = 0; j < kOwn; ++j)
+            if (own[j] < prev && own[j] > best) best = own[j];
+        for (int i = tid + 256 * kOwn; i < n; i += 256) {
             const u64 v = src[i];
             if (v < prev && v > best) best = v;
         }
@@ -267,11 +206,173 @@ __global__ __launch_bounds__(256) void q8_topk_final_kernel(const u64* __restric
         __syncthreads();
         best = max(max(shm[0], shm[1]), max(shm[2], shm[3]));
         if (tid == 0) {
-            ids[(size_t)b * k + r] = best ? (int32_t)(0xffffffffu - (unsigned)(best & 0xffffffffu)) + id_offset : -1;
-            out_scores[(size_t)b * k + r] = (uint8_t)(best >> 32);
+            ids[r] = best ? (int32_t)(0xffffffffu - (unsigned)(best & 0xffffffffu)) + id_offset : -1;
+            out_scores[r] = (uint8_t)(best >> 32);
         }
-        prev = best ? best : 0;  // nothing left: the remaining rounds find nothing either
+        prev = best;  // 0 when nothing is left: the remaining rounds find nothing either
     }
+}
+
+// one workgroup per query.  (Merging in the chunk kernel's last workgroup per query instead was measured: the fences it
+// needs -- L2 write-back and invalidate in 2000 workgroups -- made that kernel four times slower.)
+__global__ __launch_bounds__(256) void q8_topk_final_kernel(const u64* __restrict__ cand, int n_chunks, int k, int32_t id_offset,
+                                                            int32_t* __restrict__ ids, uint8_t* __restrict__ out_scores) {
+    const int b = blockIdx.x;
+    q8_topk_merge(cand + (size_t)b * n_chunks * kCand, n_chunks * kCand, k, id_offset, ids + (size_t)b * k, out_scores + (size_t)b * k);
+}
+
+// bit 7 of every byte of x that is >= the byte replicated in m4
+__device__ __forceinline__ unsigned ge_mask(unsigned x, unsigned m4) {
+    const unsigned H = 0x80808080u;
+    const unsigned t = (x | H) - (m4 & 0x7f7f7f7fu);
+    return ((x & ~m4) | (~(x ^ m4) & t)) & H;
+}
+
+// scores: [B][ld] bytes (ld a multiple of 64, buffer 16-byte aligned); cand: [B][n_chunks][kCand] keys
+// key = score << 32 | (0xffffffff - row): larger key = better (score descending, then row ascending); 0 = empty
+//
+// A thread holds 64 consecutive scores (16 words).  Fast path: L = the n_take-th largest of the 256 per-thread maxima is
+// a lower bound of the cut (n_take different entries are >= L); when at most kListCap entries are >= L they are
+// gathered in LDS and ranked against each other.  Otherwise (long runs of equal scores: saturated or coarse encodings)
+// the cut is found by bisection over the byte value between L and the chunk maximum, and the entries above it plus the
+// lowest-numbered entries equal to it are taken.
+constexpr int kListCap = 256;
+__global__ __launch_bounds__(256) void q8_topk_chunk_kernel(const uint8_t* __restrict__ scores, int64_t ld, int64_t n_rows, int k,
+                                                            int n_chunks, u64* __restrict__ cand) {
+    __shared__ int sh[4];
+    __shared__ int sh_scan[4];
+    __shared__ unsigned smax[64];  // the 256 per-thread maxima, one byte each
+    __shared__ unsigned lst[kListCap];
+    __shared__ u64 list[kCand];
+    __shared__ int s_cnt, s_cntL;
+    const int chunk = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int64_t r0 = (int64_t)chunk * kChunkRows + (int64_t)tid * 64;
+    const int64_t left = n_rows - r0;
+    const int nvalid = left <= 0 ? 0 : (left < 64 ? (int)left : 64);
+    unsigned w[16];
+    {
+        const uint8_t* src = scores + (size_t)b * ld + r0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (16 * j < nvalid) v = *reinterpret_cast<const uint4*>(src + 16 * j);  // ld is padded to 64: whole pieces exist
+            w[4 * j] = v.x, w[4 * j + 1] = v.y, w[4 * j + 2] = v.z, w[4 * j + 3] = v.w;
+        }
+        // bytes past the last row count as score 0 with the highest row numbers
+        if (nvalid < 64) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int rem = nvalid - 4 * j;
+                if (rem < 4) w[j] = rem <= 0 ? 0u : (w[j] & ((1u << (8 * rem)) - 1u));
+            }
+        }
+    }
+    if (tid < kCand) list[tid] = 0;
+    if (tid == 0) s_cnt = 0, s_cntL = 0;
+    const int64_t chunk_left = n_rows - (int64_t)chunk * kChunkRows;
+    const int chunk_rows = chunk_left < kChunkRows ? (int)chunk_left : kChunkRows;  // >= 1: the grid covers n_rows
+    const int n_take = k < chunk_rows ? k : chunk_rows;
+    // per-thread maximum -> LDS
+    unsigned my_max;
+    {
+        u16x2 e = (u16x2){0, 0}, o = (u16x2){0, 0};  // even / odd bytes as 16-bit fields (v_pk_max_u16)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            e = __builtin_elementwise_max(e, __builtin_bit_cast(u16x2, w[j] & 0x00ff00ffu));
+            o = __builtin_elementwise_max(o, __builtin_bit_cast(u16x2, (w[j] >> 8) & 0x00ff00ffu));
+        }
+        e = __builtin_elementwise_max(e, o);
+        my_max = max((unsigned)e[0], (unsigned)e[1]);
+        reinterpret_cast<uint8_t*>(smax)[tid] = (uint8_t)my_max;
+    }
+    __syncthreads();
+    // every wave finds L from the 256 maxima on its own (lane l looks at word l = the maxima of threads 4l .. 4l+3)
+    int L;
+    {
+        const unsigned mw = smax[tid & 63];
+        const int m0 = (int)(mw & 0xffu), m1 = (int)((mw >> 8) & 0xffu), m2 = (int)((mw >> 16) & 0xffu), m3 = (int)(mw >> 24);
+        int lo = 0, hi = 256;  // the number of maxima >= lo is >= n_take (256 of them are >= 0), fewer are >= hi
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            const int c = __builtin_popcountll(__ballot(m0 >= mid)) + __builtin_popcountll(__ballot(m1 >= mid)) +
+                          __builtin_popcountll(__ballot(m2 >= mid)) + __builtin_popcountll(__ballot(m3 >= mid));
+            if (c >= n_take) lo = mid;
+            else hi = mid;
+        }
+        L = lo;
+    }
+    int c_lo = L > 0 ? (my_max >= (unsigned)L ? count_ge(w, L) : 0) : nvalid;  // this thread's entries >= L
+    if (c_lo) atomicAdd(&s_cntL, c_lo);  // few threads hold such entries
+    __syncthreads();
+    const int cnt_L = s_cntL;  // >= n_take
+    if (L > 0 && cnt_L <= kListCap) {
+        // gather (score, row) of every entry >= L: key = score << 16 | (16383 - row in chunk)
+        if (my_max >= (unsigned)L) {
+            const unsigned m4 = 0x01010101u * (unsigned)L;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                unsigned g = ge_mask(w[j], m4);
+                while (g) {
+                    const int i = (__builtin_ctz(g) >> 3);
+                    g &= g - 1;
+                    const unsigned v = (w[j] >> (8 * i)) & 0xffu;
+                    const int pos = atomicAdd(&s_cnt, 1);
+                    lst[pos] = (v << 16) | (unsigned)(16383 - (tid * 64 + 4 * j + i));
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < cnt_L) {
+            const unsigned key = lst[tid];
+            int rank = 0;
+            for (int j = 0; j < cnt_L; ++j) rank += lst[j] > key;
+            if (rank < n_take)
+                list[rank] = ((u64)(key >> 16) << 32) | (u64)(0xffffffffu - (unsigned)((int64_t)chunk * kChunkRows + (16383 - (int)(key & 0xffffu))));
+        }
+    } else {
+        // t = the largest byte value with at least n_take entries >= t.
+        // Invariant: cnt(lo) >= n_take > cnt(hi); c_lo / c_hi are this thread's own counts at lo / hi.
+        int lo = L, hi = 256, cnt_hi = 0, c_hi = 0;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            const int c = count_ge(w, mid);
+            const int cnt = block_sum_256(c, sh);
+            if (cnt >= n_take) lo = mid, c_lo = c;
+            else hi = mid, cnt_hi = cnt, c_hi = c;
+        }
+        const int t = lo;
+        const int need_eq = n_take - cnt_hi;  // entries equal to t still to take, lowest rows first
+        // entries equal to t per thread (valid ones: c_lo at t = 0 is nvalid) -> exclusive scan over the block (row order)
+        const int c_eq = c_lo - c_hi;
+        int incl = c_eq;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int up = __shfl_up(incl, o);
+            if ((tid & 63) >= o) incl += up;
+        }
+        if ((tid & 63) == 63) sh_scan[tid >> 6] = incl;
+        __syncthreads();
+        int base = incl - c_eq;
+        for (int wv = 0; wv < (tid >> 6); ++wv) base += sh_scan[wv];
+        // only threads that hold an entry above the cut, or one of the first need_eq entries at the cut
+        if (c_hi > 0 || (c_eq > 0 && base < need_eq)) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int v = (int)((w[j] >> (8 * i)) & 0xffu);
+                    bool take = v > t;
+                    if (v == t && 4 * j + i < nvalid && base < need_eq) take = true, ++base;
+                    if (take) {
+                        const int pos = atomicAdd(&s_cnt, 1);
+                        if (pos < kCand) list[pos] = ((u64)v << 32) | (u64)(0xffffffffu - (unsigned)(r0 + 4 * j + i));
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < kCand) cand[((size_t)b * n_chunks + chunk) * kCand + tid] = list[tid];
 }
 
 }  // namespace
@@ -285,8 +386,8 @@ struct vs_q8 {
     int num_cus = 256;
     int8_t* d_wq = nullptr;      // [n_pad][128]
     int32_t* d_wterm = nullptr;  // [n_pad]
-    int8_t* d_q8 = nullptr;      // [32][128]
-    int32_t* d_cq = nullptr;     // [32]
+    int8_t* d_q8 = nullptr;      // [kGroup][32][128] quantised queries of up to kGroup batches
+    int32_t* d_cq = nullptr;     // [kGroup][32]
     float* d_q = nullptr;        // [32][128] staging of host queries
     uint8_t* d_scores = nullptr; // [32][n_pad]  the runner's output buffer (QnnRunner.cpp:322-323)
     u64* d_cand = nullptr;       // [32][n_chunks][kCand]
@@ -391,7 +492,7 @@ int q8_create_impl(const float* base_host, int64_t n_rows, int dim, const vs_q8_
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) h->num_cus = prop.multiProcessorCount;
     // database -> uint8 (stored minus 128) + 128 * row sums, in slabs of 1 M rows
     if (hipMalloc((void**)&h->d_wq, (size_t)h->n_pad * kDim) != hipSuccess || hipMalloc((void**)&h->d_wterm, (size_t)h->n_pad * 4) != hipSuccess ||
-        hipMalloc((void**)&h->d_q8, kBatch * kDim) != hipSuccess || hipMalloc((void**)&h->d_cq, kBatch * 4) != hipSuccess ||
+        hipMalloc((void**)&h->d_q8, (size_t)kGroup * kBatch * kDim) != hipSuccess || hipMalloc((void**)&h->d_cq, (size_t)kGroup * kBatch * 4) != hipSuccess ||
         hipMalloc((void**)&h->d_q, kBatch * kDim * 4) != hipSuccess || hipMalloc((void**)&h->d_scores, (size_t)kBatch * h->n_pad) != hipSuccess ||
         hipMalloc((void**)&h->d_cand, (size_t)kBatch * h->n_chunks * kCand * 8) != hipSuccess ||
         hipMalloc((void**)&h->d_ids, kBatch * kCand * 4) != hipSuccess || hipMalloc((void**)&h->d_top, kBatch * kCand) != hipSuccess ||
@@ -424,19 +525,34 @@ int q8_create_impl(const float* base_host, int64_t n_rows, int dim, const vs_q8_
     return VS_OK;
 }
 
-int q8_execute_enqueue(vs_q8* h, const float* q_dev, int B, uint8_t* scores_dev, int64_t ld, hipStream_t s) {
-    hipLaunchKernelGGL(q8_quantize_queries_kernel, dim3(kBatch), dim3(64), 0, s, q_dev, B, h->inv_in, h->enc.weight_offset, h->d_q8, h->d_cq);
-    const int64_t n_groups = h->n_pad / kGroupRows;
-    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n_groups + 3) / 4, (int64_t)h->num_cus * 5));
-    const int aligned = (ld % 16 == 0) && (reinterpret_cast<uintptr_t>(scores_dev) % 16 == 0);
-    if (B <= 16)
-        hipLaunchKernelGGL(q8_scores_kernel<1>, dim3(grid), dim3(256), 0, s, h->d_wq, h->d_wterm, h->d_q8, h->d_cq, h->n_rows, n_groups, B,
-                           h->mult, scores_dev, ld, aligned);
-    else
-        hipLaunchKernelGGL(q8_scores_kernel<2>, dim3(grid), dim3(256), 0, s, h->d_wq, h->d_wterm, h->d_q8, h->d_cq, h->n_rows, n_groups, B,
-                           h->mult, scores_dev, ld, aligned);
+int q8_quantize_enqueue(vs_q8* h, const float* q_dev, int n_batches, int B, hipStream_t s) {
+    hipLaunchKernelGGL(q8_quantize_queries_kernel, dim3(n_batches * kBatch), dim3(64), 0, s, q_dev, B, h->inv_in, h->enc.weight_offset, h->d_q8,
+                       h->d_cq);
     HIPCHK(hipGetLastError());
     return VS_OK;
+}
+
+// scores of the slot-th quantised batch
+int q8_scores_enqueue(vs_q8* h, int slot, int B, uint8_t* scores_dev, int64_t ld, hipStream_t s) {
+    const int64_t n_groups = h->n_pad / kGroupRows;
+    // 4 workgroups = 16 waves per CU: what 120 registers allow
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n_groups + 3) / 4, (int64_t)h->num_cus * 4));
+    const int aligned = (ld % 16 == 0) && (reinterpret_cast<uintptr_t>(scores_dev) % 16 == 0);
+    const int8_t* q8 = h->d_q8 + (size_t)slot * kBatch * kDim;
+    const int32_t* cq = h->d_cq + slot * kBatch;
+    if (B <= 16)
+        hipLaunchKernelGGL(q8_scores_kernel<1>, dim3(grid), dim3(256), 0, s, h->d_wq, h->d_wterm, q8, cq, h->n_rows, n_groups, B, h->mult,
+                           scores_dev, ld, aligned);
+    else
+        hipLaunchKernelGGL(q8_scores_kernel<2>, dim3(grid), dim3(256), 0, s, h->d_wq, h->d_wterm, q8, cq, h->n_rows, n_groups, B, h->mult,
+                           scores_dev, ld, aligned);
+    HIPCHK(hipGetLastError());
+    return VS_OK;
+}
+
+int q8_execute_enqueue(vs_q8* h, const float* q_dev, int B, uint8_t* scores_dev, int64_t ld, hipStream_t s) {
+    int rc = q8_quantize_enqueue(h, q_dev, 1, B, s);
+    return rc ? rc : q8_scores_enqueue(h, 0, B, scores_dev, ld, s);
 }
 
 int q8_topk_enqueue(vs_q8* h, int B, int k, int32_t* ids_dev, uint8_t* top_dev, hipStream_t s) {
@@ -505,9 +621,14 @@ int vs_q8_search_dev(vs_q8* h, const float* queries_dev, int n_batches, int B, i
     }
     HIPCHK(hipSetDevice(h->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    for (int nb = 0; nb < n_batches; ++nb) {
-        int rc = q8_execute_enqueue(h, queries_dev + (size_t)nb * B * kDim, B, h->d_scores, h->n_pad, s);
-        if (rc || (rc = q8_topk_enqueue(h, B, k, ids_dev + (size_t)nb * B * k, scores_dev + (size_t)nb * B * k, s))) return rc;
+    for (int g0 = 0; g0 < n_batches; g0 += kGroup) {  // one quantiser launch per group of batches, three launches per batch
+        const int gs = std::min(kGroup, n_batches - g0);
+        int rc = q8_quantize_enqueue(h, queries_dev + (size_t)g0 * B * kDim, gs, B, s);
+        if (rc) return rc;
+        for (int j = 0; j < gs; ++j) {
+            const size_t o = (size_t)(g0 + j) * B * k;
+            if ((rc = q8_scores_enqueue(h, j, B, h->d_scores, h->n_pad, s)) || (rc = q8_topk_enqueue(h, B, k, ids_dev + o, scores_dev + o, s))) return rc;
+        }
     }
     return VS_OK;
 }
