@@ -6,6 +6,9 @@
 //   vsearch_bf <context_binary> <queries.fvecs> <results_dir> <backend.so> <documents.fvecs> <top_k> [batch]
 //                                              : the qidk_bruteforce form (main.cpp:73-85); the model and backend
 //                                                slots are accepted and ignored, results_dir gets results.txt + metrics.txt
+//   ... --q8[=in_scale,w_scale,w_offset,out_scale]: the qidk form through the runner's UFIXED_POINT_8 path (QnnRunner.cpp:
+//                                                13-55, 608-645; main.cpp:30-57): uint8 scores, results.txt holds
+//                                                (id, score8 * output_scale) with 4 decimals (main.cpp:244-246)
 //   ... --gpus N                               : any form on N GPUs, one process per GPU (forked before HIP starts): the base
 //                                                is row-sharded, per-shard top-(k+1) lists meet in one RCCL all-gather per
 //                                                32 batches (vs_bf_search_sharded); rank 0 writes the files
@@ -18,6 +21,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstdio>
 #include <cmath>
 #include <fstream>
 #include <iomanip>
@@ -228,6 +232,62 @@ bool run_benchmark(const std::string& dataset_name, const std::string& base_file
     }
 }
 
+// the qidk_bruteforce harness with the quantised runner: main.cpp:196-251 (batch loop, top-k over raw uint8 scores,
+// dequantised scores in results.txt) and the core sections of its metrics.txt (main.cpp:321-352)
+bool run_q8(const std::string& docs_file, const std::string& query_file, int k, const std::string& results_dir, int batch,
+            const vs_q8_encodings* enc) {
+    using namespace std::chrono;
+    std::vector<float> Q_data, B_data;
+    int Q_rows = 0, Q_dim = 0, B_rows = 0, B_dim = 0;
+    if (!vsearch::read_fvecs(docs_file, B_data, B_rows, B_dim) || !vsearch::read_fvecs(query_file, Q_data, Q_rows, Q_dim)) {
+        std::cerr << "Error: " << vs_last_error() << std::endl;
+        return false;
+    }
+    if (Q_dim != B_dim) {
+        std::cerr << "Error: Query and Base dimensions must be equal." << std::endl;
+        return false;
+    }
+    try {
+        vsearch::QuantizedRunner runner(B_data, B_rows, B_dim, enc, 0);
+        vs_q8_encodings e{};
+        vsearch::check(vs_q8_get_encodings(runner.handle(), &e));
+        std::cout << "UFIXED_POINT_8 runner: input scale " << e.input_scale << ", weight scale " << e.weight_scale << " offset "
+                  << e.weight_offset << ", output scale " << e.output_scale << std::endl;
+        std::vector<int32_t> ids;
+        std::vector<uint8_t> top;
+        runner.search(Q_data, std::min(Q_rows, 32), k, ids, top);  // untimed warm-up (kernel code loads)
+        const auto t0 = high_resolution_clock::now();
+        runner.search(Q_data, Q_rows, k, ids, top);
+        const double total_s = duration_cast<duration<double>>(high_resolution_clock::now() - t0).count();
+        std::vector<float> scores((size_t)Q_rows * k);
+        for (size_t i = 0; i < scores.size(); ++i) scores[i] = static_cast<float>(top[i]) * e.output_scale;  // main.cpp:244
+        if (vs_results_write((results_dir + "/results.txt").c_str(), ids.data(), scores.data(), Q_rows, k, 1) != VS_OK) {
+            std::cerr << "Failed to write results!" << std::endl;
+            return false;
+        }
+        const size_t n_batches = (size_t)((Q_rows + batch - 1) / batch);
+        const double flops_per_batch = 2.0 * batch * Q_dim * (double)B_rows;                                  // main.cpp:284
+        const double bytes = 1.0 * batch * Q_dim + 1.0 * Q_dim * (double)B_rows + 1.0 * batch * (double)B_rows;  // main.cpp:298-305: 1 byte per element
+        std::ofstream m(results_dir + "/metrics.txt");
+        m << std::fixed << std::setprecision(6);
+        m << "=== MI355X RAG Demo Performance Metrics (Batched, UFIXED_POINT_8) ===\n\n";
+        m << "Dataset Information:\n  Number of queries: " << Q_rows << "\n  Number of documents: " << B_rows << "\n  Dimension: " << Q_dim
+          << "\n  Batch size: " << batch << "\n  Number of batches: " << n_batches << "\n  Top-K: " << k << "\n\n";
+        m << "Quantization:\n  Input scale: " << e.input_scale << "\n  Weight scale: " << e.weight_scale << "\n  Weight offset: "
+          << e.weight_offset << "\n  Output scale: " << e.output_scale << "\n\n";
+        m << "Operational Intensity Analysis:\n  FLOPs per batch: " << std::scientific << flops_per_batch << "\n  Bytes moved per batch: "
+          << std::fixed << bytes << "\n  Operational Intensity: " << flops_per_batch / bytes << " FLOPs/byte\n\n";
+        m << "Overall Performance:\n  Total execution time: " << total_s << " s\n  Throughput: " << (Q_rows / std::max(total_s, 1e-12))
+          << " queries/sec\n  Avg total per query: " << total_s * 1000.0 / std::max(Q_rows, 1) << " ms\n";
+        std::cout << "Throughput: " << (Q_rows / std::max(total_s, 1e-12)) << " queries/sec\nMetrics saved to: " << results_dir
+                  << "/metrics.txt" << std::endl;
+        return true;
+    } catch (const std::exception& ex) {
+        std::cerr << "Error: " << ex.what() << std::endl;
+        return false;
+    }
+}
+
 std::string metrics_name(const std::string& out) {
     const std::string tag = "_results.txt";
     if (out.size() >= tag.size() && out.compare(out.size() - tag.size(), tag.size(), tag) == 0)
@@ -239,6 +299,24 @@ std::string metrics_name(const std::string& out) {
 
 int main(int argc, char* argv[]) {
     int status = 0;
+    bool q8 = false, q8_enc_given = false;
+    vs_q8_encodings q8_enc{};
+    for (int i = 1; i < argc; ++i) {
+        const std::string a = argv[i];
+        if (a.rfind("--q8", 0) != 0) continue;
+        q8 = true;
+        if (a.size() > 5 && a[4] == '=') {
+            q8_enc_given = std::sscanf(a.c_str() + 5, "%f,%f,%d,%f", &q8_enc.input_scale, &q8_enc.weight_scale, &q8_enc.weight_offset,
+                                       &q8_enc.output_scale) == 4;
+            if (!q8_enc_given) {
+                std::cerr << "FATAL ERROR: --q8=<input_scale>,<weight_scale>,<weight_offset>,<output_scale>" << std::endl;
+                return 1;
+            }
+        }
+        for (int j = i; j + 1 < argc; ++j) argv[j] = argv[j + 1];
+        --argc;
+        break;
+    }
     try {
         g_ranks = vsearch::fork_ranks(vsearch::take_gpus_flag(argc, argv));  // before anything touches HIP
         vsearch::connect_ranks(g_ranks);
@@ -255,7 +333,12 @@ int main(int argc, char* argv[]) {
         const int k = std::stoi(argv[6]);
         const int batch = argc > 7 ? std::stoi(argv[7]) : 32;
         mkdir(results_dir.c_str(), 0755);
-        if (!run_benchmark(argv[5], argv[5], argv[2], k, results_dir + "/results.txt", results_dir + "/metrics.txt", batch)) {
+        if (q8) {
+            if (g_ranks.world > 1 || !run_q8(argv[5], argv[2], k, results_dir, batch, q8_enc_given ? &q8_enc : nullptr)) {
+                std::cerr << "FATAL ERROR" << (g_ranks.world > 1 ? ": --q8 runs on one GPU" : "") << std::endl;
+                status = 1;
+            }
+        } else if (!run_benchmark(argv[5], argv[5], argv[2], k, results_dir + "/results.txt", results_dir + "/metrics.txt", batch)) {
             std::cerr << "FATAL ERROR" << std::endl;
             status = 1;
         }

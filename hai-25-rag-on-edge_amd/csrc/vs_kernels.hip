@@ -1003,9 +1003,10 @@ __global__ __launch_bounds__(kScanThreads, NQH <= 8 ? 2 : 1) void scan_i8w_kerne
     (void)lds_ticket;
     // a wave takes whole passes (or the m-th part of passes where they do not deal evenly to the 8 waves): see
     // scan_f32s_kernel.  No shared ticket, no barrier.
-    const int low = n_pass & -n_pass;
-    const int m_log = low >= kScanWaves ? 0 : (low == 4 ? 1 : (low == 2 ? 2 : 3));
-    const int n_units = n_pass << m_log;
+    const int n_whole = n_pass & ~(kScanWaves - 1), n_rest = n_pass - n_whole;
+    const int low = n_rest & -n_rest;
+    const int m_log = low == 4 ? 1 : (low == 2 ? 2 : 3);
+    const int n_units = n_whole + (n_rest << m_log);
     char* ring = smem + wave * (kDepth * kSlotBytes);
     unsigned voff[8];
 #pragma unroll
@@ -1046,10 +1047,14 @@ __global__ __launch_bounds__(kScanThreads, NQH <= 8 ? 2 : 1) void scan_i8w_kerne
                 pass_out = n_pass;
                 return (int)blockIdx.x;  // past the end: the DMA still goes out (queue accounting), to a tile nobody uses
             }
-            it_pass = it_u >> m_log;
-            const int part = it_u & ((1 << m_log) - 1);
-            it_n = (int)(((long long)part * T) >> m_log);
-            it_end = (int)(((long long)(part + 1) * T) >> m_log);
+            if (it_u < n_whole) {
+                it_pass = it_u, it_n = 0, it_end = T;
+            } else {
+                const int v = it_u - n_whole, part = v & ((1 << m_log) - 1);
+                it_pass = n_whole + (v >> m_log);
+                it_n = (int)(((long long)part * T) >> m_log);
+                it_end = (int)(((long long)(part + 1) * T) >> m_log);
+            }
         }
         pass_out = it_pass;
         return (int)blockIdx.x + (it_n++) * G;
@@ -1205,12 +1210,14 @@ __global__ __launch_bounds__(kScanThreads, NB == 1 ? 2 : 1) void scan_f32s_kerne
     (void)lds_ticket;
     // Work of a wave = whole passes, not tiles dealt one by one: a pass costs its operand fetch and a drain on entry (1.3 us
     // with one batch per pass, 6.6 us with two), so a wave should enter as few passes as possible.  The workgroup's passes
-    // are cut into `m` parts of its T tiles each, m the smallest number for which the units (pass, part) deal evenly to
-    // the 8 waves (m = 8 / gcd(n_pass, 8): 16 passes -> a wave takes 2 whole passes instead of entering all 16).  No shared
-    // ticket, no barrier: waves never meet.
-    const int low = n_pass & -n_pass;                                   // lowest set bit of n_pass
-    const int m_log = low >= kScanWaves ? 0 : (low == 4 ? 1 : (low == 2 ? 2 : 3));
-    const int n_units = n_pass << m_log;
+    // are dealt whole as far as they deal evenly to the 8 waves (the first n_pass & ~7); the n_rest others are cut into `m`
+    // parts of the T tiles each, m the smallest number for which those units (pass, part) deal evenly (m = 8 / gcd(n_rest,
+    // 8)): 16 passes -> a wave takes 2 whole passes instead of entering all 16; 10 passes -> one whole pass and a quarter
+    // of another instead of five quarters.  No shared ticket, no barrier: waves never meet.
+    const int n_whole = n_pass & ~(kScanWaves - 1), n_rest = n_pass - n_whole;  // passes taken whole / cut into parts
+    const int low = n_rest & -n_rest;                                           // lowest set bit of n_rest
+    const int m_log = low == 4 ? 1 : (low == 2 ? 2 : 3);
+    const int n_units = n_whole + (n_rest << m_log);
     char* ring = smem + wave * (kDepth * kSlotBytes);
     unsigned voff[8];
 #pragma unroll
@@ -1249,10 +1256,14 @@ __global__ __launch_bounds__(kScanThreads, NB == 1 ? 2 : 1) void scan_f32s_kerne
                 pass_out = n_pass;
                 return (int)blockIdx.x;  // past the end: the DMA still goes out (queue accounting), to a tile nobody uses
             }
-            it_pass = it_u >> m_log;
-            const int part = it_u & ((1 << m_log) - 1);
-            it_n = (int)(((long long)part * T) >> m_log);
-            it_end = (int)(((long long)(part + 1) * T) >> m_log);
+            if (it_u < n_whole) {
+                it_pass = it_u, it_n = 0, it_end = T;
+            } else {
+                const int v = it_u - n_whole, part = v & ((1 << m_log) - 1);
+                it_pass = n_whole + (v >> m_log);
+                it_n = (int)(((long long)part * T) >> m_log);
+                it_end = (int)(((long long)(part + 1) * T) >> m_log);
+            }
         }
         pass_out = it_pass;
         return (int)blockIdx.x + (it_n++) * G;

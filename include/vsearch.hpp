@@ -5,6 +5,7 @@
 //   vsearch::read_fvecs / load_ivecs   <- cpu/cpu_baseline.cpp:31-58, main_ivf.cpp:35-50
 //   vsearch::ExactSearch               <- the query loop of run_benchmark (cpu_baseline.cpp:209-254)
 //                                         with QnnRunner-style getters (QnnRunner.h:37-39)
+//   vsearch::QuantizedRunner           <- class QnnRunner (qidk_bruteforce QnnRunner.h:18-55), UFIXED_POINT_8 I/O
 //   vsearch::IVFIndex                  <- class IVFIndex (IVFIndex.h:14-97): search / searchBatch /
 //                                         SearchTiming / getNumVectors / getNumClusters / getDim
 // Errors: the IVF side throws std::runtime_error like the reference (IVFIndex.cpp:184-198,
@@ -12,6 +13,7 @@
 #pragma once
 #include <cstdint>
 #include <stdexcept>
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -110,6 +112,59 @@ public:
 
 private:
     vs_index* h_ = nullptr;
+};
+
+// QnnRunner with its UFIXED_POINT_8 I/O (qidk_bruteforce QnnRunner.h:18-55): same method names, the database is handed
+// over as floats and quantised at construction (the reference bakes it into the model blob offline).
+struct ExecutionTiming {  // QnnRunner.h:12-17
+    double quantize_ms = 0.0;       // here: inside graph_execute_ms (the quantiser is a device launch)
+    double graph_execute_ms = 0.0;
+    double dequantize_ms = 0.0;
+    double total_ms = 0.0;
+};
+
+class QuantizedRunner {
+public:
+    // enc == nullptr: the runner's hard-coded input / output scales (QnnRunner.cpp:490-521), weights min-max
+    QuantizedRunner(const std::vector<float>& docs, int64_t rows, int dim, const vs_q8_encodings* enc = nullptr, int device = 0) {
+        check(vs_q8_create(docs.data(), rows, dim, enc, device, 0, &h_));
+        out_.resize((size_t)vs_q8_batch(h_) * (size_t)rows);
+    }
+    ~QuantizedRunner() { vs_q8_destroy(h_); }
+    QuantizedRunner(const QuantizedRunner&) = delete;
+    QuantizedRunner& operator=(const QuantizedRunner&) = delete;
+
+    size_t getBatchSize() const { return (size_t)vs_q8_batch(h_); }
+    size_t getDim() const { return (size_t)vs_q8_dim(h_); }
+    size_t getNumDocs() const { return (size_t)vs_q8_num_docs(h_); }
+    float getOutputScale() const { return vs_q8_output_scale(h_); }
+    bool isFloatModel() const { return false; }
+
+    // batch_queries: [B * dim], B <= getBatchSize() (the reference pads to the model batch with zeros, main.cpp:206-211)
+    void executeBatchRaw(const std::vector<float>& batch_queries, ExecutionTiming& timing) {
+        const auto t0 = std::chrono::high_resolution_clock::now();
+        const int B = (int)(batch_queries.size() / getDim());
+        check(vs_q8_execute(h_, batch_queries.data(), B, out_.data()));
+        timing.graph_execute_ms = timing.total_ms =
+            std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
+        rows_valid_ = B;
+    }
+    // [B x getNumDocs()] uint8, valid until the next execute (QnnRunner.h:37)
+    const uint8_t* getRawOutputBuffer() const { return out_.data(); }
+    size_t getOutputSize() const { return (size_t)rows_valid_ * getNumDocs(); }
+
+    // executeBatchRaw + find_top_k_batch_parallel (main.cpp:59-71) on the device: ids / raw scores, [nq x k]
+    void search(const std::vector<float>& queries, int64_t nq, int k, std::vector<int32_t>& ids, std::vector<uint8_t>& scores) {
+        ids.assign((size_t)nq * k, -1);
+        scores.assign((size_t)nq * k, 0);
+        check(vs_q8_search(h_, queries.data(), nq, k, ids.data(), scores.data()));
+    }
+    vs_q8* handle() { return h_; }
+
+private:
+    vs_q8* h_ = nullptr;
+    std::vector<uint8_t> out_;
+    int rows_valid_ = 0;
 };
 
 class IVFIndex {

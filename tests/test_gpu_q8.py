@@ -131,3 +131,39 @@ def test_sift1m_score_matrix_and_topk(gpu_pkg):
     assert np.array_equal(got, want)
     oid, otop = oracle.q8_topk(want, 5)
     assert np.array_equal(ids, oid) and np.array_equal(top, otop)
+
+
+def test_cli_q8_mode_writes_the_qidk_harness_files(gpu_pkg, tmp_path):
+    """`vsearch_bf <ctx> <queries> <results_dir> <backend> <documents> <k> [batch] --q8=...`: the qidk_bruteforce harness
+    (main.cpp:196-251) through the quantised runner -- results.txt holds (id, score8 * output_scale) with 4 decimals
+    (main.cpp:244-246), equal to the oracle's restatement."""
+    import os
+    import subprocess
+
+    base = gpu_pkg.synth_sift(30000, seed=51)
+    q = gpu_pkg.synth_sift(70, seed=52)
+    i_s, w_s, o_s = (np.float32(x) for x in _calibrated(base, q))
+    gpu_pkg.write_fvecs(str(tmp_path / "docs.fvecs"), base)
+    gpu_pkg.write_fvecs(str(tmp_path / "queries.fvecs"), q)
+    exe = os.path.join(os.path.dirname(gpu_pkg.LIB_PATH), "vsearch_bf")
+    assert os.path.exists(exe), "vsearch_bf not built (make -C hai-25-rag-on-edge_amd/csrc all)"
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = gpu_pkg.hip_runtime_dir() + os.pathsep + env.get("LD_LIBRARY_PATH", "")
+    enc = f"--q8={float(i_s)!r},{float(w_s)!r},0,{float(o_s)!r}"
+    r = subprocess.run([exe, "ctx.bin", "queries.fvecs", "out", "libQnnHtp.so", "docs.fvecs", "5", "32", enc], cwd=tmp_path, env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    raw = oracle.q8_scores(base, q, i_s, w_s, 0, o_s)
+    oid, otop = oracle.q8_topk(raw, 5)
+    ids, scores = oracle.parse_results_txt(str(tmp_path / "out" / "results.txt"))
+    assert np.array_equal(np.array(ids), oid)
+    want = np.array([[float(f"{np.float32(t) * o_s:.4f}") for t in row] for row in otop])
+    assert np.array_equal(np.array(scores), want)
+    m = open(tmp_path / "out" / "metrics.txt").read()
+    for needle in ("UFIXED_POINT_8", "Number of queries: 70", "Number of documents: 30000", "Batch size: 32", "Number of batches: 3",
+                   "Top-K: 5", "Output scale:", "Operational Intensity:", "Throughput:", "queries/sec"):
+        assert needle in m, needle
+    # unparsable encodings are refused before any work
+    r = subprocess.run([exe, "ctx.bin", "queries.fvecs", "out", "libQnnHtp.so", "docs.fvecs", "5", "--q8=1,2"], cwd=tmp_path, env=env,
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "--q8=" in r.stderr
