@@ -1001,12 +1001,9 @@ __global__ __launch_bounds__(kScanThreads, NQH <= 8 ? 2 : 1) void scan_i8w_kerne
     const int NB = NQH / p.bpb;                                  // batches per pass
     const int n_pass = (p.n_batches + NB - 1) / NB;
     (void)lds_ticket;
-    // a wave takes whole passes (or the m-th part of passes where they do not deal evenly to the 8 waves): see
-    // scan_f32s_kernel.  No shared ticket, no barrier.
+    // a wave takes whole passes, and a contiguous range of the tiles of the passes that do not deal evenly to the 8 waves:
+    // see scan_f32s_kernel.  No shared ticket, no barrier.
     const int n_whole = n_pass & ~(kScanWaves - 1), n_rest = n_pass - n_whole;
-    const int low = n_rest & -n_rest;
-    const int m_log = low == 4 ? 1 : (low == 2 ? 2 : 3);
-    const int n_units = n_whole + (n_rest << m_log);
     char* ring = smem + wave * (kDepth * kSlotBytes);
     unsigned voff[8];
 #pragma unroll
@@ -1040,20 +1037,21 @@ __global__ __launch_bounds__(kScanThreads, NQH <= 8 ? 2 : 1) void scan_i8w_kerne
     }
     const unsigned fa_n = (unsigned)(wave * (kDepth * kSlotBytes) + 8192 + 16 * g);
     int it_u = wave - kScanWaves, it_n = 0, it_end = 0, it_pass = 0;
+    int rem_pos = (int)((long long)wave * n_rest * T / kScanWaves), rem_end = (int)((long long)(wave + 1) * n_rest * T / kScanWaves);
     auto next_tile = [&](int& pass_out) __attribute__((always_inline)) -> int {
         while (it_n >= it_end) {
-            it_u += kScanWaves;
-            if (it_u >= n_units) {
+            if (it_u + kScanWaves < n_whole) {          // the next whole pass of this wave
+                it_u += kScanWaves;
+                it_pass = it_u, it_n = 0, it_end = T;
+            } else if (rem_pos < rem_end) {             // its range of the remaining passes' tiles: at most two passes
+                const int pr = rem_pos / T;
+                it_pass = n_whole + pr;
+                it_n = rem_pos - pr * T;
+                it_end = min(T, it_n + (rem_end - rem_pos));
+                rem_pos += it_end - it_n;
+            } else {
                 pass_out = n_pass;
                 return (int)blockIdx.x;  // past the end: the DMA still goes out (queue accounting), to a tile nobody uses
-            }
-            if (it_u < n_whole) {
-                it_pass = it_u, it_n = 0, it_end = T;
-            } else {
-                const int v = it_u - n_whole, part = v & ((1 << m_log) - 1);
-                it_pass = n_whole + (v >> m_log);
-                it_n = (int)(((long long)part * T) >> m_log);
-                it_end = (int)(((long long)(part + 1) * T) >> m_log);
             }
         }
         pass_out = it_pass;
@@ -1210,14 +1208,12 @@ __global__ __launch_bounds__(kScanThreads, NB == 1 ? 2 : 1) void scan_f32s_kerne
     (void)lds_ticket;
     // Work of a wave = whole passes, not tiles dealt one by one: a pass costs its operand fetch and a drain on entry (1.3 us
     // with one batch per pass, 6.6 us with two), so a wave should enter as few passes as possible.  The workgroup's passes
-    // are dealt whole as far as they deal evenly to the 8 waves (the first n_pass & ~7); the n_rest others are cut into `m`
-    // parts of the T tiles each, m the smallest number for which those units (pass, part) deal evenly (m = 8 / gcd(n_rest,
-    // 8)): 16 passes -> a wave takes 2 whole passes instead of entering all 16; 10 passes -> one whole pass and a quarter
-    // of another instead of five quarters.  No shared ticket, no barrier: waves never meet.
-    const int n_whole = n_pass & ~(kScanWaves - 1), n_rest = n_pass - n_whole;  // passes taken whole / cut into parts
-    const int low = n_rest & -n_rest;                                           // lowest set bit of n_rest
-    const int m_log = low == 4 ? 1 : (low == 2 ? 2 : 3);
-    const int n_units = n_whole + (n_rest << m_log);
+    // are dealt whole as far as they deal evenly to the 8 waves (the first n_pass & ~7); the tiles of the n_rest others,
+    // pass after pass, are shared out as 8 equal contiguous ranges (a range is at most one pass long, so it touches at most
+    // two passes): 16 passes -> a wave takes 2 whole passes instead of entering all 16; 10 passes -> one whole pass and a
+    // quarter of another; 5 passes -> 5/8 of a pass in at most two entries instead of an eighth of each of the five.
+    // No shared ticket, no barrier: waves never meet.
+    const int n_whole = n_pass & ~(kScanWaves - 1), n_rest = n_pass - n_whole;  // passes taken whole / shared out by range
     char* ring = smem + wave * (kDepth * kSlotBytes);
     unsigned voff[8];
 #pragma unroll
@@ -1249,20 +1245,21 @@ __global__ __launch_bounds__(kScanThreads, NB == 1 ? 2 : 1) void scan_f32s_kerne
     const unsigned fa_n = (unsigned)(wave * (kDepth * kSlotBytes) + 8192 + 16 * g);
     // this wave's position: unit it_u (= pass * m + part), tile index it_n of the workgroup's T inside [.., it_end)
     int it_u = wave - kScanWaves, it_n = 0, it_end = 0, it_pass = 0;
+    int rem_pos = (int)((long long)wave * n_rest * T / kScanWaves), rem_end = (int)((long long)(wave + 1) * n_rest * T / kScanWaves);
     auto next_tile = [&](int& pass_out) __attribute__((always_inline)) -> int {
-        while (it_n >= it_end) {  // (also skips empty parts: T < m)
-            it_u += kScanWaves;
-            if (it_u >= n_units) {
+        while (it_n >= it_end) {
+            if (it_u + kScanWaves < n_whole) {          // the next whole pass of this wave
+                it_u += kScanWaves;
+                it_pass = it_u, it_n = 0, it_end = T;
+            } else if (rem_pos < rem_end) {             // its range of the remaining passes' tiles: at most two passes
+                const int pr = rem_pos / T;
+                it_pass = n_whole + pr;
+                it_n = rem_pos - pr * T;
+                it_end = min(T, it_n + (rem_end - rem_pos));
+                rem_pos += it_end - it_n;
+            } else {
                 pass_out = n_pass;
                 return (int)blockIdx.x;  // past the end: the DMA still goes out (queue accounting), to a tile nobody uses
-            }
-            if (it_u < n_whole) {
-                it_pass = it_u, it_n = 0, it_end = T;
-            } else {
-                const int v = it_u - n_whole, part = v & ((1 << m_log) - 1);
-                it_pass = n_whole + (v >> m_log);
-                it_n = (int)(((long long)part * T) >> m_log);
-                it_end = (int)(((long long)(part + 1) * T) >> m_log);
             }
         }
         pass_out = it_pass;
