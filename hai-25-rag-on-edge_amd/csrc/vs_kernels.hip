@@ -1272,7 +1272,7 @@ __global__ __launch_bounds__(kScanThreads, NB == 1 ? 2 : 1) void scan_f32s_kerne
     // step); the hand-counted waits of the tile loop cover them.  A padding query (main.cpp:206-211) reads row 0 and
     // is masked where candidates are taken: its MFMA column influences nothing else.
     f32x4 qf[NH][8];
-    float qn[NH], tau[NH];
+    float qn[NH], tau[NH], thr[NH];
     int qglob[NH];
     bool live[NH];
     auto load_pass = [&](int pass) __attribute__((always_inline)) {
@@ -1312,6 +1312,14 @@ __global__ __launch_bounds__(kScanThreads, NB == 1 ? 2 : 1) void scan_f32s_kerne
             load_pass(pass_cur);
             have_pass = pass_cur;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // operands are here (and so are both staged tiles)
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                // bound of the hot test.  L2: d = RN(RN(qn + bn) - 2 dot) < tau implies RN(bn - 2 dot) < tau - qn + slack:
+                // the three roundings together move the comparison by less than 2^-24 * 8 (qn + |tau|) (a row under the
+                // bound has bn < 2 (qn + tau)); the slack is 16 times that.  IP: -dot < tau <=> dot > -tau, exactly.
+                const float l2thr = (tau[h] - qn[h]) + 9.5367431640625e-7f * (qn[h] + fabsf(tau[h]));
+                thr[h] = p.metric ? (live[h] ? -tau[h] : __builtin_inff()) : (live[h] ? l2thr : -__builtin_inff());
+            }
         }
         int pass_new;
         const int tile_new = next_tile(pass_new);
@@ -1341,30 +1349,44 @@ __global__ __launch_bounds__(kScanThreads, NB == 1 ? 2 : 1) void scan_f32s_kerne
 #pragma unroll
                     for (int h = 0; h < 2; ++h) acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][i], qf[h][c][i], acc[h], 0, 0, 0);
         }
-        float d[NH][4];
-        bool any = false;
+        // Hot path: ONE fma and ONE compare per value, the verdicts collected as wave masks in scalar registers (every
+        // vector instruction here costs the SIMD about 8 cycles of its MFMA pipe).  The test is a superset of d < tau
+        // (thr carries the rounding slack, load_pass); whatever passes it is judged again below with the exact expression.
+        unsigned long long hit[NH][4], hits = 0;
+        if (!p.metric) {
 #pragma unroll
-        for (int h = 0; h < NH; ++h)
+            for (int h = 0; h < NH; ++h)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                // cpu_baseline.cpp:241  dist = qn + bn - 2*dot  (gcc contracts to fnmadd(2, dot, qn+bn))
-                const float l2 = fmaf(-2.0f, acc[h][j], qn[h] + bn[j]);
-                d[h][j] = p.metric ? -acc[h][j] : l2;
-                any = any || (live[h] && d[h][j] < tau[h]);
-            }
-        if (__ballot(any)) {  // rare: a few hundred rows per query per million
+                for (int j = 0; j < 4; ++j) {
+                    hit[h][j] = __ballot(fmaf(-2.0f, acc[h][j], bn[j]) < thr[h]);
+                    hits |= hit[h][j];
+                }
+        } else {
+#pragma unroll
+            for (int h = 0; h < NH; ++h)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    hit[h][j] = __ballot(acc[h][j] > thr[h]);  // -acc < tau, exactly
+                    hits |= hit[h][j];
+                }
+        }
+        if (hits) {  // rare: a few hundred rows per query per million
             const int row_t = tile_cur * TR + 4 * g;
 #pragma unroll
             for (int h = 0; h < NH; ++h)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
+                    if (!hit[h][j]) continue;  // wave-uniform
+                    // cpu_baseline.cpp:241  dist = qn + bn - 2*dot  (gcc contracts to fnmadd(2, dot, qn+bn))
+                    const float l2 = fmaf(-2.0f, acc[h][j], qn[h] + bn[j]);
+                    const float d = p.metric ? -acc[h][j] : l2;
                     const int row = row_t + j;
-                    const bool pass = live[h] && d[h][j] < tau[h] && row < (int)p.n_rows;
+                    const bool pass = live[h] && d < tau[h] && row < (int)p.n_rows;
                     const unsigned long long mask = __ballot(pass);
                     if (mask) {
                         const int pos = wbase + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
                         if (pass && pos < p.sink.wcap)
-                            wbuf[pos] = make_int4(qglob[h], __builtin_bit_cast(int, d[h][j]), row + p.id_offset, 0);
+                            wbuf[pos] = make_int4(qglob[h], __builtin_bit_cast(int, d), row + p.id_offset, 0);
                         wbase += __popcll(mask);
                     }
                 }
