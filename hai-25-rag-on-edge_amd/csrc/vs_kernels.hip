@@ -1222,28 +1222,27 @@ __global__ __launch_bounds__(kScanThreads, NB == 1 ? 2 : 1) void scan_f32s_kerne
         voff[j] = (unsigned)(row_in * 512 + 16 * ((lane & 31) ^ row_in));
     }
     const unsigned voff_n = (unsigned)lane * 4u;
+    // LDS-DMA written as instructions: "scalar tile base + this lane's 32-bit offset", M0 = the slot's LDS address + the
+    // piece (one wait state between the scalar write of M0 and the instruction that reads it).  (Through the builtin every piece cost two vector instructions -- a register copy and the M0 value read
+    // back from a spilled scalar -- and a vector instruction costs this kernel about 8 cycles of MFMA pipe.)
+    const unsigned ring_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)ring);
     auto issue_tile = [&](int tile, int slot) __attribute__((always_inline)) {
         const int64_t row0 = (int64_t)tile * TR;
-        char* dst = ring + slot * kSlotBytes;
+        const unsigned dst = ring_lds + (unsigned)(slot * kSlotBytes);
         const char* tb = reinterpret_cast<const char*>(p.base) + row0 * (kDim * 4);
+        static_assert(VS_ROW_CPOL == 2, "the row pieces are issued with the nt policy");
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            unsigned vo = voff[j];
-            asm volatile("" : "+v"(vo));
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tb + vo),
-                                             (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, 0, VS_ROW_CPOL);
-        }
+        for (int j = 0; j < 8; ++j)
+            asm volatile("s_add_u32 m0, %0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt" ::"s"(dst), "v"(voff[j]), "s"(tb), "n"(j * 1024) : "memory", "scc");
         const char* nb = reinterpret_cast<const char*>(p.bnorm + row0);
-        unsigned vn = voff_n;
-        asm volatile("" : "+v"(vn));
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(nb + vn),
-                                         (__attribute__((address_space(3))) void*)(dst + 8192), 4, 0, 0);
+        asm volatile("s_add_u32 m0, %0, 8192\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" ::"s"(dst), "v"(voff_n), "s"(nb) : "memory", "scc");
     };
     unsigned fa[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) fa[c] = (unsigned)(wave * (kDepth * kSlotBytes) + r * 512 + (((4 * c + g) ^ r) << 4));
     const unsigned fa_n = (unsigned)(wave * (kDepth * kSlotBytes) + 8192 + 16 * g);
-    // this wave's position: unit it_u (= pass * m + part), tile index it_n of the workgroup's T inside [.., it_end)
+    // this wave's position: whole pass it_u, then [rem_pos, rem_end) of the remaining passes' tiles; inside a pass tile
+    // index it_n of the workgroup's T, up to it_end
     int it_u = wave - kScanWaves, it_n = 0, it_end = 0, it_pass = 0;
     int rem_pos = (int)((long long)wave * n_rest * T / kScanWaves), rem_end = (int)((long long)(wave + 1) * n_rest * T / kScanWaves);
     auto next_tile = [&](int& pass_out) __attribute__((always_inline)) -> int {
