@@ -1012,22 +1012,17 @@ __global__ __launch_bounds__(kScanThreads, NQH <= 8 ? 2 : 1) void scan_i8w_kerne
         voff[j] = (unsigned)(row_in * 128 + 16 * ((lane & 7) ^ ((row_in >> 1) & 7)));
     }
     const unsigned voff_n = (unsigned)lane * 4u;
+    // LDS-DMA written as instructions (see scan_f32s_kernel): no vector instruction per piece
+    const unsigned ring_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)ring);
     auto issue_tile = [&](int tile, int slot) __attribute__((always_inline)) {
         const int64_t row0 = (int64_t)tile * TR;
-        char* dst = ring + slot * kSlotBytes;
+        const unsigned dst = ring_lds + (unsigned)(slot * kSlotBytes);
         const char* tb = reinterpret_cast<const char*>(p.base_u8) + row0 * kDim;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            unsigned vo = voff[j];
-            asm volatile("" : "+v"(vo));
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tb + vo),
-                                             (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, 0, 0);
-        }
+        for (int j = 0; j < 8; ++j)
+            asm volatile("s_add_u32 m0, %0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(voff[j]), "s"(tb), "n"(j * 1024) : "memory", "scc");
         const char* nb = reinterpret_cast<const char*>(p.rterm + row0);
-        unsigned vn = voff_n;
-        asm volatile("" : "+v"(vn));
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(nb + vn),
-                                         (__attribute__((address_space(3))) void*)(dst + 8192), 4, 0, 0);
+        asm volatile("s_add_u32 m0, %0, 8192\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" ::"s"(dst), "v"(voff_n), "s"(nb) : "memory", "scc");
     };
     unsigned fa[8];
 #pragma unroll
