@@ -29,4 +29,6 @@ SB="python3 bench.py --steps 64 --warmup 32 --no-cpu --no-extras --no-prof --rep
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_INSTS_VALU -d $out/sq1 -o a -- $SB > /dev/null 2> $out/sq1.err; echo "sq1 rc=$?"
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES -d $out/sq2 -o b -- $SB > /dev/null 2> $out/sq2.err; echo "sq2 rc=$?"
 python3 scripts/pmc_counters.py "$(db $out/sq1)" "$(db $out/sq2)" > $out/sq_counters.txt; rm -rf $out/sq1 $out/sq2
+# what the fp32 MFMA pipe delivers in the scan's issue pattern without the scan's other work
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/mfma_f32_ceiling scripts/microbench/mfma_f32_ceiling.hip 2> $out/mfma_ceiling.err && timeout -k 5 60 /tmp/mfma_f32_ceiling > $out/mfma_ceiling.txt; echo "mfma ceiling rc=$?"
 grep "^\[bench\]" $out/bench_default.err
