@@ -518,13 +518,17 @@ def main():
                                      lambda c, q, nb, B, ip, dp, fl, st: ivf.search_dev_sharded(c, q, nb, B, K, nprobe, ip, dp, st),
                                      gs, qp, K, iout_i, iout_d, 0)
 
+                # an extra, timed in its own steady state: regions of at least one full call (SI batches = four launch groups
+                # on the library's two streams), whatever --steps says for the headline (the driver's 20 steps would be one
+                # 20-batch group on one stream: half the rate, r02k_bench_driver_flags.json in profiles/)
+                isteps = max(steps, SI) if world == 1 else steps
                 ivf.prof_enable(True)
-                ireg = timed(ivf_step, steps, warmup)
+                ireg = timed(ivf_step, isteps, warmup)
                 okern_ms, okern_n = ivf.prof_read(1)
                 ivf.prof_enable(False)
                 iel = median(ireg)
-                info = {"metric": "ivf_qps", "value": round(steps * BATCH / iel, 1), "ms_per_step": round(iel / steps * 1e3, 4),
-                        "nlist": nlist, "nprobe": nprobe, "batch": BATCH, "batches_per_call": min(SI, steps)}
+                info = {"metric": "ivf_qps", "value": round(isteps * BATCH / iel, 1), "ms_per_step": round(iel / isteps * 1e3, 4),
+                        "nlist": nlist, "nprobe": nprobe, "batch": BATCH, "batches_per_call": min(SI, isteps), "steps": isteps}
                 if world == 1:
                     nrec = 1024
                     ids, _, total = ivf.searchBatch(queries[:nrec], nrec, K, nprobe)
@@ -547,7 +551,7 @@ def main():
                         calls = [SI] * (n // SI) + ([n % SI] if n % SI else [])
                         return [g for c in calls for g in [32] * (c // 32) + ([c % 32] if c % 32 else [])]
 
-                    window = launches_of(warmup) + launches_of(steps) * len(ireg)   # every launch of the prof window
+                    window = launches_of(warmup) + launches_of(isteps) * len(ireg)   # every launch of the prof window
                     per_size = {gs: launch_bytes(gs) for gs in set(window)}
                     ib = sum(per_size[gs][0] for gs in window) / max(len(window), 1)   # mean algorithmic bytes per launch
                     uniq_rows = per_size[max(per_size)][1]
