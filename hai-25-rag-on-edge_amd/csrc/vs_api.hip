@@ -242,6 +242,7 @@ struct vs_index {
     } ihs[2];
     // tie resolver (flagged queries of vs_bf_search): distances to the first kTieDense rows, bound, filtered candidates
     float* d_tie_dense = nullptr;  // [32][kTieDense]
+    char* pin_tie = nullptr;       // pinned staging of the tie resolver: dense [32][kTieDense] f32 | cnt [32] | rows [32][kTieCap] | dists [32][kTieCap]
     float* d_tie_tau = nullptr;    // [32]
     int32_t* d_tie_cnt = nullptr;  // [32]
     int32_t* d_tie_row = nullptr;  // [32][kTieCap]
@@ -348,6 +349,7 @@ void free_all(vs_index* h) {
         for (hipEvent_t e : evs)
             if (e) (void)hipEventDestroy(e);
     }
+    if (h->pin_tie) (void)hipHostFree(h->pin_tie);
     void* tie[] = {h->d_tie_dense, h->d_tie_tau, h->d_tie_cnt, h->d_tie_row, h->d_tie_d};
     for (void* q : tie)
         if (q) (void)hipFree(q);
@@ -1436,13 +1438,18 @@ int resolve_ties(vs_index* h, const float* queries_host, const std::vector<int64
         if ((rc = dev_alloc(&h->d_tie_cnt, 32))) return rc;
         if ((rc = dev_alloc(&h->d_tie_row, (size_t)32 * kTieCap))) return rc;
         if ((rc = dev_alloc(&h->d_tie_d, (size_t)32 * kTieCap))) return rc;
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h->pin_tie), (size_t)32 * kTieDense * 4 + 128 + (size_t)2 * 32 * kTieCap * 4, hipHostMallocDefault));
     }
     const int group = 32;
-    std::vector<float> qbuf((size_t)group * vs::kDim), dense((size_t)group * L0p), cd;
-    std::vector<int32_t> cr, order;
+    // downloads land in pinned memory (pageable destinations are staged by the runtime: several times slower)
+    float* const dense = reinterpret_cast<float*>(h->pin_tie);
+    int32_t* const cnt = reinterpret_cast<int32_t*>(h->pin_tie + (size_t)32 * kTieDense * 4);
+    int32_t* const cr = cnt + 32;
+    float* const cd = reinterpret_cast<float*>(cr + (size_t)32 * kTieCap);
+    std::vector<float> qbuf((size_t)group * vs::kDim);
+    std::vector<int32_t> order;
     std::vector<int32_t> srow;
     std::vector<float> sdist;
-    int32_t cnt[32];
     for (size_t f0 = 0; f0 < flagged.size(); f0 += group) {
         const int B = (int)std::min<size_t>(group, flagged.size() - f0);
         for (int b = 0; b < B; ++b)
@@ -1481,9 +1488,9 @@ int resolve_ties(vs_index* h, const float* queries_host, const std::vector<int64
             scan_geometry(h->n_rows - L0, h->num_cus, grid, tp);
             p.tiles_per_wg = tp;
             HIPCHK(vs::launch_scan(p, grid, 8, 2, vs::kModeFilter, h->stream));
-            HIPCHK(hipMemcpyAsync(cnt, h->d_tie_cnt, sizeof(cnt), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipMemcpyAsync(cnt, h->d_tie_cnt, 32 * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
         }
-        HIPCHK(hipMemcpyAsync(dense.data(), h->d_tie_dense, (size_t)B * L0p * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(dense, h->d_tie_dense, (size_t)B * L0p * sizeof(float), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
         int mx = 0;
         std::vector<int> overflow;
@@ -1493,11 +1500,9 @@ int resolve_ties(vs_index* h, const float* queries_host, const std::vector<int64
                 else mx = std::max(mx, cnt[b]);
             }
             if (mx > 0) {
-                cr.resize((size_t)B * mx);
-                cd.resize((size_t)B * mx);
-                HIPCHK(hipMemcpy2DAsync(cr.data(), (size_t)mx * 4, h->d_tie_row, (size_t)kTieCap * 4, (size_t)mx * 4, B,
+                HIPCHK(hipMemcpy2DAsync(cr, (size_t)mx * 4, h->d_tie_row, (size_t)kTieCap * 4, (size_t)mx * 4, B,
                                         hipMemcpyDeviceToHost, h->stream));
-                HIPCHK(hipMemcpy2DAsync(cd.data(), (size_t)mx * 4, h->d_tie_d, (size_t)kTieCap * 4, (size_t)mx * 4, B,
+                HIPCHK(hipMemcpy2DAsync(cd, (size_t)mx * 4, h->d_tie_d, (size_t)kTieCap * 4, (size_t)mx * 4, B,
                                         hipMemcpyDeviceToHost, h->stream));
                 HIPCHK(hipStreamSynchronize(h->stream));
             }
