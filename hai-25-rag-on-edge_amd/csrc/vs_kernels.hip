@@ -17,7 +17,13 @@
 //                          ivf_list_scan_kernel / pick_probes_kernel / ivf_scan_kernel: earlier and fallback paths.
 //   kpp_*_kernel, kmeans_*_kernel : index builder (create_ivf_model_reordered.py:88-118).
 //
-// Wavefront = 64 lanes everywhere; nothing here is written for 32-wide warps.
+// (The UFIXED_POINT_8 score path of the reference's device runner -- quantiser, uint8 score matrix, top-k over it --
+//  lives in vs_q8.hip with its own C ABI.)
+//
+// Wavefront = 64 lanes everywhere; nothing here is written for 32-wide warps.  In the MFMA-bound scans every ordinary
+// vector instruction costs the SIMD about 8 cycles of MFMA pipe and an LDS-DMA instruction about 50
+// (scripts/microbench/mfma_f32_ceiling.hip): their tile loops keep vector work to one fma + one compare per value and
+// issue the LDS-DMA as instructions (scalar base + lane offset, M0 by scalar add).
 #include "vs_kernels.h"
 #include <type_traits>
 #include <algorithm>
