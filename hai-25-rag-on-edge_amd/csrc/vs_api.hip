@@ -14,7 +14,9 @@
 #include <cstring>
 #include <limits>
 #include <numeric>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/vsearch.h"
@@ -1447,9 +1449,6 @@ int resolve_ties(vs_index* h, const float* queries_host, const std::vector<int64
     int32_t* const cr = cnt + 32;
     float* const cd = reinterpret_cast<float*>(cr + (size_t)32 * kTieCap);
     std::vector<float> qbuf((size_t)group * vs::kDim);
-    std::vector<int32_t> order;
-    std::vector<int32_t> srow;
-    std::vector<float> sdist;
     for (size_t f0 = 0; f0 < flagged.size(); f0 += group) {
         const int B = (int)std::min<size_t>(group, flagged.size() - f0);
         for (int b = 0; b < B; ++b)
@@ -1507,26 +1506,51 @@ int resolve_ties(vs_index* h, const float* queries_host, const std::vector<int64
                 HIPCHK(hipStreamSynchronize(h->stream));
             }
         }
-        for (int b = 0; b < B; ++b) {
-            const int m = sparse ? cnt[b] : 0;
-            if (m > kTieCap) continue;  // full-row fallback below
-            srow.resize((size_t)L0 + m);
-            sdist.resize((size_t)L0 + m);
-            for (int64_t j = 0; j < L0; ++j) {
-                srow[(size_t)j] = (int32_t)(j + h->id_offset);
-                sdist[(size_t)j] = dense[(size_t)b * L0p + j];
+        // the flagged queries are independent: their replays run on a few host threads (a replay walks ~5000 entries)
+        auto replay = [&](int b_begin, int b_end) {
+            std::vector<int32_t> srow, order;
+            std::vector<float> sdist;
+            for (int b = b_begin; b < b_end; ++b) {
+                const int m = sparse ? cnt[b] : 0;
+                if (m > kTieCap) continue;  // full-row fallback below
+                srow.resize((size_t)L0 + m);
+                sdist.resize((size_t)L0 + m);
+                for (int64_t j = 0; j < L0; ++j) {
+                    srow[(size_t)j] = (int32_t)(j + h->id_offset);
+                    sdist[(size_t)j] = dense[(size_t)b * L0p + j];
+                }
+                order.resize((size_t)m);
+                std::iota(order.begin(), order.end(), 0);
+                const int32_t* rr = m ? &cr[(size_t)b * mx] : nullptr;
+                const float* dd = m ? &cd[(size_t)b * mx] : nullptr;
+                std::sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return rr[x] < rr[y]; });
+                for (int j = 0; j < m; ++j) {
+                    srow[(size_t)L0 + j] = rr[order[(size_t)j]] + (int32_t)h->id_offset;
+                    sdist[(size_t)L0 + j] = dd[order[(size_t)j]];
+                }
+                const int64_t qi = flagged[f0 + b];
+                vs::select_topk_slots_sparse(srow.data(), sdist.data(), (int64_t)srow.size(), k, ids + qi * k, dists + qi * k);
             }
-            order.resize((size_t)m);
-            std::iota(order.begin(), order.end(), 0);
-            const int32_t* rr = m ? &cr[(size_t)b * mx] : nullptr;
-            const float* dd = m ? &cd[(size_t)b * mx] : nullptr;
-            std::sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return rr[x] < rr[y]; });
-            for (int j = 0; j < m; ++j) {
-                srow[(size_t)L0 + j] = rr[order[(size_t)j]] + (int32_t)h->id_offset;
-                sdist[(size_t)L0 + j] = dd[order[(size_t)j]];
+        };
+        const int n_thr = std::min(4, B / 4);
+        if (n_thr <= 1) {
+            replay(0, B);
+        } else {
+            std::vector<std::thread> pool;
+            std::atomic<bool> failed{false};
+            for (int t = 0; t < n_thr; ++t)
+                pool.emplace_back([&, t]() {
+                    try {
+                        replay(B * t / n_thr, B * (t + 1) / n_thr);
+                    } catch (...) {
+                        failed = true;
+                    }
+                });
+            for (auto& th : pool) th.join();
+            if (failed) {
+                set_error("out of host memory");
+                return VS_ERR_NOMEM;
             }
-            const int64_t qi = flagged[f0 + b];
-            vs::select_topk_slots_sparse(srow.data(), sdist.data(), (int64_t)srow.size(), k, ids + qi * k, dists + qi * k);
         }
         if (!overflow.empty()) {  // massive ties / duplicates: more rows under the bound than the candidate buffer holds
             if ((rc = resolve_dense_full(h, h->d_q, B, overflow, &flagged[f0], k, ids, dists))) return rc;
