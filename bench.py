@@ -311,16 +311,23 @@ def main():
         except pkg.VSearchError:
             bf.set_precision(1)
         else:
-            fp32_d, fp32_i = od.copy(), oi.copy()
+            # an extra, timed in its own steady state: regions of at least one full launch (S batches), whatever --steps
+            # says for the headline (20 batches are 5 passes of 4: the 8 waves of a workgroup cannot share them evenly)
+            steps8 = max(steps, S) if world == 1 else steps
             bf.prof_enable(not args.no_prof)
-            reg8 = timed(bf_step, steps, warmup)
+            reg8 = timed(bf_step, steps8, warmup)
             k8_ms, k8_n = bf.prof_read(0)
             bf.prof_enable(False)
             torch.cuda.synchronize()
-            assert np.array_equal(out_d.cpu().numpy(), fp32_d) and np.array_equal(out_i.cpu().numpy(), fp32_i), \
+            i8_d, i8_i = out_d.cpu().numpy().copy(), out_i.cpu().numpy().copy()
+            bf.set_precision(1)  # the same last call once more through the fp32 rows: the results must be the same bits
+            for i in range(steps8 - ((steps8 - 1) % S + 1), steps8):
+                bf_step(i, steps8)
+            torch.cuda.synchronize()
+            assert np.array_equal(out_d.cpu().numpy(), i8_d) and np.array_equal(out_i.cpu().numpy(), i8_i), \
                 "int8 path differs from the fp32 path"
             el8 = median(reg8)
-            k8_s = (k8_ms * 1e-3) / (warmup + len(reg8) * steps) * S if k8_n else 0.0
+            k8_s = (k8_ms * 1e-3) / (warmup + len(reg8) * steps8) * S if k8_n else 0.0
             # the wide scan serves VSEARCH_I8_WIDE / 2 batches of 32 queries per pass over the rows (default 4): its
             # algorithmic bytes per launch are one pass of u8 rows + i32 row terms per GROUP of batches
             bpp = max(1, int(os.environ.get("VSEARCH_I8_WIDE", "8")) // 2)
@@ -329,7 +336,7 @@ def main():
             b8_per_batch_unit = (rows_local * DIM + 4 * rows_local + 4 * BATCH * DIM + 8 * BATCH * K) * S
             int8_info = {"metric": "QPS, same workload, rows stored as u8 + int8 MFMA (bit-identical results); "
                                    f"{bpp} batches share one pass over the rows",
-                         "value": round(steps * BATCH / el8, 1), "ms_per_step": round(el8 / steps * 1e3, 5),
+                         "value": round(steps8 * BATCH / el8, 1), "ms_per_step": round(el8 / steps8 * 1e3, 5), "steps": steps8,
                          "kernel_us_per_launch": round(k8_s * 1e6, 1), "batches_per_launch": S, "batches_per_row_pass": bpp,
                          "roofline": {"bound": "hbm", "achieved": round(b8 / k8_s / 1e9, 1) if k8_s > 0 else None,
                                       "peak": HBM_PEAK_GBS, "unit": "GB/s",
