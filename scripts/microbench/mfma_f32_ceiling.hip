@@ -155,6 +155,86 @@ void runr(const char* name, float* out, const float* in, const float* base, int 
     }
 }
 
+// The ring shared by the workgroup: wave w fetches tile 8 j + w of group j into one half of the ring while
+// all eight waves compute on the other half (each on all eight tiles, for its own pass); one barrier per group.
+__global__ __launch_bounds__(512, 2) void krs(float* out, int groups, const float* in, const float* base, int n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    constexpr int kSlot = 8448;
+    f32x4 qf[4][8];
+#pragma unroll
+    for (int h = 0; h < 4; ++h)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) qf[h][c] = (f32x4){in[lane + c], in[lane + 8 + c], in[lane + h], 1.f};
+    unsigned voff[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int row_in = 2 * j + (lane >> 5);
+        voff[j] = (unsigned)(row_in * 512 + 16 * ((lane & 31) ^ row_in));
+    }
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem);
+    auto issue_tile = [&](int tile, int half) __attribute__((always_inline)) {
+        const unsigned dst = lds0 + (unsigned)((8 * half + wave) * kSlot);
+        const char* tb = reinterpret_cast<const char*>(base) + (size_t)tile * 8192;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            asm volatile("s_add_u32 m0, %0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt" ::"s"(dst), "v"(voff[j]), "s"(tb), "n"(j * 1024) : "memory", "scc");
+        asm volatile("s_add_u32 m0, %0, 8192\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" ::"s"(dst), "v"((unsigned)lane * 4u), "s"(tb) : "memory", "scc");
+    };
+    int tile = (int)blockIdx.x * 8 + wave;
+    issue_tile(tile % n_tiles, 0);
+    tile += 2048;
+    f32x4 tot = {0, 0, 0, 0};
+    unsigned fa[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) fa[c] = (unsigned)(r * 512 + (((4 * c + g) ^ r) << 4));
+    for (int grp = 0; grp < groups; ++grp) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        issue_tile(tile % n_tiles, (grp + 1) & 1);
+        tile += 2048;
+        const char* hb = smem + (grp & 1) * 8 * kSlot;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const char* src = hb + t * kSlot;
+            f32x4 a[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) a[c] = *reinterpret_cast<const f32x4*>(src + fa[c]);
+            const f32x4 bn = *reinterpret_cast<const f32x4*>(src + 8192 + 16 * g);
+            f32x4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][i], qf[h][c][i], acc[h], 0, 0, 0);
+            tot += acc[0] + acc[1] + acc[2] + acc[3] + bn;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    out[blockIdx.x * 512 + threadIdx.x] = tot[0] + tot[1] + tot[2] + tot[3];
+}
+
+void runs(const char* name, float* out, const float* in, const float* base, int n_tiles, int groups) {
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(krs), hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 8448);
+    for (int rep = 0; rep < 3; ++rep) {
+        (void)hipEventRecord(e0);
+        hipLaunchKernelGGL(krs, dim3(256), dim3(512), 16 * 8448, 0, out, groups, in, base, n_tiles);
+        (void)hipEventRecord(e1);
+        (void)hipEventSynchronize(e1);
+        float ms;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        const double flop = 256.0 * 8 * groups * 8 * 128 * 2048;
+        if (rep == 2)
+            printf("%-44s %8.1f us  %6.1f TFLOP/s  (%.3f of 157.3)  %.2f us per step and wave, %.2f TB/s from HBM\n", name, ms * 1e3,
+                   flop / (ms * 1e-3) / 1e12, flop / (ms * 1e-3) / 157.3e12, ms * 1e3 / (groups * 8), 256.0 * 8 * groups * 8256 / (ms * 1e-3) / 1e12);
+    }
+}
+
 template <int MODE>
 void run(const char* name, float* out, const float* in, int iters) {
     hipEvent_t e0, e1;
@@ -193,5 +273,6 @@ int main() {
     runr<1, 32>("ring + HBM refill, 2nd wave 32 MFMAs late", out, in, base, n_tiles, iters);
     runr<1, 64>("ring + HBM refill, 2nd wave 64 MFMAs late", out, in, base, n_tiles, iters);
     runr<1, 128>("ring + HBM refill, 2nd wave 128 MFMAs late", out, in, base, n_tiles, iters);
+    runs("ring shared by the workgroup, 1 barrier / 8 tiles", out, in, base, n_tiles, iters / 8);
     return 0;
 }
