@@ -527,7 +527,7 @@ def main():
 
                 # an extra, timed in its own steady state: regions of at least one full call (SI batches = four launch groups
                 # on the library's two streams), whatever --steps says for the headline (the driver's 20 steps would be one
-                # 20-batch group on one stream: half the rate, r02k_bench_driver_flags.json in profiles/)
+                # 20-batch group on one stream: half the rate, r02l_bench_driver_flags.json in profiles/)
                 isteps = max(steps, SI) if world == 1 else steps
                 ivf.prof_enable(True)
                 ireg = timed(ivf_step, isteps, warmup)
