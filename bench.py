@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--no-prof", action="store_true", help="do not time the scan kernel with HIP events")
     ap.add_argument("--no-int8", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip host_api / B=1 / nprobe=8 legs")
+    ap.add_argument("--only-b1", action="store_true", help="of the extras run only the B = 1 legs (quick check)")
     ap.add_argument("--kmeans-iters", type=int, default=20)
     ap.add_argument("--collective", default="auto", choices=["auto", "library", "torch"],
                     help="N > 1: RCCL all-gather inside libvsearch_hip.so (vs_comm_*) or torch.distributed's")
@@ -351,7 +352,7 @@ def main():
 
     # ---------------------------------------------------------------- host-buffer API (SURVEY 8(d)'s QPS definition)
     host_info = None
-    if world == 1 and not args.no_extras:
+    if world == 1 and not args.no_extras and not args.only_b1:
         nq_h = n_queries
         tm = pkg.Timing()
         bf.search(queries[:nq_h], K)  # pinned staging + tie scratch allocated here, not in the timed calls
@@ -375,7 +376,29 @@ def main():
         f1 = torch.zeros((32,), dtype=torch.int32, device=dev)
 
         def b1_leg(index, rows, tag):
-            # throughput: 32 single-query batches per call (each streams the base once: cpu_baseline's loop, one launch)
+            # (a) what a caller issuing one query at a time gets (cpu_baseline.cpp:222-254: one query per iteration):
+            #     ONE single-query call, synchronised -- call + launch + scan + in-kernel merge + sync on the host clock --
+            #     and the same launch's device time alone (HIP events around 64 back-to-back single-query calls)
+            lat = []
+            for i in range(80):
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                index.search_dev(q_dev.data_ptr() + i * DIM * 4, 1, K, o1_i.data_ptr(), o1_d.data_ptr(), f1.data_ptr(), sptr)
+                torch.cuda.synchronize()
+                lat.append(time.perf_counter() - t)
+            lat_us = median(lat[16:]) * 1e6
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            dev_us = []
+            for rep in range(3):
+                e0.record(stream)
+                for i in range(64):
+                    index.search_dev(q_dev.data_ptr() + i * DIM * 4, 1, K, o1_i.data_ptr(), o1_d.data_ptr(), f1.data_ptr(), sptr)
+                e1.record(stream)
+                torch.cuda.synchronize()
+                dev_us.append(e0.elapsed_time(e1) * 1e3 / 64)
+            call_us = median(dev_us)
+            # (b) many single-query batches handed over in one call (32 per launch; the launch shares passes over the rows
+            #     between batches, so this is NOT "each query streams the base once" and carries no HBM fraction)
             def step(i, n):
                 if i % 32 != 31 and i != n - 1:
                     return
@@ -385,20 +408,18 @@ def main():
             nst = 640
             reg = timed(step, nst, 64, repeats=3)
             us_q = median(reg) / nst * 1e6
-            # latency: one query per call, synchronised (launch + scan + merge + sync)
-            lat = []
-            for i in range(60):
-                torch.cuda.synchronize()
-                t = time.perf_counter()
-                index.search_dev(q_dev.data_ptr() + i * DIM * 4, 1, K, o1_i.data_ptr(), o1_d.data_ptr(), f1.data_ptr(), sptr)
-                torch.cuda.synchronize()
-                lat.append(time.perf_counter() - t)
-            lat_us = median(lat[10:]) * 1e6
             bytes_q = 4 * rows * DIM + 4 * rows + 4 * DIM + 8 * K
-            info = {"us_per_query": round(us_q, 2), "qps": round(1e6 / us_q, 1), "latency_us_single_call": round(lat_us, 1),
+            info = {"latency_us_single_call": round(lat_us, 1), "us_per_call_back_to_back": round(call_us, 2),
+                    "qps_single_calls_back_to_back": round(1e6 / call_us, 1),
                     "rows": rows, "batch": 1, "algorithmic_bytes_per_query": bytes_q,
-                    "hbm_frac": round(bytes_q / (us_q * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
-            log(f"{tag}: {us_q:.2f} us/query streamed ({info['qps']:.0f} QPS), {lat_us:.1f} us single-call latency")
+                    "hbm_frac": round(bytes_q / (call_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                    "hbm_frac_of_single_call_latency": round(bytes_q / (lat_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                    "us_per_query_32_per_launch": round(us_q, 2),
+                    "note": "hbm_frac = SURVEY 8(d) bytes of one query / device time of one single-query call (one launch: "
+                            "vs::scan_one_kernel) / 8 TB/s; latency_us_single_call adds the host's launch + synchronise"}
+            assert info["hbm_frac"] <= 1.0, info
+            log(f"{tag}: single call {lat_us:.1f} us on the host clock, {call_us:.2f} us per call back to back "
+                f"({info['hbm_frac']:.3f} of the HBM roof), {us_q:.2f} us/query at 32 single-query batches per launch")
             return info
 
         b1_info["sift1m_b1"] = b1_leg(bf, rows_local, "SIFT-1M B=1")
@@ -411,7 +432,7 @@ def main():
 
     # ---------------------------------------------------------------- UFIXED_POINT_8 score path (second half)
     q8_info = None
-    if world == 1 and not args.no_extras:
+    if world == 1 and not args.no_extras and not args.only_b1:
         try:
             in_s = float(queries.max()) / 255.0
             w_s = float(shard.max()) / 255.0

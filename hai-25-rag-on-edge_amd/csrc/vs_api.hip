@@ -42,6 +42,8 @@ constexpr int kMaxNprobe = 256;
 constexpr int kSlotWords = 32 * vs::kIvfSlots;  // per-batch slot minima of the IVF list scan (in the zeroed block)
 constexpr int kMaxLanes = 4;
 constexpr int kMaxMulti = 32;  // batches per persistent scan launch
+constexpr int kOneMaxBatches = 4;  // calls of fewer batches take one single-call scan launch per batch (fp32 rows)
+constexpr int kOneMaxQueries = 16;  // ... when a batch holds at most this many queries
 constexpr int kPairMinTiles = 96;   // tiles per workgroup and pass from which the fp32 streaming scan pairs batches
 constexpr int kIvfHostGroups = 4;  // launch groups per chunk of the host-buffer IVF call
 constexpr int64_t kIvfHostChunk = (int64_t)kIvfHostGroups * kMaxMulti * 32;
@@ -257,7 +259,9 @@ struct vs_index {
     double stage_ms[3] = {0, 0, 0};
 
     hipStream_t stream = nullptr;
-    hipEvent_t ev_busy = nullptr;  // recorded after every enqueue on a caller stream: the next call waits on it
+    hipEvent_t ev_busy = nullptr;  // a call on another stream than the previous call's waits for that stream through this event
+    hipStream_t last_stream = nullptr;
+    bool have_last = false;
     bool prof = false;
     ProfSlot prof_slot[2];
 };
@@ -479,6 +483,7 @@ int alloc_scratch(vs_index* h) {
             if ((rc = dev_alloc(&L.seed_wmin, (size_t)kMaxMulti * vs::kSeedWaves * 32))) return rc;
             if ((rc = dev_alloc(&L.tau0, (size_t)kMaxMulti * 32))) return rc;
             if ((rc = dev_alloc(&L.done, kMaxMulti))) return rc;
+            HIPCHK(hipMemset(L.done, 0, kMaxMulti * sizeof(int)));  // arrival counter of the single-call scan: 0 between launches
             if (h->kind == 0) {
                 if ((rc = dev_alloc(&L.part_d, part))) return rc;
                 if ((rc = dev_alloc(&L.part_i, part))) return rc;
@@ -674,6 +679,34 @@ int bf_launch(vs_index* h, vs_index::Lane& L, const float* q_dev, int nb, int B,
     // ticket per workgroup and write survivors to candidate lists -- no barrier, no workgroup merge, no per-batch prologue.
     const bool i8_seed = h->d_vecs_u8 && h->metric == VS_METRIC_L2 && g_seed_i8;
     const bool stream = seeded && g_stream && (use_u8 ? (g_i8_wide > 0 && i8_seed) : true);
+    if (!seeded && !use_u8 && nb < kOneMaxBatches && B <= kOneMaxQueries) {
+        // a short call on the fp32 rows: one launch per batch (lane lists, workgroup ranking, the last workgroup merges).
+        // Batches of more than 16 queries stay with the per-batch scan below: with two column blocks per tile the
+        // single-call kernel's lane lists cost more than that kernel's threshold exchange (measured at 1 M rows, B = 32:
+        // 154 us against 102 us; B <= 16: 88 - 97 us against 102 - 114 us)
+        for (int b = 0; b < nb; ++b) {
+            vs::OneParams op{};
+            op.base = h->d_vecs;
+            op.bnorm = h->d_norm;
+            op.n_rows = h->n_rows;
+            op.q = q_dev + (size_t)b * B * vs::kDim;
+            op.nq_valid = B;
+            op.k1 = k1;
+            op.metric = h->metric;
+            op.id_offset = (int32_t)h->id_offset;
+            op.part_d = L.part_d;
+            op.part_i = L.part_i;
+            op.done = L.done;
+            op.out_d = out_d + (size_t)b * B * k1;
+            op.out_i = out_i + (size_t)b * B * k1;
+            op.flags = flags ? flags + (size_t)b * B : nullptr;
+            op.dbg = g_dbg;
+            if (b == 0) prof_begin(h, 0, s);
+            HIPCHK(vs::launch_scan_one(op, vs::scan_one_grid(h->n_rows, h->num_cus), s));
+            if (b == nb - 1) prof_end(h, 0, s);
+        }
+        return VS_OK;
+    }
     if (seeded || use_u8) {
         int rc = ensure_wide(L);
         if (rc) return rc;
@@ -1360,17 +1393,19 @@ int guarded(F&& f) {
 // Calls on one index may arrive on different caller streams, but its scratch is one set: every enqueue waits for the
 // previous call's work (an event), so that two calls never overlap on the device.
 int order_begin(vs_index* h, hipStream_t s) {
-    if (!h->ev_busy) {
-        HIPCHK(hipEventCreateWithFlags(&h->ev_busy, hipEventDisableTiming));
-        return VS_OK;  // nothing enqueued yet
+    // Calls that stay on one stream are ordered by the stream itself: no event traffic (two runtime calls and two
+    // barrier packets per search call are what a single-query call's latency is made of).  A call on ANOTHER stream than
+    // the previous one waits for everything enqueued on that one so far.
+    if (!h->ev_busy) HIPCHK(hipEventCreateWithFlags(&h->ev_busy, hipEventDisableTiming));
+    if (h->have_last && h->last_stream != s) {
+        HIPCHK(hipEventRecord(h->ev_busy, h->last_stream));
+        HIPCHK(hipStreamWaitEvent(s, h->ev_busy, 0));
     }
-    HIPCHK(hipStreamWaitEvent(s, h->ev_busy, 0));
+    h->last_stream = s;  // (set here, not at the end: a call that fails half way has still enqueued work on s)
+    h->have_last = true;
     return VS_OK;
 }
-int order_end(vs_index* h, hipStream_t s) {
-    HIPCHK(hipEventRecord(h->ev_busy, s));
-    return VS_OK;
-}
+int order_end(vs_index*, hipStream_t) { return VS_OK; }
 
 int ensure_pipe(vs_index* h) {
     if (h->pipe[0].pin_q) return VS_OK;

@@ -166,6 +166,27 @@ struct StreamParams {
 };
 hipError_t launch_scan_f32_stream(const StreamParams& p, int grid, hipStream_t s);
 
+// Single-call scan (vs_scan_one.hip): one launch per batch of <= 32 queries, no seed launches, no merge launch -- a lane
+// keeps its own sorted lists, a workgroup ranks them into one partial list per query, the workgroup that arrives last
+// merges the partial lists.  fp32 rows; k1 <= 16.
+struct OneParams {
+    const float* base;       // [n_rows (+64)][128]
+    const float* bnorm;      // [n_rows + 64]
+    int64_t n_rows;
+    const float* q;          // [nq_valid][128] raw queries
+    int nq_valid, k1, metric;
+    int32_t id_offset;
+    float* part_d;           // scratch [32][grid][k1]
+    int32_t* part_i;
+    int32_t* done;           // [1] arrival counter: 0 at launch, left 0 by the last workgroup
+    float* out_d;            // [nq_valid][k1] ascending (dist, id), padded with (+inf, -1)
+    int32_t* out_i;
+    int32_t* flags;          // optional [nq_valid]: 1 = two equal distances among the k1
+    int* dbg;                // diagnostic builds (-DVS_STAMPS) only: time stamps [grid][16]
+};
+int scan_one_grid(int64_t n_rows, int num_cus);
+hipError_t launch_scan_one(const OneParams& p, int grid, hipStream_t s);
+
 // Cross-workgroup merge of sorted partial lists -> [nq][kout] + tie flags (+ seed thresholds).
 struct MergeParams {
     const float* part_d;     // [G][nq_stride][kin]

@@ -352,6 +352,19 @@ def test_sift1m_brute_force_exact(gpu_pkg):
         keep = fl.cpu().numpy() == 0
         assert keep.sum() >= 60
         assert np.array_equal(o_i.cpu().numpy()[keep, :5], oi[keep]) and np.array_equal(o_d.cpu().numpy()[keep, :5], od[keep])
+        # BASELINE.json config 2's shape at full size: one query per call (cpu_baseline.cpp:222 runs one query per
+        # iteration) -- the single-call scan, one launch each, back to back on one stream
+        o_d.fill_(-1.0)
+        o_i.fill_(-7)
+        fl.fill_(-7)
+        for i in range(12):
+            idx.search_dev(qd.data_ptr() + i * 128 * 4, 1, 5, o_i.data_ptr() + i * 6 * 4, o_d.data_ptr() + i * 6 * 4,
+                           fl.data_ptr() + i * 4, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        f = fl.cpu().numpy()[:12]
+        assert set(np.unique(f)) <= {0, 1}
+        assert np.array_equal(o_d.cpu().numpy()[:12, :5], od[:12])
+        assert np.array_equal(o_i.cpu().numpy()[:12][f == 0, :5], oi[:12][f == 0])
 
 
 def test_cli_no_arguments_reproduces_reference_run(gpu_pkg, golden_dir, tmp_path):
