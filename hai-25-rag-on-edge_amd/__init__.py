@@ -150,6 +150,7 @@ def lib():
         "vs_bf_search_sharded": (i32, [vp, vp, vp, i64, i32, vp, vp, C.POINTER(Timing)]),
         "vs_ivf_search_sharded": (i32, [vp, vp, vp, i64, i32, i32, vp, vp, C.POINTER(i64), C.POINTER(Timing)]),
         "vs_ivf_search_dev_sharded": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp]),
+        "vs_ivf_search_dev_vshards": (i32, [C.POINTER(vp), i32, vp, i32, i32, i32, i32, vp, vp, C.POINTER(C.c_double), vp]),
         "vs_q8_create": (i32, [vp, i64, i32, C.POINTER(Q8Encodings), i32, i64, C.POINTER(vp)]),
         "vs_q8_destroy": (None, [vp]),
         "vs_q8_num_docs": (i64, [vp]),
@@ -506,6 +507,17 @@ class IVFIndex(_Index):
                            dists_ptr: int, stream: int):
         """Collective: this rank's lists + ONE RCCL all-gather of top-k lists per launch group + device merge."""
         _check(lib().vs_ivf_search_dev_sharded(self._h, comm._c, q_ptr, n_batches, B, k, nprobe, ids_ptr, dists_ptr, stream))
+
+    @staticmethod
+    def search_dev_vshards(shards, q_ptr: int, n_batches: int, B: int, k: int, nprobe: int, ids_ptr: int, dists_ptr: int,
+                           stream: int, timed: bool = False):
+        """Virtual ranks (vs_ivf_search_dev_vshards): `shards[r]` = IVFIndex(..., rank=r, world=len(shards)) on one device.
+        Returns the per-rank device time in ms (front + back halves) when `timed`."""
+        G = len(shards)
+        arr = (C.c_void_p * G)(*[s._h for s in shards])
+        ms = (C.c_double * G)() if timed else None
+        _check(lib().vs_ivf_search_dev_vshards(arr, G, q_ptr, n_batches, B, k, nprobe, ids_ptr, dists_ptr, ms, stream))
+        return list(ms) if timed else None
 
 
 class Comm:

@@ -39,14 +39,15 @@ namespace {
 constexpr int kMaxEvents = 8192;
 constexpr int kKcapMax = 16;       // largest per-lane list the scan kernels are compiled for
 constexpr int kMaxNprobe = 256;
-constexpr int kSlotWords = 32 * vs::kIvfSlots;  // per-batch slot minima of the IVF list scan (in the zeroed block)
 constexpr int kMaxLanes = 4;
 constexpr int kMaxMulti = 32;  // batches per persistent scan launch
 constexpr int kOneMaxBatches = 4;  // calls of fewer batches take one single-call scan launch per batch (fp32 rows)
 constexpr int kOneMaxQueries = 16;  // ... when a batch holds at most this many queries
 constexpr int kPairMinTiles = 96;   // tiles per workgroup and pass from which the fp32 streaming scan pairs batches
-constexpr int kIvfHostGroups = 4;  // launch groups per chunk of the host-buffer IVF call
-constexpr int64_t kIvfHostChunk = (int64_t)kIvfHostGroups * kMaxMulti * 32;
+constexpr int kIvfGroupDefault = 32;  // batches per launch group of an unsharded IVF index (VSEARCH_IVF_GROUP)
+constexpr int kIvfGroupMax = 256;     // ... at most (8 super-batches of 32): also the group of an index sharded 8 ways
+constexpr int kIvfShardMaxWorld = 16; // ranks the cluster-sharded pipeline is compiled for (one super-batch per rank)
+constexpr int64_t kIvfHostChunk = 4 * 32 * 32;  // queries per chunk of the host-buffer IVF call (one upload, one download)
 constexpr int kWideLanesMax = 4;  // streams (and scratch sets) the launch groups of one wide IVF call may be dealt to
 constexpr int kWideWaveCap = 1024;  // entries per wave buffer of the wide int8 scan (expected fill: about 100 per launch)
 constexpr int kWideSub = 16;      // sub-lists per query of the streaming scans' candidate lists
@@ -142,7 +143,7 @@ struct vs_index {
     float* d_out_d = nullptr;    // [32][64]
     int32_t* d_out_i = nullptr;
     int32_t* d_flags = nullptr;  // [32]
-    float* d_scores = nullptr;   // IVF coarse [32][nlist_pad]; tie fallback rows
+    float* d_scores = nullptr;   // IVF query-major fallback: coarse scores [32][nlist_pad]; tie fallback rows
     int64_t scores_cap = 0;      // floats
     int32_t* d_probes = nullptr; // [32][kMaxNprobe]
     float* d_ipart_d = nullptr;  // [32][kMaxNprobe][16]
@@ -152,41 +153,17 @@ struct vs_index {
     int32_t* d_chunk_list = nullptr;   // [n_chunks] (list, 1024-row chunk) work items over the resident lists
     int32_t* d_chunk_row0 = nullptr;
     int32_t* d_chunk_rows = nullptr;
-    int32_t* d_units = nullptr;        // [n_units_max] per-batch work plan of the list scan (chunk * 32 + unit)
-    // further sets of the per-batch IVF scratch, VSEARCH_IVF_MULTI=0: batches are dealt to streams so that one batch's
-    // small latency-bound kernels (coarse + pick, bound, select) run beside the other batch's list scan
-    struct IvfScratch {
-        float* d_scores = nullptr;
-        int64_t scores_cap = 0;
-        int32_t* d_probes = nullptr;
-        float* d_ipart_d = nullptr;
-        int32_t* d_ipart_i = nullptr;
-        int32_t* d_lcnt = nullptr;
-        int32_t* d_gsel = nullptr;
-        unsigned* d_bins = nullptr;
-        int32_t* d_lq = nullptr;
-        long long* d_lbase = nullptr;
-        int32_t* d_qoff = nullptr;
-        float* d_candbuf = nullptr;
-        long long cand_stride = 0;
-        float* d_gcand_d = nullptr;
-        int32_t* d_gcand_p = nullptr;
-        int32_t* d_units = nullptr;
-    } ivf_alt[7];
-    int ivf_lanes = 0;  // streams set up by vs_ivf_search_dev_multi (0 = not yet)
-    // multi-batch launches (blockIdx.y = batch): kMaxMulti copies of the per-batch scratch, one slab per batch plus a
-    // small block per batch that is zeroed with one memset per group
-    char* mb_slab = nullptr;
-    int32_t* mb_zslab = nullptr;
-    long long mb_slab_stride = 0, mb_zslab_stride = 0, mb_cand_stride = 0;
-    int mb_nbk = 0;  // per-query score-block minima (32 scores per block) of the list scan
-    long long mb_off_lq = 0, mb_off_lbase = 0, mb_off_qoff = 0, mb_off_probes = 0, mb_off_gd = 0, mb_off_gp = 0, mb_off_units = 0,
-              mb_off_cand = 0, mb_off_scores = 0;
+    int ivf_gb = 32;                   // batches per launch group (multiple of 32) the wide pipeline's scratch is sized for
+    int ivf_nsb = 1;                   // ... in at most this many super-batches (sharded: one per rank)
+    int64_t ivf_host_cap = 0;          // queries per chunk the host-buffer call's staging slots hold
+    int32_t* vsh_blk = nullptr;        // virtual ranks (vs_ivf_search_dev_vshards): the gathered blocks / top-k lists, owned by shard 0
+    int32_t* vsh_loc = nullptr;
+    size_t vsh_loc_words = 0;
     // wide IVF pipeline (a launch group of up to 32 batches shares one list-major pass): slot tables, zeroed counters,
     // plans, bounds, prepared queries, candidate sink
     struct IvfWide {
-        int32_t* lq = nullptr;      // [n_sb][nlist][kIvfWideQ]
-        int32_t* zero = nullptr;    // one zeroed block per launch group: plan words (pair counters, record count) | slow [1024] | overflow (16) | list counters [16][1024]
+        int32_t* lq = nullptr;      // [ivf_nsb][nlist][kIvfWideQ]
+        int32_t* zero = nullptr;    // one zeroed block per launch group (see wide_zero)
         size_t zero_words = 0;
         int32_t* units = nullptr;   // [n_sb_max][units_cap][4]
         int units_cap = 0;
@@ -204,21 +181,9 @@ struct vs_index {
     } wide[kWideLanesMax];          // scratch sets: consecutive launch groups of one call run on different streams
     hipStream_t wide_stream[kWideLanesMax] = {};
     hipEvent_t wide_fork = nullptr, wide_join[kWideLanesMax] = {};
-    hipStream_t ivf_stream[8] = {};
-    hipEvent_t ivf_fork = nullptr, ivf_join[8] = {};
     int64_t n_units_max = 0;
     int n_chunks = 0;
     int32_t max_list = 0;              // longest resident list
-    int32_t* d_lcnt = nullptr;         // [nlist]
-    int32_t* d_lq = nullptr;           // [nlist][32]
-    long long* d_lbase = nullptr;      // [nlist][32]
-    int32_t* d_qoff = nullptr;         // [32][257]
-    unsigned* d_bins = nullptr;        // [32][16]
-    float* d_gcand_d = nullptr;        // [32][4096]
-    int32_t* d_gcand_p = nullptr;
-    int32_t* d_gsel = nullptr;         // [3][32]: gcnt, gdone, govf
-    float* d_candbuf = nullptr;        // [32][cand_stride]
-    long long cand_stride = 0;
     int max_grid = 0;
 
     // host-buffer API (vs_bf_search / vs_ivf_search): two slots of pinned staging + device I/O buffers, so that chunk
@@ -302,23 +267,10 @@ void free_all(vs_index* h) {
     void* ptrs[] = {h->d_vecs, h->d_norm, h->d_vecs_u8, h->d_rterm, h->d_seed_f32, h->d_seed_bnorm, h->d_seed_u8, h->d_seed_rterm, h->d_vecs_t8, h->d_nrh_t, h->d_rterm_t, h->d_r2o_t, h->d_tdelta, h->d_chunk_trow0, h->d_invalid, h->d_centroids, h->d_cnorm, h->d_offsets, h->d_r2o, h->d_q,
                     h->d_out_d, h->d_out_i,
                     h->d_flags, h->d_scores, h->d_probes, h->d_ipart_d, h->d_ipart_i, h->d_cand,
-                    h->d_chunk_list, h->d_chunk_row0, h->d_chunk_rows, h->d_lcnt, h->d_lq, h->d_lbase, h->d_qoff,
-                    h->d_candbuf, h->d_gcand_d, h->d_gcand_p, h->d_units};
+                    h->d_chunk_list, h->d_chunk_row0, h->d_chunk_rows, h->vsh_blk, h->vsh_loc};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     {
-        for (auto& s : h->ivf_alt) {
-            void* alt[] = {s.d_scores, s.d_probes, s.d_ipart_d, s.d_ipart_i, s.d_lcnt, s.d_lq, s.d_lbase, s.d_qoff, s.d_candbuf, s.d_gcand_d, s.d_gcand_p, s.d_units};
-            for (void* p : alt)
-                if (p) (void)hipFree(p);
-        }
-        for (int i = 0; i < 8; ++i) {
-            if (h->ivf_stream[i]) (void)hipStreamDestroy(h->ivf_stream[i]);
-            if (h->ivf_join[i]) (void)hipEventDestroy(h->ivf_join[i]);
-        }
-        if (h->ivf_fork) (void)hipEventDestroy(h->ivf_fork);
-        if (h->mb_slab) (void)hipFree(h->mb_slab);
-        if (h->mb_zslab) (void)hipFree(h->mb_zslab);
         for (auto& W : h->wide) {
             void* wd[] = {W.lq, W.zero, W.units, W.tau, W.qnorm, W.q8, W.qterm, W.wbuf, W.cand_d, W.cand_i, W.slab};
             for (void* w : wd)
@@ -393,7 +345,7 @@ void scan_geometry(int64_t rows, int num_cus, int& grid, int& tiles_per_wg, int 
     grid = std::max(grid, 1);
 }
 
-// per-batch scratch of the IVF search (one set per stream that runs batches)
+// scratch of the query-major IVF fallback (one batch at a time)
 int alloc_ivf_scratch(vs_index* h) {
     int rc;
     h->scores_cap = (int64_t)32 * ((h->nlist + 63) & ~63);
@@ -401,61 +353,6 @@ int alloc_ivf_scratch(vs_index* h) {
     if ((rc = dev_alloc(&h->d_probes, 32 * kMaxNprobe))) return rc;
     if ((rc = dev_alloc(&h->d_ipart_d, (size_t)32 * kMaxNprobe * kKcapMax))) return rc;
     if ((rc = dev_alloc(&h->d_ipart_i, (size_t)32 * kMaxNprobe * kKcapMax))) return rc;
-    // one zero-filled block per batch: [lcnt nlist][gsel 96][bins 512][plan_done, n_units]
-    if ((rc = dev_alloc(&h->d_lcnt, (size_t)h->nlist + 96 + 512 + 8 + kSlotWords))) return rc;
-    h->d_gsel = h->d_lcnt + h->nlist;
-    h->d_bins = reinterpret_cast<unsigned*>(h->d_lcnt + h->nlist + 96);
-    if ((rc = dev_alloc(&h->d_lq, (size_t)h->nlist * 32))) return rc;
-    if ((rc = dev_alloc(&h->d_lbase, (size_t)h->nlist * 32))) return rc;
-    if ((rc = dev_alloc(&h->d_qoff, (size_t)32 * (vs::kIvfMaxProbe + 1)))) return rc;
-    if ((rc = dev_alloc(&h->d_gcand_d, (size_t)32 * 4096))) return rc;
-    if ((rc = dev_alloc(&h->d_gcand_p, (size_t)32 * 4096))) return rc;
-    return VS_OK;
-}
-
-// exchange the index's per-batch IVF scratch with the alternate set (host pointers only: launches already
-// enqueued keep the addresses they were given)
-void swap_ivf_scratch(vs_index* h, int alt) {
-    auto& s = h->ivf_alt[alt];
-    std::swap(h->d_scores, s.d_scores);
-    std::swap(h->scores_cap, s.scores_cap);
-    std::swap(h->d_probes, s.d_probes);
-    std::swap(h->d_ipart_d, s.d_ipart_d);
-    std::swap(h->d_ipart_i, s.d_ipart_i);
-    std::swap(h->d_lcnt, s.d_lcnt);
-    std::swap(h->d_gsel, s.d_gsel);
-    std::swap(h->d_bins, s.d_bins);
-    std::swap(h->d_lq, s.d_lq);
-    std::swap(h->d_lbase, s.d_lbase);
-    std::swap(h->d_qoff, s.d_qoff);
-    std::swap(h->d_candbuf, s.d_candbuf);
-    std::swap(h->cand_stride, s.cand_stride);
-    std::swap(h->d_gcand_d, s.d_gcand_d);
-    std::swap(h->d_gcand_p, s.d_gcand_p);
-    std::swap(h->d_units, s.d_units);
-}
-
-// tuning knob (VSEARCH_IVF_LANES, 1..8): streams that vs_ivf_search_dev_multi deals the batches to
-int g_ivf_lanes = [] {
-    const char* e = getenv("VSEARCH_IVF_LANES");
-    return e ? std::max(1, std::min(8, atoi(e))) : 4;
-}();
-
-int ensure_ivf_alt(vs_index* h) {
-    if (h->ivf_lanes) return VS_OK;
-    for (int l = 1; l < g_ivf_lanes; ++l) {
-        swap_ivf_scratch(h, l - 1);  // the (empty) alternate set becomes current: allocate into it
-        int rc = alloc_ivf_scratch(h);
-        if (!rc && h->n_units_max > 0) rc = dev_alloc(&h->d_units, (size_t)h->n_units_max * 4);
-        swap_ivf_scratch(h, l - 1);
-        if (rc) return rc;
-    }
-    for (int i = 0; i < g_ivf_lanes; ++i) {
-        HIPCHK(hipStreamCreateWithFlags(&h->ivf_stream[i], hipStreamNonBlocking));
-        HIPCHK(hipEventCreateWithFlags(&h->ivf_join[i], hipEventDisableTiming));
-    }
-    HIPCHK(hipEventCreateWithFlags(&h->ivf_fork, hipEventDisableTiming));
-    h->ivf_lanes = g_ivf_lanes;
     return VS_OK;
 }
 
@@ -887,124 +784,38 @@ int scores_dev(vs_index* h, const float* vecs, const float* norms, int64_t rows,
     return VS_OK;
 }
 
-// tuning knob (VSEARCH_IVF_I8=0): the unit scan reads the fp32 rows even when the exact int8 copy exists
-int g_ivf_i8 = [] {
-    const char* e = getenv("VSEARCH_IVF_I8");
-    return e ? atoi(e) : 1;
+// tuning knob (VSEARCH_IVF_WIDE_LANES=1): vs_ivf_search_dev_multi keeps all launch groups of a call on the caller's stream
+// instead of alternating them between two streams
+int g_ivf_wide_lanes = [] {
+    const char* e = getenv("VSEARCH_IVF_WIDE_LANES");
+    return e ? std::max(1, std::min(kWideLanesMax, atoi(e))) : 2;
 }();
-// tuning knob (VSEARCH_IVF_PLAN=0): list-major scan without the per-batch work plan (one workgroup per chunk)
-int g_ivf_plan = [] {
-    const char* e = getenv("VSEARCH_IVF_PLAN");
-    return e ? atoi(e) : 1;
-}();
-// tuning knob (VSEARCH_IVF_GROUPED=0): fall back to the (query, probe)-major scan
-int g_ivf_grouped = [] {
-    const char* e = getenv("VSEARCH_IVF_GROUPED");
-    return e ? atoi(e) : 1;
-}();
+// tuning knob (VSEARCH_IVF_GROUP, read when an index is created): batches per launch group of an unsharded index
+// (multiple of 32, <= 256): every kernel of the pipeline is launched once per group
+int ivf_group_batches() {
+    const char* e = getenv("VSEARCH_IVF_GROUP");
+    const int v = e ? atoi(e) : kIvfGroupDefault;
+    return std::max(32, std::min(kIvfGroupMax, (v + 31) / 32 * 32));
+}
 
-int ivf_batch_dev(vs_index* h, const float* q_dev, int B, int k, int nprobe, float* out_d, int32_t* out_i,
-                  hipStream_t s, double* t_marks /*optional host marks*/) {
-    (void)t_marks;
+// Is the wide list-major pipeline available for this index?  (nlist <= 4096, rows resident, k <= 16; otherwise the
+// query-major fallback: coarse scores on the MFMA scan kernel, pick_probes, one workgroup per (query, probe).)
+bool ivf_wide_ok(const vs_index* h, int k) { return h->nlist <= vs::kIvfFastNlist && h->n_chunks > 0 && pick_kcap(k) != 0; }
+
+// Query-major fallback for one batch (nlist > 4096, or a shard without resident rows).
+int ivf_fallback_batch_dev(vs_index* h, const float* q_dev, int B, int k, int nprobe, float* out_d, int32_t* out_i, hipStream_t s) {
     const int kcap = pick_kcap(k);
     if (!kcap) {
         set_error("k too large for the compiled IVF kernels (k <= 16)");
         return VS_ERR_UNSUPPORTED;
     }
     const int64_t ld = (h->nlist + 63) & ~63;
-    const bool grouped = g_ivf_grouped && h->nlist <= vs::kIvfFastNlist && h->n_chunks > 0;
-    vs::IvfGroup grp{};
-    if (grouped) {
-        // candidate-score array: a query's probed lists back to back
-        const long long need = std::min<long long>(h->n_rows, (long long)nprobe * h->max_list);
-        const long long stride = (need + 63) & ~63ll;
-        if (h->cand_stride < stride) {
-            HIPCHK(hipStreamSynchronize(s));
-            if (h->d_candbuf) (void)hipFree(h->d_candbuf);
-            h->d_candbuf = nullptr;
-            h->cand_stride = 0;
-            int rc = dev_alloc(&h->d_candbuf, (size_t)32 * stride);
-            if (rc) return rc;
-            h->cand_stride = stride;
-        }
-        HIPCHK(hipMemsetAsync(h->d_lcnt, 0, ((size_t)h->nlist + 96 + 512 + 8 + kSlotWords) * sizeof(int32_t), s));
-        grp.offsets = h->d_offsets;
-        grp.lcnt = h->d_lcnt;
-        grp.lq = h->d_lq;
-        grp.lbase = h->d_lbase;
-        grp.qoff = h->d_qoff;
-        grp.cand_stride = h->cand_stride;
-        grp.cand_count = h->d_cand;
-        if (h->d_units && g_ivf_plan) {
-            grp.chunk_list = h->d_chunk_list;
-            grp.chunk_row0 = h->d_chunk_row0;
-            grp.chunk_rows = h->d_chunk_rows;
-            grp.n_chunks = h->n_chunks;
-            grp.plan_done = h->d_lcnt + h->nlist + 96 + 512;
-            grp.n_units = h->d_lcnt + h->nlist + 96 + 512 + 1;
-            grp.units = h->d_units;
-        }
-    }
     stage_mark(h, 0, s);
-    if (h->nlist <= vs::kIvfFastNlist) {
-        // coarse scores (MFMA) + deterministic top-nprobe (IVFIndex.cpp:654-666, :697-723), then the grouping tables
-        HIPCHK(vs::launch_ivf_coarse_pick(q_dev, B, h->d_centroids, h->d_cnorm, h->nlist, nprobe, h->metric, h->d_scores, (int)ld,
-                                          h->d_probes, grp, s));
-        stage_mark(h, 1, s);
-        HIPCHK(vs::launch_ivf_group_plan(h->d_probes, B, h->nlist, nprobe, grp, s));
-    } else {
-        // large nlist: Q x C^T + ||c||^2 epilogue on the MFMA scan kernel, then a selection launch
-        int rc = scores_dev(h, h->d_centroids, h->d_cnorm, h->nlist, q_dev, B, h->d_scores, ld, s);
-        if (rc) return rc;
-        HIPCHK(vs::launch_pick_probes(h->d_scores, ld, B, h->nlist, nprobe, h->d_probes, s));
-        stage_mark(h, 1, s);
-    }
+    int rc = scores_dev(h, h->d_centroids, h->d_cnorm, h->nlist, q_dev, B, h->d_scores, ld, s);
+    if (rc) return rc;
+    HIPCHK(vs::launch_pick_probes(h->d_scores, ld, B, h->nlist, nprobe, h->d_probes, s));
+    stage_mark(h, 1, s);
     stage_mark(h, 2, s);
-    if (grouped) {
-        vs::IvfListScanParams lp{};
-        lp.vecs = h->d_vecs;
-        lp.vnorm = h->d_norm;
-        if (h->d_vecs_u8 && g_ivf_i8) {
-            lp.vecs_u8 = h->d_vecs_u8;
-            lp.rterm = h->d_rterm;
-        }
-        lp.offsets = h->d_offsets;
-        lp.chunk_list = h->d_chunk_list;
-        lp.chunk_row0 = h->d_chunk_row0;
-        lp.chunk_rows = h->d_chunk_rows;
-        lp.q = q_dev;
-        lp.lcnt = h->d_lcnt;
-        lp.lq = h->d_lq;
-        lp.lbase = h->d_lbase;
-        lp.cand = h->d_candbuf;
-        if (grp.units) lp.slotmin = reinterpret_cast<unsigned*>(h->d_lcnt + h->nlist + 96 + 512 + 8);
-        lp.metric = h->metric;
-        prof_begin(h, 1, s);
-        if (grp.units) HIPCHK(vs::launch_ivf_unit_scan(lp, grp.units, grp.n_units, B, h->num_cus, s));
-        else HIPCHK(vs::launch_ivf_list_scan(lp, h->n_chunks, s));
-        prof_end(h, 1, s);
-        vs::IvfSelectParams sp{};
-        sp.cand = h->d_candbuf;
-        sp.cand_stride = h->cand_stride;
-        sp.qoff = h->d_qoff;
-        sp.probes = h->d_probes;
-        sp.offsets = h->d_offsets;
-        sp.id_map = h->d_r2o;
-        sp.tq = h->d_bins;
-        sp.slotmin = lp.slotmin;  // filled by the planned unit scan (else the bound kernel runs)
-        sp.gcand_d = h->d_gcand_d;
-        sp.gcand_p = h->d_gcand_p;
-        sp.gcnt = h->d_gsel;
-        sp.gdone = h->d_gsel + 32;
-        sp.govf = h->d_gsel + 64;
-        sp.nprobe = nprobe;
-        sp.k = k;
-        sp.out_d = out_d;
-        sp.out_i = out_i;
-        HIPCHK(vs::launch_ivf_select(sp, B, s));
-        stage_mark(h, 3, s);
-        return VS_OK;
-    }
     vs::IvfScanParams ip{};
     ip.vecs = h->d_vecs;
     ip.vnorm = h->d_norm;
@@ -1037,43 +848,16 @@ int ivf_batch_dev(vs_index* h, const float* q_dev, int B, int k, int nprobe, flo
     return VS_OK;
 }
 
-// tuning knob (VSEARCH_IVF_BUCKETS=0): multi-batch launches bound the selection by 64 slot minima per query instead of
-// per-block minima (the selection then reads every candidate score)
-int g_ivf_buckets = [] {
-    const char* e = getenv("VSEARCH_IVF_BUCKETS");
-    return e ? atoi(e) : 1;
-}();
-
-// tuning knob (VSEARCH_IVF_MULTI=0): vs_ivf_search_dev_multi deals batches to streams instead of launching every
-// kernel once for a whole group of batches
-int g_ivf_multi = [] {
-    const char* e = getenv("VSEARCH_IVF_MULTI");
-    return e ? atoi(e) : 1;
-}();
-
-int ensure_ivf_mb(vs_index* h, int nprobe, hipStream_t s);
-// tuning knob (VSEARCH_IVF_WIDE=0): launch groups use the per-batch list-major pipeline instead of the wide one
-// tuning knob (VSEARCH_IVF_WIDE_LANES=1): vs_ivf_search_dev_multi keeps all launch groups of a call on the caller's stream
-// instead of alternating them between two streams
-int g_ivf_wide_lanes = [] {
-    const char* e = getenv("VSEARCH_IVF_WIDE_LANES");
-    return e ? atoi(e) : 2;
-}();
-
-int g_ivf_wide = [] {
-    const char* e = getenv("VSEARCH_IVF_WIDE");
-    return e ? atoi(e) : 1;
-}();
-
+// Scratch of one lane of the wide pipeline, sized for launch groups of h->ivf_gb batches in up to h->ivf_nsb super-batches.
 int ensure_ivf_wide(vs_index* h, int lane) {
     vs_index::IvfWide& W = h->wide[lane];
     if (W.slab) return VS_OK;
     int rc;
-    const size_t nq = (size_t)kMaxMulti * 32;
-    const int n_sb_max = (kMaxMulti + vs::kIvfWideBatches - 1) / vs::kIvfWideBatches;
+    const size_t nq = (size_t)h->ivf_gb * 32;
+    const int n_sb_max = h->ivf_nsb;
     W.n_waves = 0;
     for (int n = 1; n <= n_sb_max; ++n) W.n_waves = std::max(W.n_waves, vs::ivf_wide_waves(h->num_cus, n));
-    W.zero_words = (size_t)n_sb_max * vs::ivf_wide_plan_words(h->nlist) + nq + 64 + nq * kWideSub;
+    W.zero_words = (size_t)n_sb_max * vs::ivf_wide_plan_words(h->nlist) + nq + 16 + h->ivf_gb + nq * kWideSub;
     if ((rc = dev_alloc(&W.lq, (size_t)n_sb_max * h->nlist * vs::kIvfWideQ))) return rc;
     if ((rc = dev_alloc(&W.zero, W.zero_words))) return rc;
     HIPCHK(hipMemset(W.zero, 0, W.zero_words * sizeof(int32_t)));
@@ -1088,55 +872,30 @@ int ensure_ivf_wide(vs_index* h, int lane) {
     if ((rc = dev_alloc(&W.cand_i, nq * kWideSub * kIvfWideSubCap))) return rc;
     W.off_scores = (32ll * kMaxNprobe * 4 + 255) & ~255ll;
     W.slab_stride = (W.off_scores + 32ll * ((h->nlist + 63) & ~63) * 4 + 255) & ~255ll;
-    if ((rc = dev_alloc(&W.slab, (size_t)W.slab_stride * kMaxMulti))) return rc;
+    if ((rc = dev_alloc(&W.slab, (size_t)W.slab_stride * h->ivf_gb))) return rc;
     return VS_OK;
 }
 
-// nb <= kMaxMulti independent batches (one launch group) through the wide pipeline on scratch lane `lane`: one memset,
-// coarse (MFMA, also prepares the byte queries) + pick (also fills the lists' slot tables), bounds and plan in one
-// launch, ONE list-major pass with candidates to the sink (binned by the scan's own waves), and the ranking launch
-// (merge, or the exact slow path for queries without a bound / for everybody if a candidate buffer overflowed).
-int ivf_group_wide_dev(vs_index* h, int lane, const float* q_dev, int nb, int B, int k, int nprobe, float* out_d, int32_t* out_i, hipStream_t s) {
-    int rc = ensure_ivf_wide(h, lane);
-    if (rc) return rc;
-    vs_index::IvfWide& W = h->wide[lane];
-    const size_t nq = (size_t)kMaxMulti * 32;
-    int32_t* const z_plan = W.zero;                                   // [n_sb_max][ivf_wide_plan_words]
-    const int n_sb_max = (kMaxMulti + vs::kIvfWideBatches - 1) / vs::kIvfWideBatches;
-    int32_t* const z_slow = z_plan + (size_t)n_sb_max * vs::ivf_wide_plan_words(h->nlist);  // [1024]
-    int32_t* const z_ovf = z_slow + nq;                               // [16]: word 0 = overflow
-    int32_t* const invalid = z_ovf + 16;                              // [32] batches with a query that is not byte valued
-    int32_t* const z_cnt = z_ovf + 64;                                // [1024][16]
-    // The zeroed block is left zeroed by the group's last kernel (ivf_wide_rank_kernel): a memset only after a call that
-    // did not get as far as that launch.
-    if (W.dirty) HIPCHK(hipMemsetAsync(W.zero, 0, W.zero_words * sizeof(int32_t), s));
-    W.dirty = true;
-    vs::IvfMulti mb{};
-    mb.slab = W.slab_stride;
-    mb.q = (long long)B * vs::kDim * sizeof(float);
-    char* sl = W.slab;
-    int32_t* probes = reinterpret_cast<int32_t*>(sl);
-    stage_mark(h, 0, s);
-    vs::IvfGroup grp{};
-    grp.offsets = h->d_offsets;
-    grp.lcnt = z_plan;  // (non-null: the pick kernel goes on to the grouping; its wide branch needs neither lcnt nor qoff)
-    grp.mb = mb;
-    // the coarse kernel also prepares the queries for the int8 paths, the pick kernel also fills the lists' slot tables
-    // (the candidate statistic is added up by the plan kernel: one atomic per launch instead of one per query)
-    grp.w_qnorm = W.qnorm;
-    grp.w_q8 = W.q8;
-    grp.w_qterm = W.qterm;
-    grp.w_invalid = invalid;
-    grp.w_overflow = z_ovf;
-    grp.w_cnt = z_plan;
-    grp.w_lq = W.lq;
-    grp.w_q = vs::kIvfWideQ;
-#ifdef VS_STAMPS
-    grp.dbg = g_dbg ? g_dbg + 4096 * 16 : nullptr;
-#endif
-    HIPCHK(vs::launch_ivf_coarse_pick(q_dev, B, h->d_centroids, h->d_cnorm, h->nlist, nprobe, h->metric,
-                                      reinterpret_cast<float*>(sl + W.off_scores), (h->nlist + 63) & ~63, probes, grp, s, nb));
-    stage_mark(h, 1, s);
+// The zeroed block of a lane: plan words per super-batch | slow [nq] | overflow (16) | invalid [batches] | list counters [16][nq]
+struct WideZero {
+    int32_t *plan, *slow, *ovf, *invalid, *cnt;
+};
+WideZero wide_zero(const vs_index* h, const vs_index::IvfWide& W) {
+    const size_t nq = (size_t)h->ivf_gb * 32;
+    WideZero z;
+    z.plan = W.zero;
+    z.slow = z.plan + (size_t)h->ivf_nsb * vs::ivf_wide_plan_words(h->nlist);
+    z.ovf = z.slow + nq;
+    z.invalid = z.ovf + 16;
+    z.cnt = z.invalid + h->ivf_gb;
+    return z;
+}
+
+// Parameters of the wide pipeline's kernels for a launch group of nb batches in super-batches of sbb.
+vs::IvfWideParams wide_params(vs_index* h, vs_index::IvfWide& W, const float* q_dev, int nb, int sbb, int B, int k, int nprobe,
+                              float* out_d, int32_t* out_i) {
+    const WideZero z = wide_zero(h, W);
+    const size_t nq = (size_t)h->ivf_gb * 32;
     vs::IvfWideParams wp{};
 #ifdef VS_STAMPS
     wp.dbg = g_dbg;
@@ -1144,15 +903,16 @@ int ivf_group_wide_dev(vs_index* h, int lane, const float* q_dev, int nb, int B,
 #endif
     wp.vecs = h->d_vecs;
     wp.vnorm = h->d_norm;
-    if (h->d_vecs_u8 && g_ivf_i8) {
+    if (h->d_vecs_u8 && h->precision != 1) {
         wp.vecs_u8 = h->d_vecs_u8;
         wp.rterm = h->d_rterm;
         wp.vecs_t8 = h->d_vecs_t8;
         wp.nrh_t = h->d_nrh_t;
         wp.rterm_t = h->d_rterm_t;
     }
-    wp.tdelta = h->d_tdelta;  // (null without a tiled copy: padded rows = rows)
-    wp.chunk_trow0 = h->d_chunk_trow0 ? h->d_chunk_trow0 : h->d_chunk_row0;
+    // (without the byte path the records and candidates are plain rows: no padded-row offsets)
+    wp.tdelta = wp.vecs_t8 ? h->d_tdelta : nullptr;
+    wp.chunk_trow0 = wp.vecs_t8 ? h->d_chunk_trow0 : h->d_chunk_row0;
     wp.offsets = h->d_offsets;
     wp.chunk_list = h->d_chunk_list;
     wp.chunk_row0 = h->d_chunk_row0;
@@ -1163,39 +923,66 @@ int ivf_group_wide_dev(vs_index* h, int lane, const float* q_dev, int nb, int B,
     wp.k = k;
     wp.metric = h->metric;
     wp.q = q_dev;
-    wp.q_batch_bytes = mb.q;
+    wp.q_batch_bytes = (long long)B * vs::kDim * sizeof(float);
     wp.n_batches = nb;
     wp.B = B;
+    wp.sb_batches = sbb;
     wp.qnorm = W.qnorm;
     wp.q8 = W.q8;
     wp.qterm = W.qterm;
-    wp.invalid = invalid;
-    wp.probes = probes;
-    wp.probes_batch_bytes = mb.slab;
+    wp.invalid = z.invalid;
+    wp.probes = reinterpret_cast<int32_t*>(W.slab);
+    wp.probes_batch_bytes = W.slab_stride;
     wp.lq = W.lq;
-    wp.zero = z_plan;
+    wp.zero = z.plan;
     wp.cand_count = h->d_cand;
     wp.units = W.units;
     wp.units_sb_stride = (long long)W.units_cap * 4;
     wp.units_cap = W.units_cap;
     wp.tau = W.tau;
-    wp.slow = z_slow;
+    wp.slow = z.slow;
     wp.sink.wbuf = W.wbuf;
     wp.sink.wcap = kIvfWideWaveCap;
-    wp.sink.overflow = z_ovf;
-    wp.sink.cnt = z_cnt;
+    wp.sink.overflow = z.ovf;
+    wp.sink.cnt = z.cnt;
     wp.sink.cand_d = W.cand_d;
     wp.sink.cand_i = W.cand_i;
     wp.sink.cap = kIvfWideSubCap;
     wp.sink.nsub = kWideSub;
-    wp.sink.slow = z_slow;
+    wp.sink.slow = z.slow;
     wp.sink.xcd_subs = kWideSub / 8;
     wp.sink.cnt_sub_stride = (int)nq;
     wp.out_d = out_d;
     wp.out_i = out_i;
     wp.id_map = h->d_r2o;
-    HIPCHK(vs::launch_ivf_wide_bounds_plan(wp, s));
-    stage_mark(h, 2, s);  // "gather" (IVFIndex.cpp's second stage) = bounds + plan here; the fine search is the scan + ranking
+    return wp;
+}
+
+vs::IvfGroup wide_group(vs_index* h, vs_index::IvfWide& W, int sbb, int B) {
+    const WideZero z = wide_zero(h, W);
+    vs::IvfGroup grp{};
+    grp.mb.slab = W.slab_stride;
+    grp.mb.probes = W.slab_stride;  // (the probes sit at the head of a batch's slab)
+    grp.mb.q = (long long)B * vs::kDim * sizeof(float);
+    grp.sb_batches = sbb;
+    grp.w_qnorm = W.qnorm;
+    grp.w_q8 = W.q8;
+    grp.w_qterm = W.qterm;
+    grp.w_invalid = z.invalid;
+    grp.w_overflow = z.ovf;
+    grp.w_cnt = z.plan;
+    grp.w_lq = W.lq;
+    grp.w_q = vs::kIvfWideQ;
+#ifdef VS_STAMPS
+    grp.dbg = g_dbg ? g_dbg + 4096 * 16 : nullptr;
+#endif
+    return grp;
+}
+
+// scan + rank of a launch group whose slot tables, bounds and plan are in place
+int wide_scan_rank(vs_index* h, vs_index::IvfWide& W, const vs::IvfWideParams& wp, hipStream_t s) {
+    const WideZero z = wide_zero(h, W);
+    const size_t nq = (size_t)h->ivf_gb * 32;
     prof_begin(h, 1, s);  // (the profiling window holds the scan kernel alone)
     HIPCHK(vs::launch_ivf_wide_scan(wp, h->num_cus, s));
     prof_end(h, 1, s);
@@ -1204,25 +991,116 @@ int ivf_group_wide_dev(vs_index* h, int lane, const float* q_dev, int nb, int B,
     m.part_i = W.cand_i;
     m.G = kWideSub;
     m.kin = kIvfWideSubCap;
-    m.nq = nb * B;
-    m.kout = k;
-    m.out_d = out_d;
-    m.out_i = out_i;
-    m.q_group_out = B;
+    m.nq = wp.n_batches * wp.B;
+    m.kout = wp.k;
+    m.out_d = wp.out_d;
+    m.out_i = wp.out_i;
+    m.q_group_out = wp.B;
     m.q_group_in = vs::kMaxBatch;
-    m.flat_len = z_cnt;
+    m.flat_len = z.cnt;
     m.flat_len_sub_stride = (int)nq;
-    m.id_map = h->d_r2o_t ? h->d_r2o_t : h->d_r2o;  // the scan's candidates are padded rows
+    m.id_map = (wp.vecs_t8 && h->d_r2o_t) ? h->d_r2o_t : h->d_r2o;  // the byte scan's candidates are padded rows
 #ifdef VS_STAMPS
     m.dbg = g_dbg ? g_dbg + 8192 * 16 : nullptr;
 #endif
     HIPCHK(vs::launch_ivf_wide_rank(m, kIvfWideSubCap, (int64_t)kWideSub * kIvfWideSubCap, wp, s));
+    return VS_OK;
+}
+
+// nb <= h->ivf_gb independent batches (one launch group) through the wide pipeline on scratch lane `lane`: coarse (MFMA,
+// also prepares the byte queries) + pick (also fills the lists' slot tables), bounds and plan in one launch, ONE list-major
+// pass per super-batch of 32 batches with candidates to the sink (binned by the scan's own waves), and the ranking launch
+// (merge, or the exact slow path for queries without a bound / for everybody if a candidate buffer overflowed).
+int ivf_group_wide_dev(vs_index* h, int lane, const float* q_dev, int nb, int B, int k, int nprobe, float* out_d, int32_t* out_i, hipStream_t s) {
+    int rc = ensure_ivf_wide(h, lane);
+    if (rc) return rc;
+    vs_index::IvfWide& W = h->wide[lane];
+    // The zeroed block is left zeroed by the group's last kernel (ivf_wide_rank_kernel): a memset only after a call that
+    // did not get as far as that launch.
+    if (W.dirty) HIPCHK(hipMemsetAsync(W.zero, 0, W.zero_words * sizeof(int32_t), s));
+    W.dirty = true;
+    const int sbb = vs::kIvfWideBatches;
+    const vs::IvfGroup grp = wide_group(h, W, sbb, B);
+    const vs::IvfWideParams wp = wide_params(h, W, q_dev, nb, sbb, B, k, nprobe, out_d, out_i);
+    stage_mark(h, 0, s);
+    HIPCHK(vs::launch_ivf_coarse_pick(q_dev, B, h->d_centroids, h->d_cnorm, h->nlist, nprobe, h->metric,
+                                      reinterpret_cast<float*>(W.slab + W.off_scores), (h->nlist + 63) & ~63,
+                                      reinterpret_cast<int32_t*>(W.slab), grp, s, nb));
+    stage_mark(h, 1, s);
+    HIPCHK(vs::launch_ivf_wide_bounds_plan(wp, s));
+    stage_mark(h, 2, s);  // "gather" (IVFIndex.cpp's second stage) = bounds + plan here; the fine search is the scan + ranking
+    if ((rc = wide_scan_rank(h, W, wp, s))) return rc;
 #ifdef VS_STAMPS
     W.dirty = (wp.diag & 128) != 0;
 #else
     W.dirty = false;
 #endif
     stage_mark(h, 3, s);
+    return VS_OK;
+}
+
+// ---- cluster-sharded pipeline (SURVEY 8e / BASELINE configs[4]).  A launch group is cut into `world` slices of sbb batches;
+// slice r's per-query stages (coarse scores, probe selection, bound) run on rank r ONLY, their output -- a block of
+// int32 words: probes [sbb * 32][nprobe] | tau [sbb * 32] | slow [sbb * 32] -- is exchanged (one all-gather), and every
+// rank then scans its resident lists for ALL slices (slice = super-batch of the list-major pass).  What a rank does
+// per launch group is therefore what an unsharded index does for ONE slice, except the ranking (all queries, an eighth of
+// the candidates each).
+long long ivf_block_words(int sbb, int nprobe) { return (long long)sbb * 32 * (nprobe + 2); }
+
+// front half on rank h->rank: prepares ALL queries of the group (bytes, terms, norms: the scan needs them for every
+// slice), scores its own slice [b0, b0 + nbs) and writes the slice's block to `blk`
+int ivf_shard_front(vs_index* h, int lane, const float* q_dev, int nb, int sbb, int b0, int nbs, int B, int k, int nprobe, int32_t* blk,
+                    hipStream_t s) {
+    int rc = ensure_ivf_wide(h, lane);
+    if (rc) return rc;
+    vs_index::IvfWide& W = h->wide[lane];
+    if (W.dirty) HIPCHK(hipMemsetAsync(W.zero, 0, W.zero_words * sizeof(int32_t), s));
+    W.dirty = true;
+    vs::IvfGroup grp = wide_group(h, W, sbb, B);
+    HIPCHK(vs::launch_ivf_prep_queries(q_dev, B, h->d_centroids, h->d_cnorm, h->nlist, grp, s, nb));
+    const long long sb_q = (long long)sbb * 32;
+    HIPCHK(hipMemsetAsync(blk + sb_q * nprobe + sb_q, 0, (size_t)sb_q * sizeof(int32_t), s));  // the slice's `slow` marks
+    if (nbs <= 0) return VS_OK;
+    // the slice's launches see their own batches only: every per-batch / per-query array is advanced to batch b0
+    const size_t q0 = (size_t)b0 * 32;
+    vs::IvfGroup fg = grp;
+    fg.w_qnorm = nullptr;
+    fg.w_q8 = nullptr;
+    fg.w_qterm = nullptr;
+    fg.w_invalid = nullptr;
+    fg.w_overflow = nullptr;
+    fg.w_cnt = nullptr;  // (slot tables are filled after the exchange, for all slices)
+    fg.w_lq = nullptr;
+    fg.mb.probes = (long long)32 * nprobe * sizeof(int32_t);
+    const float* qs = q_dev + (size_t)b0 * B * vs::kDim;
+    HIPCHK(vs::launch_ivf_coarse_pick(qs, B, h->d_centroids, h->d_cnorm, h->nlist, nprobe, h->metric,
+                                      reinterpret_cast<float*>(W.slab + W.off_scores), (h->nlist + 63) & ~63, blk, fg, s, nbs));
+    vs::IvfWideParams wp = wide_params(h, W, qs, nbs, sbb, B, k, nprobe, nullptr, nullptr);
+    wp.qnorm = W.qnorm + q0;
+    wp.q8 = W.q8 + q0 * vs::kDim;
+    wp.qterm = W.qterm + q0;
+    wp.invalid = wp.invalid + b0;
+    wp.probes = blk;
+    wp.probes_batch_bytes = fg.mb.probes;
+    wp.tau = reinterpret_cast<float*>(blk + sb_q * nprobe);
+    wp.slow = blk + sb_q * nprobe + sb_q;
+    HIPCHK(vs::launch_ivf_wide_bounds_plan(wp, s, 1));  // bounds only
+    return VS_OK;
+}
+
+// back half: slot tables for all slices from the exchanged blocks, plan, scan, rank -> this rank's top-k of every query
+int ivf_shard_back(vs_index* h, int lane, const float* q_dev, int nb, int sbb, int B, int k, int nprobe, const int32_t* gathered,
+                   float* out_d, int32_t* out_i, hipStream_t s) {
+    vs_index::IvfWide& W = h->wide[lane];
+    const WideZero z = wide_zero(h, W);
+    const vs::IvfGroup grp = wide_group(h, W, sbb, B);
+    const vs::IvfWideParams wp = wide_params(h, W, q_dev, nb, sbb, B, k, nprobe, out_d, out_i);
+    HIPCHK(vs::launch_ivf_fill(gathered, ivf_block_words(sbb, nprobe), B, nprobe, h->nlist, h->d_offsets, reinterpret_cast<int32_t*>(W.slab),
+                               W.tau, z.slow, grp, s, nb));
+    HIPCHK(vs::launch_ivf_wide_bounds_plan(wp, s, 2));  // plan only
+    int rc = wide_scan_rank(h, W, wp, s);
+    if (rc) return rc;
+    W.dirty = false;
     return VS_OK;
 }
 
@@ -1238,12 +1116,14 @@ int ensure_wide_streams(vs_index* h) {
 
 int ensure_ivf_host(vs_index* h) {
     int rc;
+    h->ivf_host_cap = std::max<int64_t>(kIvfHostChunk, (int64_t)h->ivf_gb * 32);
+    const size_t cap = (size_t)h->ivf_host_cap;
     for (auto& S : h->ihs)
         if (!S.pin_q) {
-            HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&S.pin_q), (size_t)kIvfHostChunk * vs::kDim * sizeof(float), hipHostMallocDefault));
-            HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&S.pin_out), (size_t)kIvfHostChunk * 64 * 2 * sizeof(float), hipHostMallocDefault));
-            if ((rc = dev_alloc(&S.d_q, (size_t)kIvfHostChunk * vs::kDim))) return rc;
-            if ((rc = dev_alloc(&S.d_out, (size_t)kIvfHostChunk * 64 * 2))) return rc;
+            HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&S.pin_q), cap * vs::kDim * sizeof(float), hipHostMallocDefault));
+            HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&S.pin_out), cap * 64 * 2 * sizeof(float), hipHostMallocDefault));
+            if ((rc = dev_alloc(&S.d_q, cap * vs::kDim))) return rc;
+            if ((rc = dev_alloc(&S.d_out, cap * 64 * 2))) return rc;
             HIPCHK(hipEventCreateWithFlags(&S.ev_h2d, hipEventDisableTiming));
             HIPCHK(hipEventCreateWithFlags(&S.ev_comp[0], hipEventDisableTiming));
             HIPCHK(hipEventCreateWithFlags(&S.ev_comp[1], hipEventDisableTiming));
@@ -1252,129 +1132,38 @@ int ensure_ivf_host(vs_index* h) {
     return VS_OK;
 }
 
-bool ivf_multi_ok(const vs_index* h, int k) {
-    return g_ivf_multi && g_ivf_grouped && g_ivf_plan && h->nlist <= vs::kIvfFastNlist && h->n_chunks > 0 && h->d_units && pick_kcap(k);
-}
-
-int ensure_ivf_mb(vs_index* h, int nprobe, hipStream_t s) {
-    const long long need = std::min<long long>(h->n_rows, (long long)nprobe * h->max_list);
-    const long long cstride = (need + 63) & ~63ll;
-    if (h->mb_slab && h->mb_cand_stride >= cstride) return VS_OK;
-    HIPCHK(hipStreamSynchronize(s));
-    if (h->mb_slab) (void)hipFree(h->mb_slab);
-    if (h->mb_zslab) (void)hipFree(h->mb_zslab);
-    h->mb_slab = nullptr;
-    h->mb_zslab = nullptr;
-    auto al = [](long long x) { return (x + 255) & ~255ll; };
-    long long off = 0;
-    h->mb_off_lq = off;      off = al(off + (long long)h->nlist * 32 * 4);
-    h->mb_off_lbase = off;   off = al(off + (long long)h->nlist * 32 * 8);
-    h->mb_off_qoff = off;    off = al(off + 32ll * (vs::kIvfMaxProbe + 1) * 4);
-    h->mb_off_probes = off;  off = al(off + 32ll * kMaxNprobe * 4);
-    h->mb_off_gd = off;      off = al(off + 32ll * 4096 * 4);
-    h->mb_off_gp = off;      off = al(off + 32ll * 4096 * 4);
-    h->mb_off_units = off;   off = al(off + std::max<long long>(h->n_units_max, 1) * 16);
-    h->mb_off_scores = off;  off = al(off + 32ll * ((h->nlist + 63) & ~63) * 4);
-    h->mb_off_cand = off;    off = al(off + 32ll * cstride * 4);
-    h->mb_slab_stride = off;
-    h->mb_nbk = (int)(cstride / 32 + 2);
-    h->mb_zslab_stride = (((long long)h->nlist + 96 + 512 + 8 + kSlotWords + 32ll * h->mb_nbk) + 63) & ~63ll;  // ints
-    h->mb_cand_stride = cstride;
-    HIPCHK(hipMalloc(reinterpret_cast<void**>(&h->mb_slab), (size_t)h->mb_slab_stride * kMaxMulti));
-    HIPCHK(hipMalloc(reinterpret_cast<void**>(&h->mb_zslab), (size_t)h->mb_zslab_stride * kMaxMulti * sizeof(int32_t)));
-    return VS_OK;
-}
-
-// nb <= kMaxMulti independent batches, every kernel launched once for all of them (blockIdx.y = batch)
-int ivf_group_dev(vs_index* h, const float* q_dev, int nb, int B, int k, int nprobe, float* out_d, int32_t* out_i, hipStream_t s) {
-    if (g_ivf_wide) return ivf_group_wide_dev(h, 0, q_dev, nb, B, k, nprobe, out_d, out_i, s);
-    int rc = ensure_ivf_mb(h, nprobe, s);
-    if (rc) return rc;
-    HIPCHK(hipMemsetAsync(h->mb_zslab, 0, (size_t)h->mb_zslab_stride * nb * sizeof(int32_t), s));
-    vs::IvfMulti mb{};
-    mb.slab = h->mb_slab_stride;
-    mb.zslab = h->mb_zslab_stride * (long long)sizeof(int32_t);
-    mb.q = (long long)B * vs::kDim * sizeof(float);
-    mb.out_d = (long long)B * k * sizeof(float);
-    mb.out_i = (long long)B * k * sizeof(int32_t);
-    int32_t* z = h->mb_zslab;
-    char* sl = h->mb_slab;
-    int32_t* probes = reinterpret_cast<int32_t*>(sl + h->mb_off_probes);
-    vs::IvfGroup grp{};
-    grp.offsets = h->d_offsets;
-    grp.lcnt = z;
-    grp.lq = reinterpret_cast<int32_t*>(sl + h->mb_off_lq);
-    grp.lbase = reinterpret_cast<long long*>(sl + h->mb_off_lbase);
-    grp.qoff = reinterpret_cast<int32_t*>(sl + h->mb_off_qoff);
-    grp.cand_stride = h->mb_cand_stride;
-    grp.cand_count = h->d_cand;
-    grp.chunk_list = h->d_chunk_list;
-    grp.chunk_row0 = h->d_chunk_row0;
-    grp.chunk_rows = h->d_chunk_rows;
-    grp.n_chunks = h->n_chunks;
-    grp.plan_done = z + h->nlist + 96 + 512;
-    grp.n_units = z + h->nlist + 96 + 512 + 1;
-    grp.units = reinterpret_cast<int32_t*>(sl + h->mb_off_units);
-    grp.mb = mb;
-    stage_mark(h, 0, s);
-    HIPCHK(vs::launch_ivf_coarse_pick(q_dev, B, h->d_centroids, h->d_cnorm, h->nlist, nprobe, h->metric,
-                                      reinterpret_cast<float*>(sl + h->mb_off_scores), (h->nlist + 63) & ~63, probes, grp, s, nb));
-    stage_mark(h, 1, s);
-    HIPCHK(vs::launch_ivf_group_plan(probes, B, h->nlist, nprobe, grp, s, nb));
-    stage_mark(h, 2, s);
-    vs::IvfListScanParams lp{};
-    lp.vecs = h->d_vecs;
-    lp.vnorm = h->d_norm;
-    if (h->d_vecs_u8 && g_ivf_i8) {
-        lp.vecs_u8 = h->d_vecs_u8;
-        lp.rterm = h->d_rterm;
+// nb batches on the device, any number: launch groups of h->ivf_gb batches, alternating between the lanes' streams when
+// there is more than one group (a group is a chain of dependent kernels, several of them small: the next group's small
+// kernels fill the device beside the current group's scan and ranking)
+int ivf_multi_dev(vs_index* h, const float* q_dev, int nb, int B, int k, int nprobe, float* out_d, int32_t* out_i, hipStream_t user) {
+    int rc = VS_OK;
+    if (!ivf_wide_ok(h, k)) {
+        for (int b = 0; b < nb && !rc; ++b)
+            rc = ivf_fallback_batch_dev(h, q_dev + (size_t)b * B * vs::kDim, B, k, nprobe, out_d + (size_t)b * B * k, out_i + (size_t)b * B * k, user);
+        return rc;
     }
-    lp.offsets = h->d_offsets;
-    lp.chunk_list = h->d_chunk_list;
-    lp.chunk_row0 = h->d_chunk_row0;
-    lp.chunk_rows = h->d_chunk_rows;
-    lp.q = q_dev;
-    lp.lcnt = grp.lcnt;
-    lp.lq = grp.lq;
-    lp.lbase = grp.lbase;
-    lp.cand = reinterpret_cast<float*>(sl + h->mb_off_cand);
-    lp.slotmin = reinterpret_cast<unsigned*>(z + h->nlist + 96 + 512 + 8);
-    if (g_ivf_buckets) {
-        lp.bkt = reinterpret_cast<unsigned*>(z + h->nlist + 96 + 512 + 8 + kSlotWords);
-        lp.nbk = h->mb_nbk;
-        lp.cand_stride = h->mb_cand_stride;
+    const int gb = h->ivf_gb;
+    const int groups = (nb + gb - 1) / gb;
+    const int lanes = std::min({g_ivf_wide_lanes, kWideLanesMax, groups});
+    if (lanes <= 1) {
+        for (int b0 = 0; b0 < nb && !rc; b0 += gb)
+            rc = ivf_group_wide_dev(h, 0, q_dev + (size_t)b0 * B * vs::kDim, std::min(gb, nb - b0), B, k, nprobe, out_d + (size_t)b0 * B * k,
+                                    out_i + (size_t)b0 * B * k, user);
+        return rc;
     }
-    lp.metric = h->metric;
-    lp.mb = mb;
-    prof_begin(h, 1, s);
-    HIPCHK(vs::launch_ivf_unit_scan(lp, grp.units, grp.n_units, B, h->num_cus, s, nb));
-    prof_end(h, 1, s);
-    vs::IvfSelectParams sp{};
-    sp.cand = lp.cand;
-    sp.cand_stride = h->mb_cand_stride;
-    sp.qoff = grp.qoff;
-    sp.probes = probes;
-    sp.offsets = h->d_offsets;
-    sp.id_map = h->d_r2o;
-    sp.tq = reinterpret_cast<unsigned*>(z + h->nlist + 96);
-    sp.slotmin = lp.slotmin;
-    sp.bkt = lp.bkt;
-    sp.nbk = lp.nbk;
-    sp.gcand_d = reinterpret_cast<float*>(sl + h->mb_off_gd);
-    sp.gcand_p = reinterpret_cast<int32_t*>(sl + h->mb_off_gp);
-    sp.gcnt = z + h->nlist;
-    sp.gdone = z + h->nlist + 32;
-    sp.govf = z + h->nlist + 64;
-    sp.nprobe = nprobe;
-    sp.k = k;
-    sp.out_d = out_d;
-    sp.out_i = out_i;
-    sp.mb = mb;
-    HIPCHK(vs::launch_ivf_select(sp, B, s, nb));
-    stage_mark(h, 3, s);
-    return VS_OK;
+    if ((rc = ensure_wide_streams(h))) return rc;
+    HIPCHK(hipEventRecord(h->wide_fork, user));
+    for (int i = 0; i < lanes; ++i) HIPCHK(hipStreamWaitEvent(h->wide_stream[i], h->wide_fork, 0));
+    int g = 0;
+    for (int b0 = 0; b0 < nb && !rc; b0 += gb, ++g)
+        rc = ivf_group_wide_dev(h, g % lanes, q_dev + (size_t)b0 * B * vs::kDim, std::min(gb, nb - b0), B, k, nprobe, out_d + (size_t)b0 * B * k,
+                                out_i + (size_t)b0 * B * k, h->wide_stream[g % lanes]);
+    for (int i = 0; i < lanes; ++i) {  // (also after an error: the user's stream must not run ahead of what was enqueued)
+        HIPCHK(hipEventRecord(h->wide_join[i], h->wide_stream[i]));
+        HIPCHK(hipStreamWaitEvent(user, h->wide_join[i], 0));
+    }
+    return rc;
 }
-
 
 // no C++ exception leaves the C ABI (vs_status instead)
 template <class F>
@@ -2065,7 +1854,6 @@ static int ivf_create_impl(const float* vectors, int64_t n_rows, int dim, const 
             if ((rc = dev_alloc(&h->d_chunk_rows, cl.size()))) return fail(rc);
             h->n_units_max = 0;
             for (int32_t r : crn) h->n_units_max += (r + 31) >> 5;
-            if ((rc = dev_alloc(&h->d_units, (size_t)std::max<int64_t>(h->n_units_max, 1) * 4))) return fail(rc);
             if ((e = hipMemcpy(h->d_chunk_list, cl.data(), cl.size() * 4, hipMemcpyHostToDevice)) != hipSuccess ||
                 (e = hipMemcpy(h->d_chunk_row0, cr0.data(), cl.size() * 4, hipMemcpyHostToDevice)) != hipSuccess ||
                 (e = hipMemcpy(h->d_chunk_rows, crn.data(), cl.size() * 4, hipMemcpyHostToDevice)) != hipSuccess) {
@@ -2075,7 +1863,11 @@ static int ivf_create_impl(const float* vectors, int64_t n_rows, int dim, const 
         }
     }
     if ((rc = alloc_scratch(h))) return fail(rc);
-    if (g_ivf_wide && g_ivf_multi && g_ivf_grouped && g_ivf_plan && h->nlist <= vs::kIvfFastNlist && h->n_chunks > 0) {
+    // launch groups: an unsharded index takes VSEARCH_IVF_GROUP batches per group (super-batches of 32); a sharded one a
+    // slice of up to 32 batches per rank (ivf_shard_front / ivf_shard_back)
+    h->ivf_gb = world > 1 ? std::min(kIvfGroupMax, 32 * std::min(world, kIvfShardMaxWorld)) : ivf_group_batches();
+    h->ivf_nsb = world > 1 ? std::max(h->ivf_gb / 32, std::min(world, kIvfShardMaxWorld)) : h->ivf_gb / 32;
+    if (h->nlist <= vs::kIvfFastNlist && h->n_chunks > 0) {
         // the wide pipeline's scratch (two lanes), streams and host staging now rather than inside the first search:
         // index load is outside every timed region, a first call that allocates 200 MB is not (the reference's harness
         // times every searchBatch call, main_ivf.cpp:157-163)
@@ -2408,7 +2200,7 @@ int vs_ivf_search_dev(vs_index* h, const float* queries_dev, int B, int k, int n
     if (rc) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if ((rc = order_begin(h, st))) return rc;
-    rc = ivf_batch_dev(h, queries_dev, B, k, nprobe, dists_dev, ids_dev, st, nullptr);
+    rc = ivf_multi_dev(h, queries_dev, 1, B, k, nprobe, dists_dev, ids_dev, st);
     return rc ? rc : order_end(h, st);
 }
 
@@ -2428,57 +2220,7 @@ int vs_ivf_search_dev_multi(vs_index* h, const float* queries_dev, int n_batches
     if (rc) return rc;
     hipStream_t user = static_cast<hipStream_t>(stream);
     if ((rc = order_begin(h, user))) return rc;
-    if (n_batches == 1 || g_ivf_lanes == 1) {
-        for (int b = 0; b < n_batches && !rc; ++b)
-            rc = ivf_batch_dev(h, queries_dev + (size_t)b * B * vs::kDim, B, k, nprobe, dists_dev + (size_t)b * B * k,
-                               ids_dev + (size_t)b * B * k, user, nullptr);
-        return rc ? rc : order_end(h, user);
-    }
-    if (ivf_multi_ok(h, k) && g_ivf_wide && g_ivf_wide_lanes > 1 && n_batches > kMaxMulti) {
-        // Launch groups of kMaxMulti batches are dealt to two (VSEARCH_IVF_WIDE_LANES) streams with a scratch set each: a group is a chain of
-        // dependent kernels, several of them small (coarse, pick, bounds + plan), and the next group's small kernels fill
-        // the device beside the current group's scan and ranking.
-        const int lanes = std::min({g_ivf_wide_lanes, kWideLanesMax, (n_batches + kMaxMulti - 1) / kMaxMulti});
-        if ((rc = ensure_wide_streams(h))) return rc;
-        HIPCHK(hipEventRecord(h->wide_fork, user));
-        for (int i = 0; i < lanes; ++i) HIPCHK(hipStreamWaitEvent(h->wide_stream[i], h->wide_fork, 0));
-        int g = 0;
-        for (int b0 = 0; b0 < n_batches && !rc; b0 += kMaxMulti, ++g) {
-            const int nb = std::min(kMaxMulti, n_batches - b0);
-            rc = ivf_group_wide_dev(h, g % lanes, queries_dev + (size_t)b0 * B * vs::kDim, nb, B, k, nprobe, dists_dev + (size_t)b0 * B * k,
-                                    ids_dev + (size_t)b0 * B * k, h->wide_stream[g % lanes]);
-        }
-        for (int i = 0; i < lanes; ++i) {  // (also after an error: the user's stream must not run ahead of what was enqueued)
-            HIPCHK(hipEventRecord(h->wide_join[i], h->wide_stream[i]));
-            HIPCHK(hipStreamWaitEvent(user, h->wide_join[i], 0));
-        }
-        return rc ? rc : order_end(h, user);
-    }
-    if (ivf_multi_ok(h, k)) {
-        // every kernel once per group of up to kMaxMulti batches
-        for (int b0 = 0; b0 < n_batches && !rc; b0 += kMaxMulti) {
-            const int nb = std::min(kMaxMulti, n_batches - b0);
-            rc = ivf_group_dev(h, queries_dev + (size_t)b0 * B * vs::kDim, nb, B, k, nprobe, dists_dev + (size_t)b0 * B * k,
-                               ids_dev + (size_t)b0 * B * k, user);
-        }
-        return rc ? rc : order_end(h, user);
-    }
-    if ((rc = ensure_ivf_alt(h))) return rc;
-    // the batches are independent: deal them round-robin to the streams (stream l > 0 uses scratch set l - 1)
-    const int lanes = h->ivf_lanes;
-    HIPCHK(hipEventRecord(h->ivf_fork, user));
-    for (int i = 0; i < lanes; ++i) HIPCHK(hipStreamWaitEvent(h->ivf_stream[i], h->ivf_fork, 0));
-    for (int b = 0; b < n_batches && !rc; ++b) {
-        const int lane = b % lanes;
-        if (lane) swap_ivf_scratch(h, lane - 1);
-        rc = ivf_batch_dev(h, queries_dev + (size_t)b * B * vs::kDim, B, k, nprobe, dists_dev + (size_t)b * B * k,
-                           ids_dev + (size_t)b * B * k, h->ivf_stream[lane], nullptr);
-        if (lane) swap_ivf_scratch(h, lane - 1);
-    }
-    for (int i = 0; i < lanes; ++i) {
-        HIPCHK(hipEventRecord(h->ivf_join[i], h->ivf_stream[i]));
-        HIPCHK(hipStreamWaitEvent(user, h->ivf_join[i], 0));
-    }
+    rc = ivf_multi_dev(h, queries_dev, n_batches, B, k, nprobe, dists_dev, ids_dev, user);
     return rc ? rc : order_end(h, user);
 }
 
@@ -2502,88 +2244,24 @@ int vs_ivf_search(vs_index* h, const float* queries_host, int64_t nq, int k, int
         if (rc) return rc;
         const double t_start = now_ms();
         vs_timing tm{};
-        if ((rc = ensure_pipe(h)) || (rc = order_begin(h, h->stream))) return rc;
+        if ((rc = ensure_pipe(h)) || (rc = ensure_wide_streams(h)) || (rc = ensure_ivf_host(h)) || (rc = order_begin(h, h->stream))) return rc;
         h->stage_on = true;
         h->stage_used = 0;
         HIPCHK(hipMemsetAsync(h->d_cand, 0, sizeof(unsigned long long), h->stream));
         const float inf = std::numeric_limits<float>::infinity();
-        // Queries go through in chunks of kMaxMulti batches: every kernel is launched once per chunk (the harness loop of
-        // main_ivf.cpp:150-214 collapsed into a call); a ragged tail batch gets its own launches.  Two chunks in flight,
-        // copies on their own streams (see vs_bf_search).
-        const bool multi = ivf_multi_ok(h, k);
-        if (multi && g_ivf_wide && nq > 0) {
-            // ---- wide pipeline: chunks of up to kIvfHostGroups launch groups, two in flight; a chunk is one upload, its
-            // groups on the two lanes, one download (the split below exists because the host, not the device, is the
-            // limit of this call: one hipMemcpyAsync costs about as much host time as a launch group's seven launches)
-            if ((rc = ensure_wide_streams(h)) || (rc = ensure_ivf_host(h))) return rc;
-            HIPCHK(hipEventRecord(h->wide_fork, h->stream));  // (behind the memset above)
-            for (int i = 0; i < 2; ++i) HIPCHK(hipStreamWaitEvent(h->wide_stream[i], h->wide_fork, 0));
-            const int64_t group_q = (int64_t)kMaxMulti * h->batch;
-            // at least two chunks per call where there is enough work, so that the second upload runs beside the first groups
-            const int64_t wchunk = std::min<int64_t>(kIvfHostChunk / 32 * h->batch, std::max<int64_t>(group_q, (nq / 2 + group_q - 1) / group_q * group_q));
-            int next_lane = 0;
-            auto enqueue_w = [&](vs_index::IvfHostSlot& S, int64_t q0, int64_t n) -> int {
-                const double t0 = now_ms();
-                S.q0 = q0;
-                S.n = n;
-                std::memcpy(S.pin_q, queries_host + q0 * vs::kDim, (size_t)n * vs::kDim * sizeof(float));
-                HIPCHK(hipMemcpyAsync(S.d_q, S.pin_q, (size_t)n * vs::kDim * sizeof(float), hipMemcpyHostToDevice, h->s_h2d));
-                HIPCHK(hipEventRecord(S.ev_h2d, h->s_h2d));
-                tm.h2d_ms += now_ms() - t0;
-                float* od = S.d_out;
-                int32_t* oi = reinterpret_cast<int32_t*>(S.d_out + (size_t)n * k);
-                bool used[2] = {false, false};
-                for (int64_t g0 = 0; g0 < n; g0 += group_q) {
-                    const int64_t gn = std::min<int64_t>(group_q, n - g0);
-                    const int full = (int)(gn / h->batch), rem = (int)(gn % h->batch);
-                    const int lane = next_lane;
-                    next_lane ^= 1;
-                    const hipStream_t cs = h->wide_stream[lane];
-                    if (!used[lane]) HIPCHK(hipStreamWaitEvent(cs, S.ev_h2d, 0));
-                    used[lane] = true;
-                    int r2 = VS_OK;
-                    if (full) r2 = ivf_group_wide_dev(h, lane, S.d_q + (size_t)g0 * vs::kDim, full, h->batch, k, nprobe, od + (size_t)g0 * k, oi + (size_t)g0 * k, cs);
-                    if (!r2 && rem) {  // the call's ragged tail: one more group of a single short batch
-                        const size_t o = (size_t)g0 + (size_t)full * h->batch;
-                        r2 = ivf_group_wide_dev(h, lane, S.d_q + o * vs::kDim, 1, rem, k, nprobe, od + o * k, oi + o * k, cs);
-                    }
-                    if (r2) return r2;
-                }
-                for (int lane = 0; lane < 2; ++lane)
-                    if (used[lane]) {
-                        HIPCHK(hipEventRecord(S.ev_comp[lane], h->wide_stream[lane]));
-                        HIPCHK(hipStreamWaitEvent(h->s_d2h, S.ev_comp[lane], 0));
-                    }
-                HIPCHK(hipMemcpyAsync(S.pin_out, S.d_out, (size_t)n * k * 2 * sizeof(float), hipMemcpyDeviceToHost, h->s_d2h));
-                HIPCHK(hipEventRecord(S.ev_d2h, h->s_d2h));
-                return VS_OK;
-            };
-            auto retire_w = [&](vs_index::IvfHostSlot& S) -> int {
-                if (S.q0 < 0) return VS_OK;
-                const double t0 = now_ms();
-                HIPCHK(hipEventSynchronize(S.ev_d2h));
-                tm.d2h_ms += now_ms() - t0;
-                const float* hd = S.pin_out;
-                const int32_t* hi = reinterpret_cast<const int32_t*>(S.pin_out + (size_t)S.n * k);
-                for (int64_t i = 0; i < S.n * k; ++i) {
-                    const int32_t id = hi[i];
-                    ids[S.q0 * k + i] = id;
-                    dists[S.q0 * k + i] = id >= 0 ? hd[i] : inf;
-                }
-                S.q0 = -1;
-                return VS_OK;
-            };
-            int c = 0;
-            for (int64_t q0 = 0; q0 < nq; q0 += wchunk, ++c) {
-                vs_index::IvfHostSlot& S = h->ihs[c & 1];
-                if ((rc = retire_w(S))) return rc;
-                if ((rc = enqueue_w(S, q0, std::min<int64_t>(wchunk, nq - q0)))) return rc;
-            }
-            if ((rc = retire_w(h->ihs[c & 1]))) return rc;
-            if ((rc = retire_w(h->ihs[(c + 1) & 1]))) return rc;
-        }
-        const int64_t chunk = (int64_t)(multi ? kMaxMulti : 1) * h->batch;
-        auto enqueue = [&](vs_index::PipeSlot& S, int64_t q0, int64_t n) -> int {
+        // Queries go through in chunks (the harness loop of main_ivf.cpp:150-214 collapsed into a call): a chunk is ONE
+        // upload, its launch groups dealt to the two lanes' streams, ONE download -- the host, not the device, is the limit
+        // of this call (a hipMemcpyAsync costs about as much host time as a launch group's five launches).  Two chunks in
+        // flight; at least two chunks per call where there is enough work, so that the second upload runs beside the
+        // first chunk's kernels.  A ragged tail batch gets a launch group of its own.
+        const bool wide = ivf_wide_ok(h, k);
+        HIPCHK(hipEventRecord(h->wide_fork, h->stream));  // (behind the memset above)
+        for (int i = 0; i < 2; ++i) HIPCHK(hipStreamWaitEvent(h->wide_stream[i], h->wide_fork, 0));
+        const int64_t group_q = (int64_t)h->ivf_gb * h->batch;
+        const int64_t cap_q = h->ivf_host_cap / group_q * group_q;  // (group_q <= ivf_gb * 32 <= the slots' capacity)
+        const int64_t wchunk = std::min<int64_t>(cap_q, std::max<int64_t>(group_q, (nq / 2 + group_q - 1) / group_q * group_q));
+        int next_lane = 0;
+        auto enqueue = [&](vs_index::IvfHostSlot& S, int64_t q0, int64_t n) -> int {
             const double t0 = now_ms();
             S.q0 = q0;
             S.n = n;
@@ -2591,57 +2269,74 @@ int vs_ivf_search(vs_index* h, const float* queries_host, int64_t nq, int k, int
             HIPCHK(hipMemcpyAsync(S.d_q, S.pin_q, (size_t)n * vs::kDim * sizeof(float), hipMemcpyHostToDevice, h->s_h2d));
             HIPCHK(hipEventRecord(S.ev_h2d, h->s_h2d));
             tm.h2d_ms += now_ms() - t0;
-            HIPCHK(hipStreamWaitEvent(h->stream, S.ev_h2d, 0));
-            const int full = (int)(n / h->batch), rem = (int)(n % h->batch);
-            int r2 = VS_OK;
-            if (full > 1) r2 = ivf_group_dev(h, S.d_q, full, h->batch, k, nprobe, S.d_out_d, S.d_out_i, h->stream);
-            else if (full == 1) r2 = ivf_batch_dev(h, S.d_q, h->batch, k, nprobe, S.d_out_d, S.d_out_i, h->stream, nullptr);
-            if (r2) return r2;
-            if (rem) {
-                const size_t o = (size_t)full * h->batch;
-                r2 = ivf_batch_dev(h, S.d_q + o * vs::kDim, rem, k, nprobe, S.d_out_d + o * k, S.d_out_i + o * k, h->stream, nullptr);
+            float* od = S.d_out;
+            int32_t* oi = reinterpret_cast<int32_t*>(S.d_out + (size_t)n * k);
+            bool used[2] = {false, false};
+            for (int64_t g0 = 0; g0 < n; g0 += group_q) {
+                const int64_t gn = std::min<int64_t>(group_q, n - g0);
+                const int full = (int)(gn / h->batch), rem = (int)(gn % h->batch);
+                const int lane = wide ? next_lane : 0;
+                next_lane ^= 1;
+                const hipStream_t cs = h->wide_stream[lane];
+                if (!used[lane]) HIPCHK(hipStreamWaitEvent(cs, S.ev_h2d, 0));
+                used[lane] = true;
+                int r2 = VS_OK;
+                auto run = [&](size_t o, int nb, int B) -> int {
+                    if (wide) return ivf_group_wide_dev(h, lane, S.d_q + o * vs::kDim, nb, B, k, nprobe, od + o * k, oi + o * k, cs);
+                    int r3 = VS_OK;
+                    for (int b = 0; b < nb && !r3; ++b)
+                        r3 = ivf_fallback_batch_dev(h, S.d_q + (o + (size_t)b * B) * vs::kDim, B, k, nprobe, od + (o + (size_t)b * B) * k,
+                                                    oi + (o + (size_t)b * B) * k, cs);
+                    return r3;
+                };
+                if (full) r2 = run((size_t)g0, full, h->batch);
+                if (!r2 && rem) r2 = run((size_t)g0 + (size_t)full * h->batch, 1, rem);  // the call's ragged tail
                 if (r2) return r2;
             }
-            HIPCHK(hipEventRecord(S.ev_comp, h->stream));
-            HIPCHK(hipStreamWaitEvent(h->s_d2h, S.ev_comp, 0));
-            float* hd = reinterpret_cast<float*>(S.pin_out);
-            int32_t* hi = reinterpret_cast<int32_t*>(S.pin_out) + (size_t)kMaxMulti * 32 * 64;
-            HIPCHK(hipMemcpyAsync(hd, S.d_out_d, (size_t)n * k * sizeof(float), hipMemcpyDeviceToHost, h->s_d2h));
-            HIPCHK(hipMemcpyAsync(hi, S.d_out_i, (size_t)n * k * sizeof(int32_t), hipMemcpyDeviceToHost, h->s_d2h));
+            for (int lane = 0; lane < 2; ++lane)
+                if (used[lane]) {
+                    HIPCHK(hipEventRecord(S.ev_comp[lane], h->wide_stream[lane]));
+                    HIPCHK(hipStreamWaitEvent(h->s_d2h, S.ev_comp[lane], 0));
+                }
+            HIPCHK(hipMemcpyAsync(S.pin_out, S.d_out, (size_t)n * k * 2 * sizeof(float), hipMemcpyDeviceToHost, h->s_d2h));
             HIPCHK(hipEventRecord(S.ev_d2h, h->s_d2h));
             return VS_OK;
         };
-        auto retire = [&](vs_index::PipeSlot& S) -> int {
+        auto retire = [&](vs_index::IvfHostSlot& S) -> int {
             if (S.q0 < 0) return VS_OK;
             const double t0 = now_ms();
             HIPCHK(hipEventSynchronize(S.ev_d2h));
             tm.d2h_ms += now_ms() - t0;
-            const float* hd = reinterpret_cast<const float*>(S.pin_out);
-            const int32_t* hi = reinterpret_cast<const int32_t*>(S.pin_out) + (size_t)kMaxMulti * 32 * 64;
-            for (int64_t b = 0; b < S.n; ++b)
-                for (int t = 0; t < k; ++t) {
-                    const int32_t id = hi[(size_t)b * k + t];
-                    ids[(S.q0 + b) * k + t] = id;
-                    dists[(S.q0 + b) * k + t] = id >= 0 ? hd[(size_t)b * k + t] : inf;
-                }
+            const float* hd = S.pin_out;
+            const int32_t* hi = reinterpret_cast<const int32_t*>(S.pin_out + (size_t)S.n * k);
+            for (int64_t i = 0; i < S.n * k; ++i) {
+                const int32_t id = hi[i];
+                ids[S.q0 * k + i] = id;
+                dists[S.q0 * k + i] = id >= 0 ? hd[i] : inf;
+            }
             S.q0 = -1;
             return VS_OK;
         };
+        for (auto& S : h->ihs) S.q0 = -1;  // (a call that failed half way may have left a chunk marked in flight)
         int c = 0;
-        for (int64_t q0 = 0; q0 < nq && !(multi && g_ivf_wide); q0 += chunk, ++c) {
-            vs_index::PipeSlot& S = h->pipe[c & 1];
+        for (int64_t q0 = 0; q0 < nq; q0 += wchunk, ++c) {
+            vs_index::IvfHostSlot& S = h->ihs[c & 1];
             if ((rc = retire(S))) return rc;
-            if ((rc = enqueue(S, q0, std::min<int64_t>(chunk, nq - q0)))) return rc;
+            if ((rc = enqueue(S, q0, std::min<int64_t>(wchunk, nq - q0)))) return rc;
         }
-        if ((rc = retire(h->pipe[c & 1]))) return rc;
-        if ((rc = retire(h->pipe[(c + 1) & 1]))) return rc;
+        if ((rc = retire(h->ihs[c & 1]))) return rc;
+        if ((rc = retire(h->ihs[(c + 1) & 1]))) return rc;
+        for (int i = 0; i < 2; ++i) {  // the index's stream continues behind the lanes
+            HIPCHK(hipEventRecord(h->wide_join[i], h->wide_stream[i]));
+            HIPCHK(hipStreamWaitEvent(h->stream, h->wide_join[i], 0));
+        }
         unsigned long long cand = 0;
         HIPCHK(hipMemcpyAsync(&cand, h->d_cand, sizeof(cand), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
         if (total_candidates) *total_candidates = (int64_t)cand;
         tm.total_ms = now_ms() - t_start;
         // SearchTiming split (IVFIndex.h:31-36): device time of the three stages from the events between their launches,
-        // summed over the call's launch groups (they run back to back on one stream; uploads and downloads overlap them)
+        // summed over the call's launch groups (uploads and downloads overlap them)
         for (int i = 0; i + 3 < h->stage_used; i += 4) {
             float ms[3] = {0, 0, 0};
             for (int j = 0; j < 3; ++j) (void)hipEventElapsedTime(&ms[j], h->stage_ev[i + j], h->stage_ev[i + j + 1]);
@@ -2662,15 +2357,15 @@ __attribute__((visibility("default"))) int vs_debug_ivf_wide_stats(vs_index* h, 
     if (!h || !h->wide[0].lq) return VS_ERR_INVALID;
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
-    const size_t nq = (size_t)kMaxMulti * 32;
-    const int n_sb_max = (kMaxMulti + vs::kIvfWideBatches - 1) / vs::kIvfWideBatches;
+    const size_t nq = (size_t)h->ivf_gb * 32;
+    const int n_sb_max = h->ivf_nsb;
     std::vector<int32_t> z(h->wide[0].zero_words);
     std::vector<float> tau(nq);
     HIPCHK(hipMemcpy(z.data(), h->wide[0].zero, z.size() * 4, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(tau.data(), h->wide[0].tau, nq * 4, hipMemcpyDeviceToHost));
     const int32_t* slow = z.data() + (size_t)n_sb_max * vs::ivf_wide_plan_words(h->nlist);
     const int32_t* ovf = slow + nq;
-    const int32_t* cnt = ovf + 64;
+    const int32_t* cnt = ovf + 16 + h->ivf_gb;
     int64_t nslow = 0, total = 0, maxw = 0, maxsub = 0, ninf = 0;
     for (size_t i = 0; i < nq; ++i) nslow += slow[i] != 0;
     for (size_t i = 0; i < nq; ++i) ninf += !(tau[i] < 3e38f);
@@ -2793,6 +2488,11 @@ struct vs_comm {
     int32_t* d_loc[2] = {};   // this rank's lists of one launch group: [dists n*kin][ids n*kin] as 32-bit words
     int32_t* d_gath[2] = {};  // [world] x the same
     size_t cap_words = 0;     // per-rank capacity of d_loc
+    // cluster-sharded IVF: the slices' blocks (probes | tau | slow) of one launch group, exchanged between its two halves
+    int32_t* d_blk[2] = {};   // this rank's block
+    int32_t* d_blkg[2] = {};  // [world] blocks
+    size_t blk_cap = 0;       // words per block
+    hipEvent_t ev_front[2] = {}, ev_probe[2] = {};
 };
 
 namespace {
@@ -2912,6 +2612,8 @@ int vs_comm_create(const void* unique_id, int rank, int world, int device, vs_co
     for (int i = 0; i < 2 && e == hipSuccess; ++i) {
         e = hipEventCreateWithFlags(&c->ev_scan[i], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_coll[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_front[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_probe[i], hipEventDisableTiming);
     }
     if (e != hipSuccess) {
         set_error(std::string("vs_comm_create: ") + hipGetErrorString(e));
@@ -2935,6 +2637,10 @@ void vs_comm_destroy(vs_comm* c) {
         if (c->d_gath[i]) (void)hipFree(c->d_gath[i]);
         if (c->ev_scan[i]) (void)hipEventDestroy(c->ev_scan[i]);
         if (c->ev_coll[i]) (void)hipEventDestroy(c->ev_coll[i]);
+        if (c->d_blk[i]) (void)hipFree(c->d_blk[i]);
+        if (c->d_blkg[i]) (void)hipFree(c->d_blkg[i]);
+        if (c->ev_front[i]) (void)hipEventDestroy(c->ev_front[i]);
+        if (c->ev_probe[i]) (void)hipEventDestroy(c->ev_probe[i]);
     }
     if (c->s_coll) (void)hipStreamDestroy(c->s_coll);
     delete c;
@@ -2978,24 +2684,193 @@ int vs_ivf_search_dev_sharded(vs_index* h, vs_comm* c, const float* queries_dev,
         set_error("the index was sharded for a different (rank, world) than the communicator's");
         return VS_ERR_INVALID;
     }
+    if (h->device != c->device) {
+        set_error("index and communicator live on different devices");
+        return VS_ERR_INVALID;
+    }
     int rc = set_device(h);
     if (rc) return rc;
     hipStream_t user = static_cast<hipStream_t>(stream);
     if ((rc = order_begin(h, user))) return rc;
-    const bool multi = ivf_multi_ok(h, k);
-    rc = sharded_groups(h, c, n_batches, B, k, k, ids_dev, dists_dev, nullptr, nullptr, user,
-                        [&](int b0, int nb, float* loc_d, int32_t* loc_i, hipStream_t s) -> int {
-                            const float* q = queries_dev + (size_t)b0 * B * vs::kDim;
-                            if (multi && nb > 1) return ivf_group_dev(h, q, nb, B, k, nprobe, loc_d, loc_i, s);
-                            int r2 = VS_OK;
-                            for (int b = 0; b < nb && !r2; ++b)
-                                r2 = ivf_batch_dev(h, q + (size_t)b * B * vs::kDim, B, k, nprobe, loc_d + (size_t)b * B * k,
-                                                   loc_i + (size_t)b * B * k, s, nullptr);
-                            return r2;
-                        });
-    return rc ? rc : order_end(h, user);
+    // The per-query stages can be cut by slice only where EVERY rank runs the wide pipeline (a rank without resident
+    // rows, or nlist > 4096, takes the query-major fallback): that is a property of the index, the same on all ranks,
+    // except for empty shards -- which only occur with fewer lists than ranks.
+    const bool sliced = c->world > 1 && c->world <= kIvfShardMaxWorld && h->nlist <= vs::kIvfFastNlist && h->nlist >= c->world;
+    if (!sliced) {
+        // every rank runs the whole pipeline on its own lists, one all-gather of top-k lists per launch group
+        rc = sharded_groups(h, c, n_batches, B, k, k, ids_dev, dists_dev, nullptr, nullptr, user,
+                            [&](int b0, int nb, float* loc_d, int32_t* loc_i, hipStream_t s) -> int {
+                                return ivf_multi_dev(h, queries_dev + (size_t)b0 * B * vs::kDim, nb, B, k, nprobe, loc_d, loc_i, s);
+                            });
+        return rc ? rc : order_end(h, user);
+    }
+    // ---- sliced pipeline: group g's front half (own slice), the exchange of the slices' blocks, its back half (all
+    // slices, own lists), the all-gather of top-k lists and their merge.  Software pipelined over the launch groups:
+    // the compute stream runs F(g), then B(g - 1); the collective stream P(g), then T(g - 1) -- the same order on every
+    // rank -- so that an exchange is in flight while the neighbouring group computes.  Group g uses lane g & 1.
+    const int world = c->world, gb = h->ivf_gb;
+    const size_t blk_words_max = (size_t)ivf_block_words(vs::kIvfWideBatches, kMaxNprobe);
+    if (c->blk_cap < blk_words_max) {
+        HIPCHK(hipDeviceSynchronize());
+        for (int i = 0; i < 2; ++i) {
+            if (c->d_blk[i]) (void)hipFree(c->d_blk[i]);
+            if (c->d_blkg[i]) (void)hipFree(c->d_blkg[i]);
+            c->d_blk[i] = c->d_blkg[i] = nullptr;
+        }
+        c->blk_cap = 0;
+        for (int i = 0; i < 2; ++i) {
+            if ((rc = dev_alloc(&c->d_blk[i], blk_words_max))) return rc;
+            if ((rc = dev_alloc(&c->d_blkg[i], blk_words_max * (size_t)world))) return rc;
+        }
+        c->blk_cap = blk_words_max;
+    }
+    if ((rc = comm_reserve(c, (size_t)2 * gb * 32 * k))) return rc;
+    struct Grp {
+        int b0, nb, sbb;
+    };
+    auto group_of = [&](int g) {
+        Grp G;
+        G.b0 = g * gb;
+        G.nb = std::min(gb, n_batches - G.b0);
+        G.sbb = (G.nb + world - 1) / world;  // batches per slice (<= 32)
+        return G;
+    };
+    const int n_groups = (n_batches + gb - 1) / gb;
+    auto back_and_gather = [&](int g) -> int {
+        const Grp G = group_of(g);
+        const int lane = g & 1;
+        const size_t n = (size_t)G.nb * B, words = 2 * n * k;
+        float* loc_d = reinterpret_cast<float*>(c->d_loc[lane]);
+        int32_t* loc_i = c->d_loc[lane] + n * k;
+        HIPCHK(hipStreamWaitEvent(user, c->ev_probe[lane], 0));
+        if (c->coll_used[lane]) HIPCHK(hipStreamWaitEvent(user, c->ev_coll[lane], 0));  // group g - 2's merge has read d_gath
+        int r2 = ivf_shard_back(h, lane, queries_dev + (size_t)G.b0 * B * vs::kDim, G.nb, G.sbb, B, k, nprobe, c->d_blkg[lane], loc_d, loc_i, user);
+        if (r2) return r2;
+        HIPCHK(hipEventRecord(c->ev_scan[lane], user));
+        HIPCHK(hipStreamWaitEvent(c->s_coll, c->ev_scan[lane], 0));
+        NCCLCHK(rccl().AllGather(c->d_loc[lane], c->d_gath[lane], words, ncclInt32, c->comm, c->s_coll));
+        vs::MergeParams m{};
+        m.part_d = reinterpret_cast<const float*>(c->d_gath[lane]);
+        m.part_i = c->d_gath[lane] + n * k;
+        m.G = world;
+        m.kin = k;
+        m.nq = (int)n;
+        m.kout = k;
+        m.out_d = dists_dev + (size_t)G.b0 * B * k;
+        m.out_i = ids_dev + (size_t)G.b0 * B * k;
+        HIPCHK(vs::launch_merge_layout(m, (int64_t)words, k, c->s_coll));
+        HIPCHK(hipEventRecord(c->ev_coll[lane], c->s_coll));
+        c->coll_used[lane] = true;
+        return VS_OK;
+    };
+    for (int g = 0; g < n_groups; ++g) {
+        const Grp G = group_of(g);
+        const int lane = g & 1;
+        const int sb0 = c->rank * G.sbb, nbs = std::max(0, std::min(G.sbb, G.nb - sb0));
+        // (lane's scratch and block buffers: group g - 2's back half is behind on this stream, its exchange was waited for there)
+        if ((rc = ivf_shard_front(h, lane, queries_dev + (size_t)G.b0 * B * vs::kDim, G.nb, G.sbb, sb0, nbs, B, k, nprobe, c->d_blk[lane], user)))
+            return rc;
+        HIPCHK(hipEventRecord(c->ev_front[lane], user));
+        HIPCHK(hipStreamWaitEvent(c->s_coll, c->ev_front[lane], 0));
+        NCCLCHK(rccl().AllGather(c->d_blk[lane], c->d_blkg[lane], (size_t)ivf_block_words(G.sbb, nprobe), ncclInt32, c->comm, c->s_coll));
+        HIPCHK(hipEventRecord(c->ev_probe[lane], c->s_coll));
+        if (g >= 1 && (rc = back_and_gather(g - 1))) return rc;
+    }
+    if ((rc = back_and_gather(n_groups - 1))) return rc;
+    for (int lane = 0; lane < 2; ++lane)
+        if (c->coll_used[lane]) HIPCHK(hipStreamWaitEvent(user, c->ev_coll[lane], 0));
+    return order_end(h, user);
 }
 
+// Virtual ranks: the cluster-sharded pipeline of vs_ivf_search_dev_sharded for G shards that live on ONE device, driven by
+// one thread, the two collectives replaced by writing every rank's block / top-k lists straight into the gathered
+// layout.  For tests (the sliced pipeline must reproduce the unsharded result) and for measuring what a rank of a G-way
+// job does per launch group on a single GPU: rank_ms[r] (optional) = device time of rank r's front + back halves.
+int vs_ivf_search_dev_vshards(vs_index* const* shards, int G, const float* queries_dev, int n_batches, int B, int k, int nprobe,
+                              int32_t* ids_dev, float* dists_dev, double* rank_ms, void* stream) {
+    if (!shards || G < 2 || G > kIvfShardMaxWorld || !queries_dev || !ids_dev || !dists_dev || n_batches < 1 || B < 1 || B > vs::kMaxBatch || k < 1 ||
+        nprobe < 1) {
+        set_error("vs_ivf_search_dev_vshards: bad arguments");
+        return VS_ERR_INVALID;
+    }
+    for (int r = 0; r < G; ++r)
+        if (!shards[r] || shards[r]->kind != 1 || shards[r]->world != G || shards[r]->rank != r || shards[r]->device != shards[0]->device ||
+            shards[r]->nlist != shards[0]->nlist || !ivf_wide_ok(shards[r], k)) {
+            set_error("vs_ivf_search_dev_vshards: shard r must be an IVF index created with (rank r, world G) on one device, rows resident, nlist <= 4096");
+            return VS_ERR_INVALID;
+        }
+    vs_index* h0 = shards[0];
+    nprobe = std::min(nprobe, h0->nlist);
+    if (nprobe > kMaxNprobe || !pick_kcap(k)) {
+        set_error("nprobe > 256 or k > 16 not supported");
+        return VS_ERR_UNSUPPORTED;
+    }
+    return guarded([&]() -> int {
+        int rc = set_device(h0);
+        if (rc) return rc;
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        for (int r = 0; r < G; ++r)
+            if ((rc = order_begin(shards[r], s))) return rc;
+        const int gb = h0->ivf_gb;
+        const size_t blk_max = (size_t)ivf_block_words(vs::kIvfWideBatches, kMaxNprobe);
+        const size_t loc_max = (size_t)2 * gb * 32 * k;
+        if (!h0->vsh_blk || h0->vsh_loc_words < loc_max * G) {
+            HIPCHK(hipStreamSynchronize(s));
+            if (h0->vsh_blk) (void)hipFree(h0->vsh_blk);
+            if (h0->vsh_loc) (void)hipFree(h0->vsh_loc);
+            h0->vsh_blk = h0->vsh_loc = nullptr;
+            if ((rc = dev_alloc(&h0->vsh_blk, blk_max * G)) || (rc = dev_alloc(&h0->vsh_loc, loc_max * G))) return rc;
+            h0->vsh_loc_words = loc_max * G;
+        }
+        std::vector<hipEvent_t> ev;
+        if (rank_ms) {
+            ev.resize((size_t)4 * G);
+            for (auto& e : ev) HIPCHK(hipEventCreate(&e));
+            for (int r = 0; r < G; ++r) rank_ms[r] = 0;
+        }
+        for (int b0 = 0; b0 < n_batches && !rc; b0 += gb) {
+            const int nb = std::min(gb, n_batches - b0), sbb = (nb + G - 1) / G;
+            const float* q = queries_dev + (size_t)b0 * B * vs::kDim;
+            const size_t n = (size_t)nb * B, words = 2 * n * k;
+            const long long bw = ivf_block_words(sbb, nprobe);
+            for (int r = 0; r < G && !rc; ++r) {
+                const int sb0 = r * sbb, nbs = std::max(0, std::min(sbb, nb - sb0));
+                if (rank_ms) HIPCHK(hipEventRecord(ev[4 * r], s));
+                rc = ivf_shard_front(shards[r], 0, q, nb, sbb, sb0, nbs, B, k, nprobe, h0->vsh_blk + (size_t)r * bw, s);
+                if (rank_ms) HIPCHK(hipEventRecord(ev[4 * r + 1], s));
+            }
+            for (int r = 0; r < G && !rc; ++r) {
+                float* loc_d = reinterpret_cast<float*>(h0->vsh_loc + (size_t)r * words);
+                int32_t* loc_i = h0->vsh_loc + (size_t)r * words + n * k;
+                if (rank_ms) HIPCHK(hipEventRecord(ev[4 * r + 2], s));
+                rc = ivf_shard_back(shards[r], 0, q, nb, sbb, B, k, nprobe, h0->vsh_blk, loc_d, loc_i, s);
+                if (rank_ms) HIPCHK(hipEventRecord(ev[4 * r + 3], s));
+            }
+            if (rc) break;
+            vs::MergeParams m{};
+            m.part_d = reinterpret_cast<const float*>(h0->vsh_loc);
+            m.part_i = h0->vsh_loc + n * k;
+            m.G = G;
+            m.kin = k;
+            m.nq = (int)n;
+            m.kout = k;
+            m.out_d = dists_dev + (size_t)b0 * B * k;
+            m.out_i = ids_dev + (size_t)b0 * B * k;
+            HIPCHK(vs::launch_merge_layout(m, (int64_t)words, k, s));
+            if (rank_ms) {
+                HIPCHK(hipStreamSynchronize(s));
+                for (int r = 0; r < G; ++r) {
+                    float a = 0, b = 0;
+                    HIPCHK(hipEventElapsedTime(&a, ev[4 * r], ev[4 * r + 1]));
+                    HIPCHK(hipEventElapsedTime(&b, ev[4 * r + 2], ev[4 * r + 3]));
+                    rank_ms[r] += a + b;
+                }
+            }
+        }
+        for (auto& e : ev) (void)hipEventDestroy(e);
+        return rc;
+    });
+}
 
 // Host-buffer forms of the sharded searches (what the CLIs call with --gpus N): every rank passes the same queries and
 // receives the same merged result.  Chunks of kMaxMulti batches: upload, vs_*_search_dev_sharded, download.

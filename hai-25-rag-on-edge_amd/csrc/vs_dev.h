@@ -141,6 +141,18 @@ __device__ __forceinline__ void wave_rank_emit(const float* cd, const int* ci, i
     if (flag && lane == 0) *flag = tie;
 }
 
+// partial sums across lanes 1, 2 and 8 apart (DPP: no LDS round trip)
+__device__ __forceinline__ float dpp_add_xor1(float x) {
+    return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float dpp_add_xor2(float x) {
+    return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float dpp_add_half_mirror(float x) {
+    return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, true));
+}
+
+// wave-resident sorted list: lane j (< KCAP <= 16) holds entry j
 // order-preserving map float -> unsigned (for integer min/max on distances of either sign)
 __device__ __forceinline__ unsigned f32_ordered(float x) {
     const unsigned b = __builtin_bit_cast(unsigned, x);
@@ -152,3 +164,20 @@ __device__ __forceinline__ float f32_unordered(unsigned u) {
 }
 
 }  // namespace vs
+
+// time stamps of diagnostic builds (-DVS_STAMPS): p.dbg[workgroup][16]
+#ifdef VS_STAMPS
+#define VS_STAMP(i)                                                                                    \
+    do {                                                                                               \
+        if (p.dbg && threadIdx.x == 0)                                                                 \
+            p.dbg[blockIdx.x * 16 + (i)] = (int)(__builtin_amdgcn_s_memrealtime() & 0x7fffffff);       \
+    } while (0)
+#define VS_STAMPC(i)                                                                                   \
+    do {                                                                                               \
+        if (p.dbg && threadIdx.x == 0)                                                                 \
+            p.dbg[blockIdx.x * 16 + (i)] = (int)(__builtin_amdgcn_s_memtime() & 0x7fffffff);           \
+    } while (0)
+#else
+#define VS_STAMP(i)
+#define VS_STAMPC(i)
+#endif

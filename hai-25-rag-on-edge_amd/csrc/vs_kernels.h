@@ -235,44 +235,27 @@ hipError_t launch_pick_probes(const float* scores, int64_t ld, int B, int nlist,
 
 constexpr int kIvfMaxProbe = 256;
 
-// Multi-batch IVF launches: blockIdx.y = batch.  Every per-batch pointer of the parameter structs below points at
-// batch 0's copy; batch y's copy lies `slab` bytes (scratch written and read per batch), `zslab` bytes (the block
-// that is zeroed per batch: list counters, selection counters, plan counters), `q` bytes (queries) or `out` bytes
-// (results) further on.  All zero = single-batch launch.
+// Multi-batch IVF launches: blockIdx.y = batch.  Per-batch pointers point at batch 0's copy; batch y's coarse scores lie
+// y * slab bytes, its probes y * probes bytes, its queries y * q bytes further on.
 struct IvfMulti {
-    long long slab, zslab, q, out_d, out_i;
+    long long slab, probes, q;
 };
 
-// Grouping tables of the list-major IVF scan, filled by the coarse/pick kernel (all optional: lcnt == nullptr = off)
+// What the coarse / pick kernels of the wide pipeline do beside scores and probes (every pointer optional)
 struct IvfGroup {
-    const int32_t* offsets;          // [nlist+1] local list offsets
-    int32_t* lcnt;                   // [nlist] queries probing each list in this batch (pre-set to 0)
-    int32_t* lq;                     // [nlist][32] their query indices
-    long long* lbase;                // [nlist][32] where that (query, probe) window starts in the candidate array
-    int32_t* qoff;                   // [B][kIvfMaxProbe+1] window offsets per query, probe order; last = total
-    long long cand_stride;           // floats per query in the candidate array
-    unsigned long long* cand_count;  // += rows scanned (IVFIndex::searchBatch return value)
-    // work plan of the list scan, written by the last query's workgroup: the 32-row units of every chunk whose
-    // list is probed by some query of the batch, as chunk * 32 + unit (units == nullptr = no plan)
-    const int32_t* chunk_list;       // [n_chunks]
-    const int32_t* chunk_row0;       // [n_chunks]
-    const int32_t* chunk_rows;       // [n_chunks]
-    int n_chunks;
-    int32_t* plan_done;              // arrival counter (pre-set to 0)
-    int32_t* units;                  // [sum ceil(chunk_rows / 32)][4]: first row, chunk end row, list | queries << 16, list start
-    int32_t* n_units;                // [1]
-    IvfMulti mb;
-    // wide pipeline (one list-major pass per launch group): the coarse kernel also prepares the queries for the int8
-    // paths (block x = 0 of every batch), the pick kernel also enters every (query, probe) pair in its list's slot table
-    float* w_qnorm;                  // [n_batches][32] ||q||^2 (nullptr = not the wide pipeline)
+    IvfMulti mb;                     // batch y's slab (coarse scores, probes) lies mb.slab bytes, its queries mb.q bytes further on
+    int sb_batches;                  // batches per super-batch (<= kIvfWideBatches)
+    // the coarse kernel also prepares the queries for the int8 paths (block x = 0 of every batch)
+    float* w_qnorm;                  // [n_batches][32] ||q||^2
     int8_t* w_q8;                    // [n_batches][32][128] queries as bytes (x - 128)
     int32_t* w_qterm;                // [n_batches][32]
-    int32_t* w_invalid;              // [n_batches] (pre-set to 0): a query of the batch is not byte valued
-    int32_t* w_cnt;                  // [nlist] (pre-set to 0) queries of the GROUP probing each list
-    int32_t* w_lq;                   // [nlist][w_q] their slots (batch * 32 + q)
+    int32_t* w_invalid;              // [n_batches]: a query of the batch is not byte valued (written as 0 or 1)
+    int32_t* w_overflow;             // [1]: cleared (the wide pipeline's candidate-buffer overflow word)
+    // the pick kernel also enters every (query, probe) pair in its list's slot table
+    int32_t* w_cnt;                  // [n_sb][ivf_wide_plan_words] pair counters (pre-set to 0), list c's at word c * kIvfWideCntStride
+    int32_t* w_lq;                   // [n_sb][nlist][w_q] slots: 128 * (slot of the query in its super-batch)
     int w_q;
-    int32_t* w_overflow;      // optional [1]: cleared by the coarse kernel (the wide pipeline's candidate-buffer overflow word)
-    int32_t* dbg;             // diagnostic builds (-DVS_STAMPS) only: time stamps of the pick kernel
+    int32_t* dbg;                    // diagnostic builds (-DVS_STAMPS) only: time stamps of the pick kernel
 };
 
 // Coarse stage: Q x C^T + L2 epilogue on MFMA into scores [n_batches][32][ld] (ld >= nlist rounded up to 64; batch y's
@@ -281,68 +264,16 @@ constexpr int kIvfFastNlist = 4096;
 hipError_t launch_ivf_coarse_pick(const float* q, int B, const float* cents, const float* cnorm, int nlist, int nprobe,
                                   int metric, float* scores, int ld, int32_t* probes, const IvfGroup& grp, hipStream_t s,
                                   int n_batches = 1);
-// ... followed by the grouping + work-plan kernel (one workgroup per batch; no-op when grp.lcnt == nullptr)
-hipError_t launch_ivf_group_plan(const int32_t* probes, int B, int nlist, int nprobe, const IvfGroup& grp, hipStream_t s,
-                                 int n_batches = 1);
-
-struct IvfListScanParams {
-    const float* vecs;        // [n_rows][128] cluster-reordered
-    const float* vnorm;       // [n_rows]
-    const int8_t* vecs_u8;    // optional exact int8 copy (x - 128) of the rows + row terms (unit scan: int8 MFMA, 4x fewer
-    const int32_t* rterm;     //   bytes) -- used for a batch whose queries are integers in [0, 255] too, else the fp32 rows
-    const int32_t* offsets;   // [nlist+1]
-    const int32_t* chunk_list;  // [n_chunks] list of each (list, 1024-row chunk) work item
-    const int32_t* chunk_row0;  // [n_chunks] first row (absolute, local array)
-    const int32_t* chunk_rows;  // [n_chunks] rows in the chunk
-    const float* q;           // [B][128]
-    const int32_t* lcnt;
-    const int32_t* lq;
-    const long long* lbase;
-    float* cand;              // [B][cand_stride] candidate scores, probe order
-    unsigned* slotmin;        // [B][kIvfSlots] (pre-set to 0): per query, the minimum score of the units that hash to a slot, as
-                              // complemented ordered floats under atomicMax; their k-th smallest bounds the k-th best score
-    unsigned* bkt;            // [B][nbk] (pre-set to 0), or nullptr: finer variant of slotmin -- the minimum score of the units
-    int nbk;                  // whose first candidate falls into [32 b, 32 b + 32) of the query's candidate array; the
-                              // selection then reads only the candidate blocks under the bound instead of every score
-    long long cand_stride;    // floats per query in the candidate array (bucket index = window position / 32)
-    int metric;
-    IvfMulti mb;
-};
-constexpr int kIvfSlots = 64;
-hipError_t launch_ivf_list_scan(const IvfListScanParams& p, int n_chunks, hipStream_t s);
-// planned variant: one wave per 32-row unit of the plan (IvfGroup::units); B = queries in the batch
-hipError_t launch_ivf_unit_scan(const IvfListScanParams& p, const int32_t* units, const int32_t* n_units, int B, int num_cus,
-                                hipStream_t s, int n_batches = 1);
-
-struct IvfSelectParams {
-    const float* cand;
-    long long cand_stride;
-    const int32_t* qoff;      // [B][kIvfMaxProbe+1]
-    const int32_t* probes;    // [B][nprobe]
-    const int32_t* offsets;   // [nlist+1]
-    const int32_t* id_map;    // reorder_to_original (local)
-    unsigned* tq;             // [B] complemented ordered-float bound per query (pre-set to 0)
-    const unsigned* slotmin;  // [B][kIvfSlots] from the unit scan, or nullptr = run ivf_bound_kernel
-    const unsigned* bkt;      // [B][nbk] per-block minima from the unit scan (takes precedence), or nullptr
-    int nbk;
-    float* gcand_d;           // [B][4096] gathered candidates under the bound
-    int32_t* gcand_p;
-    int32_t* gcnt;            // [B] (pre-set to 0)
-    int32_t* gdone;           // [B] arrival counters (pre-set to 0)
-    int32_t* govf;            // [B] overflow flags (pre-set to 0)
-    int nprobe, k;
-    int split;                // workgroups per query (set by launch_ivf_select)
-    float* out_d;             // [B][k]
-    int32_t* out_i;
-    IvfMulti mb;
-};
-hipError_t launch_ivf_select(const IvfSelectParams& p, int B, hipStream_t s, int n_batches = 1);
+hipError_t launch_ivf_prep_queries(const float* q, int B, const float* cents, const float* cnorm, int nlist, const IvfGroup& grp,
+                                   hipStream_t s, int n_batches);
+hipError_t launch_ivf_fill(const int32_t* gathered, long long blk_words, int B, int nprobe, int nlist, const int32_t* offsets,
+                           int32_t* probes_out, float* tau_out, int32_t* slow_out, const IvfGroup& grp, hipStream_t s, int n_batches);
 
 // ---- wide IVF pipeline: launch groups are cut into super-batches of kIvfWideBatches batches (<= 1024 queries) that
 // share ONE list-major pass: a list probed by any of them is read once and scored against all its queries (MFMA
 // column blocks of 16).  Bounds first (ivf_tau_kernel: k-th best of the first rows of the query's nearest resident
 // list), survivors to a CandSink, ranking by merge_compact_kernel -- no candidate-score arrays, no selection kernel.
-constexpr int kIvfWideBatches = 32;  // = a whole launch group: every resident list is read once per 1024 queries
+constexpr int kIvfWideBatches = 32;  // batches per super-batch at most: every resident list is read once per 1024 queries
 constexpr int kIvfWideQ = kIvfWideBatches * kMaxBatch;  // query slots per super-batch
 constexpr int kIvfTauRows = 256;                         // rows of the nearest list that seed a query's bound
 #ifndef VS_WIDE_UNIT
@@ -370,6 +301,7 @@ struct IvfWideParams {
     const float* q;           // batch b's [B][128] at (char*)q + b * q_batch_bytes
     long long q_batch_bytes;
     int n_batches, B;
+    int sb_batches;           // batches per super-batch (<= kIvfWideBatches): super-batch sb = batches [sb * sb_batches, ...)
     const float* qnorm;       // [n_batches][32]   | from ivf_coarse_mfma_kernel
     const int8_t* q8;         // [n_batches][32][128]
     const int32_t* qterm;     // [n_batches][32]
@@ -394,7 +326,7 @@ struct IvfWideParams {
     int32_t* dbg;             // diagnostic builds (-DVS_STAMPS) only: per-workgroup time stamps, dbg[0..] see ivf_scan_wide_kernel
     int diag;                 // diagnostic builds only: bit 0 no column blocks, bit 1 every unit = the wave's first, bit 2 no binning
 };
-hipError_t launch_ivf_wide_bounds_plan(const IvfWideParams& p, hipStream_t s);        // bounds (tau) and the plan, one launch
+hipError_t launch_ivf_wide_bounds_plan(const IvfWideParams& p, hipStream_t s, int what = 3);  // bounds (what & 1) and the plan (what & 2), one launch
 hipError_t launch_ivf_wide_scan(const IvfWideParams& p, int num_cus, hipStream_t s);  // the list-major scan
 int ivf_wide_grid_x(int num_cus, int n_sb);  // grid.x of the scan
 int ivf_wide_waves(int num_cus, int n_sb);   // its waves = candidate buffers

@@ -295,7 +295,8 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_one_kernel(const OnePara
             out[h] = x;  // (+inf while a lane holds fewer than t minima)
         }
     };
-    for (int n = 0; t_cur < tiles_total; n += 2) {  // (step() advances t_cur)
+    int n = 0;
+    while (t_cur < tiles_total) {  // (step() advances t_cur)
         step(0);
         if (t_cur < tiles_total) step(1);
         if (n == 0 || n == 2 || n == 6 || n == 14) {  // wave-uniform
@@ -305,6 +306,7 @@ __global__ __launch_bounds__(kScanThreads, 2) void scan_one_kernel(const OnePara
             for (int h = 0; h < NQH; ++h)
                 if (live[h] && sb[h] < VS_INF) tau[h] = fminf(tau[h], next_up(sb[h]));
         }
+        n += 2;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     ONE_STAMP(2);

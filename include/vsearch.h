@@ -304,6 +304,19 @@ VS_API int vs_bf_search_dev_sharded(vs_index* h, vs_comm* c, const float* querie
                                     int32_t* ids_dev, float* dists_dev, int32_t* flags_dev, void* stream);
 VS_API int vs_ivf_search_dev_sharded(vs_index* h, vs_comm* c, const float* queries_dev, int n_batches, int B, int k,
                                      int nprobe, int32_t* ids_dev, float* dists_dev, void* stream);
+/* The cluster-sharded IVF call (BASELINE configs[4]; IVFIndex::searchBatch, IVFIndex.cpp:640-859, over `world` ranks).
+ * A launch group is cut into `world` slices of up to 32 batches.  Rank r alone runs the per-query stages of slice r
+ * (centroid scores, top-nprobe, the bound), ONE all-gather exchanges the slices' results (nprobe + 2 words per query),
+ * every rank then scans its resident lists for ALL slices and ranks its candidates, and the all-gather of top-k lists
+ * + merge finishes the group.  Per launch group a rank so does what an unsharded index does for ONE slice (plus the
+ * ranking of every query over an eighth of the candidates).  The exchanges of group g run beside the front half of
+ * group g + 1.  Indexes with nlist > 4096 or fewer lists than ranks run the whole pipeline per rank (one all-gather).
+ *
+ * Virtual ranks: the same pipeline for G shards (vs_ivf_create / vs_ivf_load with rank r, world G) on ONE device, driven
+ * by the calling thread, the collectives replaced by writing into the gathered layout.  For tests and for measuring
+ * a rank's cost per launch group on one GPU: rank_ms[r] (optional, G doubles) = device time of rank r's two halves. */
+VS_API int vs_ivf_search_dev_vshards(vs_index* const* shards, int G, const float* queries_dev, int n_batches, int B, int k,
+                                     int nprobe, int32_t* ids_dev, float* dists_dev, double* rank_ms, void* stream);
 
 /* Host-buffer forms (what the CLIs run with --gpus N): same contract, queries and results in host memory on every
  * rank.  Brute force: a tie inside the k+1 best is counted in timing->tie_queries but comes out in (dist, id) order

@@ -306,11 +306,12 @@ def test_int8_rows_and_fp32_fallback_agree(gpu_pkg):
         assert np.array_equal(ids3, ids) and np.array_equal(d3, d * 4.0)
 
 
-@pytest.mark.parametrize("nlist", [1024, 1500, 2500])
+@pytest.mark.parametrize("nlist", [1024, 1500, 2500, 5000])
 def test_large_nlist_paths(gpu_pkg, nlist):
-    """nlist <= 1024 and <= 2048 take the two instantiations of the fused coarse kernel, nlist > 2048 the fallback
-    (MFMA score matrix + probe pick + query-major scan).  All must agree with the oracle's restatement (same probes
-    up to last-bit coarse ties) and return exact integer distances; multi-batch == batch by batch."""
+    """nlist <= 1024, <= 2048 and <= 4096 take the three instantiations of the pick kernel of the wide list-major
+    pipeline; nlist > 4096 the query-major fallback (coarse scores on the MFMA scan kernel, probe pick, one workgroup per
+    (query, probe)).  All must agree with the oracle's restatement (same probes up to last-bit coarse ties) and return
+    exact integer distances; multi-batch == batch by batch."""
     import torch
     base = gpu_pkg.synth_sift(60000, seed=31)
     vr, off, r2o, cents, _ = gpu_pkg.ivf_build(base, nlist, max_iter=3, seed=7)
@@ -590,3 +591,81 @@ def test_wide_slow_path_duplicates_and_tiny_lists(gpu_pkg):
     ok = gi >= 0
     assert np.array_equal(np.where(ok, np.take_along_axis(ex, np.maximum(gi, 0).astype(np.int64), 1).astype(np.float32), np.inf), gd)
     assert all(len(set(r[r >= 0])) == (r >= 0).sum() for r in gi)   # no row twice
+
+
+@pytest.mark.parametrize("world,nb,B", [(2, 5, 32), (2, 150, 32), (4, 37, 32), (8, 70, 20), (8, 3, 32), (8, 256, 32)])
+def test_sliced_pipeline_virtual_ranks_equal_unsharded(gpu_pkg, world, nb, B):
+    """The cluster-sharded pipeline (BASELINE configs[4]) on virtual ranks: `world` shards of one index on one GPU go
+    through vs_ivf_search_dev_sharded's sliced pipeline -- rank r runs coarse + pick + bound for slice r only, the blocks
+    are exchanged, every rank fills its slot tables for all slices, plans, scans its lists, ranks; top-k lists merged --
+    with the two collectives replaced by writes into the gathered layout (vs_ivf_search_dev_vshards).  Distances must equal
+    the unsharded index's bit for bit (ids as sets per query: equal distances come out in a different order).  Covers a
+    launch group with fewer batches than ranks (8, 3), ragged slices, several groups per call and a full 8 x 32-batch group."""
+    import torch
+    dev = torch.device("cuda:0")
+    base, cents, vr, off, r2o = _make_index(gpu_pkg, n=60000, nlist=256, seed=16)
+    k, nprobe = 5, 24
+    q = gpu_pkg.synth_sift(nb * B, seed=500 + nb)
+    s = torch.cuda.current_stream().cuda_stream
+    qd = torch.from_numpy(q).to(dev)
+    want_i = torch.zeros((nb * B, k), dtype=torch.int32, device=dev)
+    want_d = torch.zeros((nb * B, k), dtype=torch.float32, device=dev)
+    with gpu_pkg.IVFIndex(vectors_reordered=vr, centroids=cents, cluster_offsets=off, reorder_to_original=r2o) as ivf:
+        ivf.search_dev_multi(qd.data_ptr(), nb, B, k, nprobe, want_i.data_ptr(), want_d.data_ptr(), s)
+        torch.cuda.synchronize()
+    shards = [gpu_pkg.IVFIndex(vectors_reordered=vr, centroids=cents, cluster_offsets=off, reorder_to_original=r2o, rank=r, world=world)
+              for r in range(world)]
+    try:
+        for timed in (False, True):
+            got_i = torch.full((nb * B, k), -7, dtype=torch.int32, device=dev)
+            got_d = torch.full((nb * B, k), -7.0, dtype=torch.float32, device=dev)
+            ms = gpu_pkg.IVFIndex.search_dev_vshards(shards, qd.data_ptr(), nb, B, k, nprobe, got_i.data_ptr(), got_d.data_ptr(), s, timed=timed)
+            torch.cuda.synchronize()
+            assert torch.equal(got_d, want_d), f"distances differ (world={world}, nb={nb}, B={B}, timed={timed})"
+            a, b = want_i.cpu().numpy(), got_i.cpu().numpy()
+            assert all(sorted(a[i].tolist()) == sorted(b[i].tolist()) for i in range(nb * B))
+            if timed:
+                assert len(ms) == world and all(m > 0 for m in ms)
+    finally:
+        for sh in shards:
+            sh.close()
+
+
+def test_launch_groups_of_several_super_batches_and_fp32_rows(gpu_pkg):
+    """(i) VSEARCH_IVF_GROUP (read when an index is created): launch groups of 128 batches = 4 super-batches per kernel
+    launch must give what groups of 32 give.  (ii) vs_set_precision(1) on an IVF index: the list scan on the fp32 rows
+    (IVFIndex.cpp:270-358's arithmetic) equals the exact-int8 scan of the same byte-valued rows bit for bit."""
+    import torch
+    dev = torch.device("cuda:0")
+    base, cents, vr, off, r2o = _make_index(gpu_pkg, n=60000, nlist=256, seed=16)
+    nb, B, k, nprobe = 150, 32, 5, 16
+    q = gpu_pkg.synth_sift(nb * B, seed=77)
+    s = torch.cuda.current_stream().cuda_stream
+    qd = torch.from_numpy(q).to(dev)
+
+    def run(group, precision):
+        old = os.environ.get("VSEARCH_IVF_GROUP")
+        os.environ["VSEARCH_IVF_GROUP"] = str(group)
+        try:
+            ivf = gpu_pkg.IVFIndex(vectors_reordered=vr, centroids=cents, cluster_offsets=off, reorder_to_original=r2o)
+        finally:
+            if old is None:
+                del os.environ["VSEARCH_IVF_GROUP"]
+            else:
+                os.environ["VSEARCH_IVF_GROUP"] = old
+        with ivf:
+            ivf.set_precision(precision)
+            gi = torch.zeros((nb * B, k), dtype=torch.int32, device=dev)
+            gd = torch.zeros((nb * B, k), dtype=torch.float32, device=dev)
+            ivf.search_dev_multi(qd.data_ptr(), nb, B, k, nprobe, gi.data_ptr(), gd.data_ptr(), s)
+            torch.cuda.synchronize()
+            return gi.cpu().numpy(), gd.cpu().numpy()
+
+    i32, d32 = run(32, 0)
+    i128, d128 = run(128, 0)
+    assert np.array_equal(d32, d128) and np.array_equal(i32, i128)
+    i256, d256 = run(256, 0)
+    assert np.array_equal(d32, d256) and np.array_equal(i32, i256)
+    if32, df32 = run(64, 1)
+    assert np.array_equal(d32, df32)
+    assert all(sorted(i32[i].tolist()) == sorted(if32[i].tolist()) for i in range(nb * B))
