@@ -517,11 +517,15 @@ def main():
             sizes = np.diff(off)
             log(f"IVF index: nlist={nlist}, list sizes min/avg/max = {sizes.min()}/{sizes.mean():.0f}/{sizes.max()}, "
                 f"built in {time.time() - t0:.1f}s")
-            # one vs_ivf_search_dev_multi call takes up to SI batches (N = 1: the library splits a call into launch groups of
-            # 32 batches and runs consecutive groups on two streams; N > 1: one call = one group = one all-gather)
-            SI = min(n_qbatches, 128) if world == 1 else S
+            # one vs_ivf_search_dev_multi call takes SI batches = ONE launch group: every kernel of the pipeline is launched
+            # once for all of them, the list scan makes one pass per super-batch of 32 batches (N = 1: 256 batches; N > 1:
+            # 32 per rank, the cluster-sharded pipeline's group: slice r's per-query stages run on rank r only)
+            SI = 256 if world == 1 else min(256, 32 * world)
+            q_ivf = torch.from_numpy(np.tile(queries, ((SI * BATCH + n_queries - 1) // n_queries, 1))[:SI * BATCH].copy()).to(dev)
             iout_d = torch.zeros((SI * BATCH, K), dtype=torch.float32, device=dev)
             iout_i = torch.zeros((SI * BATCH, K), dtype=torch.int32, device=dev)
+            iloc = torch.zeros((2 * SI * BATCH * K,), dtype=torch.int32, device=dev) if world > 1 else None
+            igath = torch.zeros((world * 2 * SI * BATCH * K,), dtype=torch.int32, device=dev) if world > 1 else None
             i8_rows = bool(np.all(full == np.floor(full)) and full.min() >= 0 and full.max() <= 255)
             row_bytes = (DIM + 4) if i8_rows else (4 * DIM + 4)
             cn = (cents_h.astype(np.float64) ** 2).sum(1)
@@ -529,37 +533,41 @@ def main():
             if world == 1:
                 gt_ids, _ = bf.search(queries[:1024], K)
 
-            def ivf_leg(nprobe):
+            def ivf_leg(nprobe, index=None, tag="IVF"):
+                index = index or ivf
+
                 def ivf_step(i, n):
                     si = i % SI
                     if si != SI - 1 and i != n - 1:
                         return
                     gs = si + 1
-                    qb = (i - si) % n_qbatches
-                    if qb + gs > n_qbatches:
-                        qb = 0
-                    qp = q_dev.data_ptr() + qb * BATCH * DIM * 4
+                    qp = q_ivf.data_ptr()
                     if world == 1:
-                        ivf.search_dev_multi(qp, gs, BATCH, K, nprobe, iout_i.data_ptr(), iout_d.data_ptr(), sptr)
-                    else:
-                        sharded_call(lambda q, nb, ip, dp: ivf.search_dev_multi(q, nb, BATCH, K, nprobe, ip, dp, sptr),
-                                     lambda c, q, nb, B, ip, dp, fl, st: ivf.search_dev_sharded(c, q, nb, B, K, nprobe, ip, dp, st),
-                                     gs, qp, K, iout_i, iout_d, 0)
+                        index.search_dev_multi(qp, gs, BATCH, K, nprobe, iout_i.data_ptr(), iout_d.data_ptr(), sptr)
+                    elif comm is not None:
+                        index.search_dev_sharded(comm, qp, gs, BATCH, K, nprobe, iout_i.data_ptr(), iout_d.data_ptr(), sptr)
+                    else:  # (no library communicator: every rank runs the whole pipeline on its lists, torch's all-gather)
+                        lay = pkg.GatherLayout(gs, BATCH, K)
+                        lv, gv = iloc[:lay.words], igath[:world * lay.words]
+                        index.search_dev_multi(qp, gs, BATCH, K, nprobe, lv.data_ptr() + lay.ids_offset * 4, lv.data_ptr(), sptr)
+                        all_gather(gv, lv)
+                        pkg.topk_merge_dev(gv.data_ptr(), gv.data_ptr() + lay.ids_offset * 4, world, gs * BATCH, K, K,
+                                           iout_d.data_ptr(), iout_i.data_ptr(), 0, sptr, stride_g=lay.stride_g)
 
-                # an extra, timed in its own steady state: regions of at least one full call (SI batches = four launch groups
-                # on the library's two streams), whatever --steps says for the headline (the driver's 20 steps would be one
-                # 20-batch group on one stream: half the rate, r02l_bench_driver_flags.json in profiles/)
-                isteps = max(steps, SI) if world == 1 else steps
-                ivf.prof_enable(True)
-                ireg = timed(ivf_step, isteps, warmup)
-                okern_ms, okern_n = ivf.prof_read(1)
-                ivf.prof_enable(False)
+                # an extra, timed in its own steady state: regions of at least one full call (SI batches = one launch group),
+                # whatever --steps says for the headline (the driver's 20 steps would be one 20-batch group: a caller issuing
+                # 640 queries at a time gets about half the rate)
+                isteps = max(steps, SI)
+                index.prof_enable(True)
+                ireg = timed(ivf_step, isteps, max(warmup, SI))
+                okern_ms, okern_n = index.prof_read(1)
+                index.prof_enable(False)
                 iel = median(ireg)
                 info = {"metric": "ivf_qps", "value": round(isteps * BATCH / iel, 1), "ms_per_step": round(iel / isteps * 1e3, 4),
                         "nlist": nlist, "nprobe": nprobe, "batch": BATCH, "batches_per_call": min(SI, isteps), "steps": isteps}
                 if world == 1:
                     nrec = 1024
-                    ids, _, total = ivf.searchBatch(queries[:nrec], nrec, K, nprobe)
+                    ids, _, total = index.searchBatch(queries[:nrec], nrec, K, nprobe)
                     info["recall_at_1"] = float(np.mean(ids[:, 0] == gt_ids[:, 0]))          # main_ivf.cpp:52-59 with k = 1
                     info["recall_at_5"] = float(np.mean([len(set(ids[i]) & set(gt_ids[i])) / K for i in range(nrec)]))
                     info["avg_candidates"] = total / nrec
@@ -569,17 +577,23 @@ def main():
                     # (4d + 8) * S_q, which assumes one pass per query.
                     cents64 = cents_h.astype(np.float64)
 
-                    def launch_bytes(gs):
-                        gq = queries[:gs * BATCH].astype(np.float64)
-                        pr = np.argsort(cn[None, :] - 2.0 * gq @ cents64.T, axis=1)[:, :nprobe]
-                        rows = int(sizes[np.unique(pr)].sum())
-                        return row_bytes * rows + 4 * pr.size + len(gq) * (DIM + 16 if i8_rows else 4 * DIM + 16), rows
+                    rb = row_bytes if index.precision_used == 0 else (4 * DIM + 4)
 
-                    def launches_of(n):  # sizes of the launch groups of a run of n steps: calls of <= SI batches, groups of <= 32
-                        calls = [SI] * (n // SI) + ([n % SI] if n % SI else [])
-                        return [g for c in calls for g in [32] * (c // 32) + ([c % 32] if c % 32 else [])]
+                    def launch_bytes(gs):  # one scan launch = a group of gs batches = super-batches of 32 batches, one pass each
+                        tot, rows_tot = 0, 0
+                        gq_all = q_ivf[:gs * BATCH].cpu().numpy().astype(np.float64)
+                        for b0 in range(0, gs, 32):
+                            gq = gq_all[b0 * BATCH:(b0 + 32) * BATCH]
+                            pr = np.argsort(cn[None, :] - 2.0 * gq @ cents64.T, axis=1)[:, :nprobe]
+                            rows = int(sizes[np.unique(pr)].sum())
+                            tot += rb * rows + 4 * pr.size + len(gq) * (DIM + 16 if rb < 512 else 4 * DIM + 16)
+                            rows_tot += rows
+                        return tot, rows_tot
 
-                    window = launches_of(warmup) + launches_of(isteps) * len(ireg)   # every launch of the prof window
+                    def launches_of(n):  # sizes of the launch groups of a run of n steps: calls of <= SI batches = one group each
+                        return [SI] * (n // SI) + ([n % SI] if n % SI else [])
+
+                    window = launches_of(max(warmup, SI)) + launches_of(isteps) * len(ireg)   # every launch of the prof window
                     per_size = {gs: launch_bytes(gs) for gs in set(window)}
                     ib = sum(per_size[gs][0] for gs in window) / max(len(window), 1)   # mean algorithmic bytes per launch
                     uniq_rows = per_size[max(per_size)][1]
@@ -587,28 +601,102 @@ def main():
                     ach = ib / ks_launch / 1e9 if ks_launch > 0 else None
                     itraffic = None
                     ipath = os.path.join(ROOT, "profiles", "traffic_ivf_list_scan.json")
-                    if os.path.exists(ipath) and n_rows == N_BASE and i8_rows and nprobe == NPROBE and 32 in window:  # (PMC figure of a 32-batch launch)
-                        itraffic = json.load(open(ipath)).get("hbm_bytes_per_launch_32_batches")
+                    tkey = "hbm_bytes_per_launch_fp32_rows" if rb > 512 else "hbm_bytes_per_launch"
+                    if os.path.exists(ipath) and n_rows == N_BASE and nprobe == NPROBE and set(window) == {SI}:
+                        itraffic = json.load(open(ipath)).get(tkey)   # (PMC figure of a launch of SI batches, profiles/README.md)
                     frac = round(ach / HBM_PEAK_GBS, 4) if ach else None
+                    assert frac is None or frac <= 1.0, ("the byte model does not describe the kernel", frac)
                     info["roofline"] = {"bound": "hbm", "achieved": round(ach, 1) if ach else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                        "frac": frac if (frac is not None and frac <= 1.0) else None, "traffic": itraffic,
+                                        "frac": frac, "traffic_static_from_profiles": itraffic,
                                         "kernel": "vs::ivf_scan_wide_kernel", "kernel_us": round(ks_launch * 1e6, 2),
                                         "launches": int(okern_n), "batches_per_launch": round(sum(window) / max(len(window), 1), 2),
-                                        "algorithmic_bytes_per_launch": int(ib), "row_bytes": row_bytes,
+                                        "algorithmic_bytes_per_launch": int(ib), "row_bytes": rb,
                                         "distinct_rows_per_launch": uniq_rows,
                                         "per_query_pass_bytes": int((4 * DIM + 8) * info["avg_candidates"] * BATCH * max(per_size)),
-                                        "note": "one list-major pass per launch group over the tiled exact int8 copy (128 B of row + "
-                                                "4 B of row term per row); the 132 MB of rows fit the 256 MB Infinity Cache, so "
+                                        "note": "one list-major pass per super-batch of 32 batches over the tiled exact int8 copy (128 B of "
+                                                "row + 4 B of row term per row); the 132 MB of rows fit the 256 MB Infinity Cache, so "
                                                 "repeated launches are served from there and the HBM counters can read below the "
                                                 "algorithmic bytes; fraction quoted against the HBM peak as the reference roof"
-                                                if i8_rows else "fp32 rows streamed from HBM"}
-                log(f"IVF nprobe={nprobe}: {info['value']:.0f} QPS, recall@1={info.get('recall_at_1')}, "
+                                                if rb < 512 else "one list-major pass per super-batch of 32 batches over the fp32 rows "
+                                                "(IVFIndex.cpp:270-358's arithmetic; 512 B of row + 4 B of norm per row): the 466 MB a "
+                                                "super-batch touches do not fit the Infinity Cache, the HBM roof is the binding one"}
+                log(f"{tag} nprobe={nprobe}: {info['value']:.0f} QPS, recall@1={info.get('recall_at_1')}, "
                     f"recall@5={info.get('recall_at_5')}, avg candidates={info.get('avg_candidates')}")
                 return info
 
             ivf_info = ivf_leg(NPROBE)
             if not args.no_extras:
                 ivf8_info = ivf_leg(8)
+            if world == 1 and not args.no_extras:
+                # the list scan in the reference's arithmetic: fp32 rows (IVFIndex.cpp:270-358), same index, same pipeline
+                ivf.set_precision(1)
+                ivf_info["fp32_rows"] = ivf_leg(NPROBE, tag="IVF, fp32 rows,")
+                ivf.set_precision(0)
+            if world == 1 and not args.no_extras:
+                # BASELINE configs[4] on ONE GPU: what a rank of a cluster-sharded job does per launch group.  G shards of
+                # this index (vs_ivf_create(..., rank r, world G)) run the sharded call's sliced pipeline as virtual ranks,
+                # one after the other, the two collectives replaced by writes into the gathered layout; rank_us = device
+                # time (HIP events) of a rank's front + back half for a group of 32 G batches.
+                def ev_us(fn, reps=4):
+                    fn()
+                    fn()
+                    torch.cuda.synchronize()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    ts = []
+                    for _ in range(3):
+                        e0.record(stream)
+                        for _ in range(reps):
+                            fn()
+                        e1.record(stream)
+                        torch.cuda.synchronize()
+                        ts.append(e0.elapsed_time(e1) * 1e3 / reps)
+                    return sorted(ts)[1]
+
+                def make_ivf(env=None, **kw):
+                    env = env or {}
+                    old = {k_: os.environ.get(k_) for k_ in env}
+                    os.environ.update({k_: str(v_) for k_, v_ in env.items()})
+                    try:
+                        return pkg.IVFIndex(vectors_reordered=vr, centroids=cents_h, cluster_offsets=off, reorder_to_original=r2o,
+                                            device=local_rank, **kw)
+                    finally:
+                        for k_, v_ in old.items():
+                            if v_ is None:
+                                os.environ.pop(k_, None)
+                            else:
+                                os.environ[k_] = v_
+
+                call1 = lambda ix: ix.search_dev_multi(q_ivf.data_ptr(), SI, BATCH, K, NPROBE, iout_i.data_ptr(), iout_d.data_ptr(), sptr)
+                us_default = ev_us(lambda: call1(ivf)) / (SI * BATCH / 1024)
+                with make_ivf({"VSEARCH_IVF_GROUP": 32, "VSEARCH_IVF_WIDE_LANES": 1}) as ivf32:
+                    us_g32 = ev_us(lambda: call1(ivf32)) / (SI * BATCH / 1024)
+                want_d = iout_d.clone()
+                shard_info = {"metric": "device time per launch group of a rank of a G-way cluster-sharded job, virtual ranks on one GPU "
+                                        "(vs_ivf_search_dev_vshards: the collectives replaced by writes into the gathered layout)",
+                              "nprobe": NPROBE,
+                              "unsharded_us_per_1024_queries": round(us_default, 2),
+                              "unsharded_groups_of_32_one_stream_us_per_1024_queries": round(us_g32, 2)}
+                for G in (2, 4, 8):
+                    shards = [make_ivf(rank=r_, world=G) for r_ in range(G)]
+                    nb_g = 32 * G
+                    vcall = lambda timed_=False: pkg.IVFIndex.search_dev_vshards(shards, q_ivf.data_ptr(), nb_g, BATCH, K, NPROBE, iout_i.data_ptr(),
+                                                                                iout_d.data_ptr(), sptr, timed=timed_)
+                    vcall()
+                    vcall()
+                    torch.cuda.synchronize()
+                    assert torch.equal(iout_d[:nb_g * BATCH], want_d[:nb_g * BATCH]), "sliced pipeline differs from the unsharded index"
+                    per_rank = np.median(np.array([vcall(True) for _ in range(5)]), axis=0) * 1e3
+                    worst = float(per_rank.max())
+                    shard_info[f"world{G}"] = {"batches_per_group": nb_g, "rank_us_per_group": [round(float(x), 1) for x in per_rank],
+                                               "slowest_rank_us_per_1024_queries": round(worst / G, 2),
+                                               "speedup_vs_unsharded": round(us_default / (worst / G), 2),
+                                               "speedup_vs_unsharded_groups_of_32_one_stream": round(us_g32 / (worst / G), 2)}
+                    log(f"IVF sliced, world {G}: slowest rank {worst:.1f} us per group of {nb_g} batches = {worst / G:.1f} us per 1024 queries "
+                        f"({us_default / (worst / G):.2f}x the unsharded index at {us_default:.1f} us, {us_g32 / (worst / G):.2f}x its "
+                        f"32-batch one-stream organisation at {us_g32:.1f} us)")
+                    for sh_ in shards:
+                        sh_.close()
+                ivf_info["shard_1ofG"] = shard_info
             if world > 1 and not args.no_extras:
                 # N > 1, the other way to use N GPUs for an index that fits one of them (1 M rows are 0.2 % of a GPU's HBM):
                 # every rank holds the WHOLE index and serves its own share of the batches (queries are independent: no

@@ -283,9 +283,13 @@ class _Index:
     def set_batch(self, batch: int):
         _check(lib().vs_set_batch(self._h, batch))
 
+    precision_used = 0  # what set_precision() was last called with (0 = auto)
+
     def set_precision(self, precision: int):
-        """0 = auto (int8 scan when the base is integer valued in [0, 255]), 1 = fp32, 2 = require int8."""
+        """0 = auto (int8 scan when the base is integer valued in [0, 255]), 1 = fp32, 2 = require int8.  Brute force and
+        IVF alike (an IVF index then scans the fp32 rows, IVFIndex.cpp:270-358's arithmetic)."""
         _check(lib().vs_set_precision(self._h, precision))
+        self.precision_used = precision
 
     # QnnRunner-style getters (QnnRunner.h:37-39)
     def getNumDocs(self) -> int:

@@ -44,7 +44,7 @@ constexpr int kMaxMulti = 32;  // batches per persistent scan launch
 constexpr int kOneMaxBatches = 4;  // calls of fewer batches take one single-call scan launch per batch (fp32 rows)
 constexpr int kOneMaxQueries = 16;  // ... when a batch holds at most this many queries
 constexpr int kPairMinTiles = 96;   // tiles per workgroup and pass from which the fp32 streaming scan pairs batches
-constexpr int kIvfGroupDefault = 32;  // batches per launch group of an unsharded IVF index (VSEARCH_IVF_GROUP)
+constexpr int kIvfGroupDefault = 256; // batches per launch group of an unsharded IVF index (VSEARCH_IVF_GROUP): 46 us per 1024 queries against 79 with groups of 32
 constexpr int kIvfGroupMax = 256;     // ... at most (8 super-batches of 32): also the group of an index sharded 8 ways
 constexpr int kIvfShardMaxWorld = 16; // ranks the cluster-sharded pipeline is compiled for (one super-batch per rank)
 constexpr int64_t kIvfHostChunk = 4 * 32 * 32;  // queries per chunk of the host-buffer IVF call (one upload, one download)
@@ -155,7 +155,17 @@ struct vs_index {
     int32_t* d_chunk_rows = nullptr;
     int ivf_gb = 32;                   // batches per launch group (multiple of 32) the wide pipeline's scratch is sized for
     int ivf_nsb = 1;                   // ... in at most this many super-batches (sharded: one per rank)
+    int ivf_lanes = 2;                 // streams the launch groups of one device call are dealt to
     int64_t ivf_host_cap = 0;          // queries per chunk the host-buffer call's staging slots hold
+    // sharded index: the first kIvfTauRows rows of EVERY list (resident or not), replicated on every rank: a query's bound
+    // then comes from its two nearest lists wherever they live -- the bounds of the unsharded index (a bound from the
+    // nearest RESIDENT lists of an eighth of the lists let ten times the candidates through)
+    float* d_head_vecs = nullptr;      // [head rows + 64][128], lists packed
+    float* d_head_norm = nullptr;      // [head rows + 64]
+    int32_t* d_head_off = nullptr;     // [nlist + 1]
+    int8_t* d_head_t8 = nullptr;       // byte-valued heads: 16-row tiles, every list padded to a multiple of 16 rows
+    int32_t* d_head_rterm_t = nullptr;
+    int32_t* d_head_tdelta = nullptr;  // [nlist] padded row - row
     int32_t* vsh_blk = nullptr;        // virtual ranks (vs_ivf_search_dev_vshards): the gathered blocks / top-k lists, owned by shard 0
     int32_t* vsh_loc = nullptr;
     size_t vsh_loc_words = 0;
@@ -174,6 +184,7 @@ struct vs_index {
         int4* wbuf = nullptr;       // [waves][kIvfWideWaveCap]
         int n_waves = 0;
         float* cand_d = nullptr;    // [1024][16][kIvfWideSubCap]
+        int32_t* rank_list = nullptr;   // groups of more than 2048 queries: [0] count, [1..] the queries the wave-per-query ranking left over
         int32_t* cand_i = nullptr;
         bool dirty = false;         // the zeroed block may hold a failed call's counts: memset before the next group
         char* slab = nullptr;       // per batch: probes [32][kMaxNprobe] | coarse scores [32][nlist padded]
@@ -267,12 +278,13 @@ void free_all(vs_index* h) {
     void* ptrs[] = {h->d_vecs, h->d_norm, h->d_vecs_u8, h->d_rterm, h->d_seed_f32, h->d_seed_bnorm, h->d_seed_u8, h->d_seed_rterm, h->d_vecs_t8, h->d_nrh_t, h->d_rterm_t, h->d_r2o_t, h->d_tdelta, h->d_chunk_trow0, h->d_invalid, h->d_centroids, h->d_cnorm, h->d_offsets, h->d_r2o, h->d_q,
                     h->d_out_d, h->d_out_i,
                     h->d_flags, h->d_scores, h->d_probes, h->d_ipart_d, h->d_ipart_i, h->d_cand,
-                    h->d_chunk_list, h->d_chunk_row0, h->d_chunk_rows, h->vsh_blk, h->vsh_loc};
+                    h->d_chunk_list, h->d_chunk_row0, h->d_chunk_rows, h->vsh_blk, h->vsh_loc,
+                    h->d_head_vecs, h->d_head_norm, h->d_head_off, h->d_head_t8, h->d_head_rterm_t, h->d_head_tdelta};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     {
         for (auto& W : h->wide) {
-            void* wd[] = {W.lq, W.zero, W.units, W.tau, W.qnorm, W.q8, W.qterm, W.wbuf, W.cand_d, W.cand_i, W.slab};
+            void* wd[] = {W.lq, W.zero, W.units, W.tau, W.qnorm, W.q8, W.qterm, W.wbuf, W.cand_d, W.cand_i, W.slab, W.rank_list};
             for (void* w : wd)
                 if (w) (void)hipFree(w);
         }
@@ -784,12 +796,12 @@ int scores_dev(vs_index* h, const float* vecs, const float* norms, int64_t rows,
     return VS_OK;
 }
 
-// tuning knob (VSEARCH_IVF_WIDE_LANES=1): vs_ivf_search_dev_multi keeps all launch groups of a call on the caller's stream
-// instead of alternating them between two streams
-int g_ivf_wide_lanes = [] {
+// tuning knob (VSEARCH_IVF_WIDE_LANES=1, read when an index is created): vs_ivf_search_dev_multi keeps all launch groups of
+// a call on the caller's stream instead of alternating them between two streams
+int ivf_wide_lanes() {
     const char* e = getenv("VSEARCH_IVF_WIDE_LANES");
     return e ? std::max(1, std::min(kWideLanesMax, atoi(e))) : 2;
-}();
+}
 // tuning knob (VSEARCH_IVF_GROUP, read when an index is created): batches per launch group of an unsharded index
 // (multiple of 32, <= 256): every kernel of the pipeline is launched once per group
 int ivf_group_batches() {
@@ -870,6 +882,10 @@ int ensure_ivf_wide(vs_index* h, int lane) {
     if ((rc = dev_alloc(&W.wbuf, (size_t)W.n_waves * kIvfWideWaveCap))) return rc;
     if ((rc = dev_alloc(&W.cand_d, nq * kWideSub * kIvfWideSubCap))) return rc;
     if ((rc = dev_alloc(&W.cand_i, nq * kWideSub * kIvfWideSubCap))) return rc;
+    if (nq > 2048) {
+        if ((rc = dev_alloc(&W.rank_list, nq + 1))) return rc;
+        HIPCHK(hipMemset(W.rank_list, 0, sizeof(int32_t)));
+    }
     W.off_scores = (32ll * kMaxNprobe * 4 + 255) & ~255ll;
     W.slab_stride = (W.off_scores + 32ll * ((h->nlist + 63) & ~63) * 4 + 255) & ~255ll;
     if ((rc = dev_alloc(&W.slab, (size_t)W.slab_stride * h->ivf_gb))) return rc;
@@ -970,6 +986,7 @@ vs::IvfGroup wide_group(vs_index* h, vs_index::IvfWide& W, int sbb, int B) {
     grp.w_qterm = W.qterm;
     grp.w_invalid = z.invalid;
     grp.w_overflow = z.ovf;
+    grp.w_glist = W.rank_list;
     grp.w_cnt = z.plan;
     grp.w_lq = W.lq;
     grp.w_q = vs::kIvfWideQ;
@@ -1003,7 +1020,7 @@ int wide_scan_rank(vs_index* h, vs_index::IvfWide& W, const vs::IvfWideParams& w
 #ifdef VS_STAMPS
     m.dbg = g_dbg ? g_dbg + 8192 * 16 : nullptr;
 #endif
-    HIPCHK(vs::launch_ivf_wide_rank(m, kIvfWideSubCap, (int64_t)kWideSub * kIvfWideSubCap, wp, s));
+    HIPCHK(vs::launch_ivf_wide_rank(m, kIvfWideSubCap, (int64_t)kWideSub * kIvfWideSubCap, wp, s, W.rank_list));
     return VS_OK;
 }
 
@@ -1069,6 +1086,7 @@ int ivf_shard_front(vs_index* h, int lane, const float* q_dev, int nb, int sbb, 
     fg.w_qterm = nullptr;
     fg.w_invalid = nullptr;
     fg.w_overflow = nullptr;
+    fg.w_glist = nullptr;
     fg.w_cnt = nullptr;  // (slot tables are filled after the exchange, for all slices)
     fg.w_lq = nullptr;
     fg.mb.probes = (long long)32 * nprobe * sizeof(int32_t);
@@ -1084,6 +1102,18 @@ int ivf_shard_front(vs_index* h, int lane, const float* q_dev, int nb, int sbb, 
     wp.probes_batch_bytes = fg.mb.probes;
     wp.tau = reinterpret_cast<float*>(blk + sb_q * nprobe);
     wp.slow = blk + sb_q * nprobe + sb_q;
+    if (h->d_head_vecs) {  // the bound's rows: the replicated heads of the query's two nearest lists, wherever those live
+        wp.vecs = h->d_head_vecs;
+        wp.vnorm = h->d_head_norm;
+        wp.offsets = h->d_head_off;
+        const bool bytes = h->d_head_t8 && h->precision != 1;
+        wp.vecs_u8 = bytes ? h->d_head_t8 : nullptr;  // (non-null = "byte rows exist"; the tiled copy is what is read)
+        wp.rterm = nullptr;
+        wp.vecs_t8 = bytes ? h->d_head_t8 : nullptr;
+        wp.rterm_t = bytes ? h->d_head_rterm_t : nullptr;
+        wp.nrh_t = nullptr;
+        wp.tdelta = bytes ? h->d_head_tdelta : nullptr;
+    }
     HIPCHK(vs::launch_ivf_wide_bounds_plan(wp, s, 1));  // bounds only
     return VS_OK;
 }
@@ -1144,7 +1174,7 @@ int ivf_multi_dev(vs_index* h, const float* q_dev, int nb, int B, int k, int npr
     }
     const int gb = h->ivf_gb;
     const int groups = (nb + gb - 1) / gb;
-    const int lanes = std::min({g_ivf_wide_lanes, kWideLanesMax, groups});
+    const int lanes = std::min({h->ivf_lanes, kWideLanesMax, groups});
     if (lanes <= 1) {
         for (int b0 = 0; b0 < nb && !rc; b0 += gb)
             rc = ivf_group_wide_dev(h, 0, q_dev + (size_t)b0 * B * vs::kDim, std::min(gb, nb - b0), B, k, nprobe, out_d + (size_t)b0 * B * k,
@@ -1703,6 +1733,57 @@ int vs_ivf_list_owners(const int32_t* cluster_offsets, int nlist, int world, int
     return VS_OK;
 }
 
+// the replicated heads of a sharded index (see vs_index::d_head_vecs): rows [offsets[c], offsets[c] + min(len, kIvfTauRows))
+// of every list of the WHOLE index, fp32 packed + (when every head row is byte valued) the tiled byte copy
+static int build_tau_heads(vs_index* h, const float* vectors, const int32_t* offsets, int nlist) {
+    std::vector<int32_t> hoff((size_t)nlist + 1, 0), tdelta((size_t)nlist, 0);
+    int64_t t = 0;
+    for (int c = 0; c < nlist; ++c) {
+        const int32_t len = std::min<int32_t>(offsets[c + 1] - offsets[c], vs::kIvfTauRows);
+        hoff[c + 1] = hoff[c] + len;
+        tdelta[c] = (int32_t)t - hoff[c];
+        t += (len + 15) / 16 * 16;
+    }
+    const size_t nh = (size_t)hoff[nlist], nt = (size_t)t + 64;
+    std::vector<float> hv((nh + vs::kScanPadRows) * vs::kDim, 0.f);
+    for (int c = 0; c < nlist; ++c)
+        if (hoff[c + 1] > hoff[c])
+            std::memcpy(&hv[(size_t)hoff[c] * vs::kDim], vectors + (size_t)offsets[c] * vs::kDim, (size_t)(hoff[c + 1] - hoff[c]) * vs::kDim * sizeof(float));
+    int rc;
+    if ((rc = dev_alloc(&h->d_head_vecs, hv.size())) || (rc = dev_alloc(&h->d_head_norm, nh + 64)) || (rc = dev_alloc(&h->d_head_off, hoff.size())) ||
+        (rc = dev_alloc(&h->d_head_tdelta, tdelta.size())))
+        return rc;
+    HIPCHK(hipMemcpy(h->d_head_vecs, hv.data(), hv.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(h->d_head_norm, 0, (nh + 64) * sizeof(float)));
+    HIPCHK(hipMemcpy(h->d_head_off, hoff.data(), hoff.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_head_tdelta, tdelta.data(), tdelta.size() * 4, hipMemcpyHostToDevice));
+    if (nh > 0) HIPCHK(vs::launch_row_sqnorm(h->d_head_vecs, (int64_t)nh, vs::kDim, h->d_head_norm, nullptr));
+    HIPCHK(hipDeviceSynchronize());
+    if (h->metric != VS_METRIC_L2) return VS_OK;
+    std::vector<int8_t> tb(nt * vs::kDim, 0);
+    std::vector<int32_t> rterm_t(nt, 0);
+    for (int c = 0; c < nlist; ++c)
+        for (int32_t j = 0; j < hoff[c + 1] - hoff[c]; ++j) {
+            const float* src = &hv[((size_t)hoff[c] + j) * vs::kDim];
+            const size_t R = (size_t)hoff[c] + tdelta[c] + j;
+            int8_t* tile = &tb[(R >> 4) * 16 * vs::kDim + (R & 15) * 16];
+            int32_t n2 = 0, sb = 0;
+            for (int e = 0; e < vs::kDim; ++e) {
+                const float x = src[e];
+                const int xi = (int)x;
+                if (!((float)xi == x) || xi < 0 || xi > 255) return VS_OK;  // not byte valued: bounds on the fp32 heads
+                tile[(e >> 6) * 1024 + ((e >> 4) & 3) * 256 + (e & 15)] = (int8_t)(xi - 128);
+                n2 += xi * xi;
+                sb += xi - 128;
+            }
+            rterm_t[R] = n2 - 256 * sb;
+        }
+    if ((rc = dev_alloc(&h->d_head_t8, tb.size())) || (rc = dev_alloc(&h->d_head_rterm_t, nt))) return rc;
+    HIPCHK(hipMemcpy(h->d_head_t8, tb.data(), tb.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_head_rterm_t, rterm_t.data(), nt * 4, hipMemcpyHostToDevice));
+    return VS_OK;
+}
+
 static int ivf_create_impl(const float* vectors, int64_t n_rows, int dim, const float* centroids, int nlist,
                            const int32_t* offsets, const int32_t* r2o, int device, int rank, int world,
                            vs_index** out) {
@@ -1862,10 +1943,12 @@ static int ivf_create_impl(const float* vectors, int64_t n_rows, int dim, const 
             }
         }
     }
+    if (world > 1 && (rc = build_tau_heads(h, vectors, offsets, nlist))) return fail(rc);
     if ((rc = alloc_scratch(h))) return fail(rc);
     // launch groups: an unsharded index takes VSEARCH_IVF_GROUP batches per group (super-batches of 32); a sharded one a
     // slice of up to 32 batches per rank (ivf_shard_front / ivf_shard_back)
     h->ivf_gb = world > 1 ? std::min(kIvfGroupMax, 32 * std::min(world, kIvfShardMaxWorld)) : ivf_group_batches();
+    h->ivf_lanes = ivf_wide_lanes();
     h->ivf_nsb = world > 1 ? std::max(h->ivf_gb / 32, std::min(world, kIvfShardMaxWorld)) : h->ivf_gb / 32;
     if (h->nlist <= vs::kIvfFastNlist && h->n_chunks > 0) {
         // the wide pipeline's scratch (two lanes), streams and host staging now rather than inside the first search:
@@ -2258,8 +2341,9 @@ int vs_ivf_search(vs_index* h, const float* queries_host, int64_t nq, int k, int
         HIPCHK(hipEventRecord(h->wide_fork, h->stream));  // (behind the memset above)
         for (int i = 0; i < 2; ++i) HIPCHK(hipStreamWaitEvent(h->wide_stream[i], h->wide_fork, 0));
         const int64_t group_q = (int64_t)h->ivf_gb * h->batch;
-        const int64_t cap_q = h->ivf_host_cap / group_q * group_q;  // (group_q <= ivf_gb * 32 <= the slots' capacity)
-        const int64_t wchunk = std::min<int64_t>(cap_q, std::max<int64_t>(group_q, (nq / 2 + group_q - 1) / group_q * group_q));
+        const int64_t unit_q = (int64_t)vs::kIvfWideBatches * h->batch;  // a super-batch of queries: chunks are cut at these
+        const int64_t cap_q = h->ivf_host_cap / unit_q * unit_q;
+        const int64_t wchunk = std::min<int64_t>(cap_q, std::max<int64_t>(unit_q, (nq / 2 + unit_q - 1) / unit_q * unit_q));
         int next_lane = 0;
         auto enqueue = [&](vs_index::IvfHostSlot& S, int64_t q0, int64_t n) -> int {
             const double t0 = now_ms();

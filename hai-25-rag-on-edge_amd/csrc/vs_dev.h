@@ -141,6 +141,17 @@ __device__ __forceinline__ void wave_rank_emit(const float* cd, const int* ci, i
     if (flag && lane == 0) *flag = tie;
 }
 
+// Rank by counting: lane e < M holds pair e; returns the number of pairs before it in (dist, id) order (ids are unique).
+__device__ __forceinline__ int wave_rank_count(float d, int id, int M) {
+    int rank = 0;
+    for (int j = 0; j < M; ++j) {
+        const float dj = rdlane_f(d, j);
+        const int ij = __builtin_amdgcn_readlane(id, j);
+        rank += lex_lt(dj, ij, d, id) ? 1 : 0;
+    }
+    return rank;
+}
+
 // partial sums across lanes 1, 2 and 8 apart (DPP: no LDS round trip)
 __device__ __forceinline__ float dpp_add_xor1(float x) {
     return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));

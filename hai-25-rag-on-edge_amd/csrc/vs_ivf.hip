@@ -211,6 +211,7 @@ __global__ __launch_bounds__(256) void ivf_coarse_mfma_kernel(const float* __res
             const int bad = __syncthreads_or(q_ok ? 0 : 1);  // (workgroup-uniform branch: every thread is here)
             if (tid == 0) grp.w_invalid[blockIdx.y] = bad ? 1 : 0;
             if (tid == 0 && blockIdx.y == 0 && grp.w_overflow) grp.w_overflow[0] = 0;  // the previous group's verdict has been read
+            if (tid == 0 && blockIdx.y == 0 && grp.w_glist) grp.w_glist[0] = 0;        // ... and so has its list of left-over queries
         }
     }
     __syncthreads();
@@ -501,15 +502,16 @@ hipError_t launch_ivf_prep_queries(const float* q, int B, const float* cents, co
     return hipGetLastError();
 }
 
-// Sharded back half, first step: one workgroup (a wave) per query of the launch group unpacks what the exchange delivered
+// Sharded back half, first step: one wave per query of the launch group unpacks what the exchange delivered
 // -- the query's probes (to the per-batch slab: the slow path reads them there), its bound and `slow` mark -- and takes a
 // slot in the table of every probed list that is resident HERE (what ivf_pick_kernel does on an unsharded index).
 // gathered: per slice s (= super-batch) a block of blk_words int32: probes [sb_q][nprobe] | tau [sb_q] | slow [sb_q],
 // sb_q = sb_batches * 32 query slots (batch-padded).
-__global__ __launch_bounds__(64) void ivf_fill_kernel(const int32_t* __restrict__ gathered, long long blk_words, int nprobe, int nlist,
-                                                      const int32_t* __restrict__ offsets, int32_t* __restrict__ probes_out,
-                                                      float* __restrict__ tau_out, int32_t* __restrict__ slow_out, IvfGroup grp) {
-    const int b = blockIdx.x, batch = blockIdx.y, lane = threadIdx.x;
+__global__ __launch_bounds__(256) void ivf_fill_kernel(const int32_t* __restrict__ gathered, long long blk_words, int nprobe, int nlist,
+                                                       const int32_t* __restrict__ offsets, int32_t* __restrict__ probes_out,
+                                                       float* __restrict__ tau_out, int32_t* __restrict__ slow_out, IvfGroup grp, int B) {
+    const int b = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6), batch = blockIdx.y, lane = threadIdx.x & 63;  // a wave per query
+    if (b >= B) return;
     const int sb = batch / grp.sb_batches, lb = batch % grp.sb_batches;
     const int sb_q = grp.sb_batches * kMaxBatch;
     const int lq = lb * kMaxBatch + b;  // the query's slot in its slice
@@ -532,8 +534,8 @@ __global__ __launch_bounds__(64) void ivf_fill_kernel(const int32_t* __restrict_
 hipError_t launch_ivf_fill(const int32_t* gathered, long long blk_words, int B, int nprobe, int nlist, const int32_t* offsets,
                            int32_t* probes_out, float* tau_out, int32_t* slow_out, const IvfGroup& grp, hipStream_t s, int n_batches) {
     if (!grp.w_cnt || !grp.w_lq || grp.sb_batches < 1) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(ivf_fill_kernel, dim3(B, n_batches), dim3(64), 0, s, gathered, blk_words, nprobe, nlist, offsets, probes_out, tau_out,
-                       slow_out, grp);
+    hipLaunchKernelGGL(ivf_fill_kernel, dim3((B + 3) / 4, n_batches), dim3(256), 0, s, gathered, blk_words, nprobe, nlist, offsets, probes_out,
+                       tau_out, slow_out, grp, B);
     return hipGetLastError();
 }
 
@@ -1358,7 +1360,7 @@ __global__ __launch_bounds__(256) void ivf_wide_rank_kernel(const MergeParams m,
     __shared__ float cd[kCompactCap];
     __shared__ int ci[kCompactCap];
     if (p.sink.overflow[0] || p.slow[qg]) ivf_wide_slow_body(p, qg, cd, ci);  // workgroup-uniform
-    else merge_compact_body(m, L, cd, ci);
+    else merge_compact_body(m, L, cd, ci, q);
     // Last kernel of the launch group: it leaves the group's counters zeroed for the next group (no memset launch per
     // group).  Every workgroup clears what belongs to its query and a share of the lists' pair counters.
     __syncthreads();
@@ -1380,11 +1382,159 @@ __global__ __launch_bounds__(256) void ivf_wide_rank_kernel(const MergeParams m,
     // per query and cost more than the memset it saves -- measured)
 }
 
-hipError_t launch_ivf_wide_rank(const MergeParams& m, int64_t stride_g, int64_t stride_q, const IvfWideParams& p, hipStream_t s) {
+// The same ranking, four queries per workgroup: one WAVE per query.  A launch group of several super-batches ranks
+// thousands of queries, most of them with a few dozen candidates (a rank of a sharded job holds an eighth of every query's
+// candidates): a 256-thread workgroup per query then costs what its launch costs (42 us per 8192 queries).  A wave
+// gathers its query's candidates (<= 256: four per lane), bounds the k-th best by the k-th smallest lane minimum, and ranks
+// what is not above it by counting.  A query with more candidates, a `slow` mark or an overflowed launch is put on a
+// list (glist: [0] = count, [1..] = output queries) and taken by ivf_wide_rank_list_kernel behind, with the workgroup-wide
+// paths of ivf_wide_rank_kernel -- kept out of this kernel: their registers and LDS would halve its occupancy.
+__global__ __launch_bounds__(256) void ivf_wide_rank4_kernel(const MergeParams m, const IvfWideParams p, int32_t* const glist) {
+    __shared__ float wcd[4 * 256];
+    __shared__ int wci[4 * 256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = (int)blockIdx.x * 4 + wave;  // output query = batch * B + qi
+    if (q >= m.nq) return;
+    const int qg = (q / p.B) * kMaxBatch + q % p.B;
+    const int nsub = p.sink.nsub, cap = p.sink.cap;
+    bool generic = p.sink.overflow[0] != 0 || p.slow[qg] != 0;
+    // the sub-lists' lengths (lanes 0 .. nsub - 1), their running sum, the candidates in all
+    int len = 0;
+    if (lane < nsub) len = min(p.sink.cnt[(int64_t)lane * p.sink.cnt_sub_stride + qg], cap + 1);
+    generic = generic || __any(len > cap);  // (a sub-list that overflowed marks the query `slow` as well)
+    int incl = len;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+        const int t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    const int T = __builtin_amdgcn_readlane(incl, 15);
+    generic = generic || T > 256;
+    if (!generic) {
+        float d[4];
+        int id[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = lane + 64 * u;
+            d[u] = VS_INF;
+            id[u] = 0x7fffffff;
+            if (64 * u < T) {  // wave-uniform
+                int sub = 0, start = 0;
+#pragma unroll
+                for (int s2 = 0; s2 < 16; ++s2) {
+                    const int end = __builtin_amdgcn_readlane(incl, s2);
+                    if (s2 < nsub && end <= e) {
+                        sub = s2 + 1;
+                        start = end;
+                    }
+                }
+                if (e < T) {
+                    const int64_t src = ((int64_t)qg * nsub + sub) * cap + (e - start);
+                    d[u] = m.part_d[src];
+                    id[u] = m.part_i[src];
+                }
+            }
+        }
+        float sd = d[0];
+        int si = id[0];
+        int M = T;
+        if (T > 64) {
+            // bound: the k-th smallest of the 64 lane minima (k distinct candidates are at least that close)
+            float md = d[0];
+            int mi = id[0];
+#pragma unroll
+            for (int u = 1; u < 4; ++u)
+                if (lex_lt(d[u], id[u], md, mi)) {
+                    md = d[u];
+                    mi = id[u];
+                }
+            const int mrank = wave_rank_count(md, mi, 64);
+            const unsigned long long who = __ballot(mrank == min(m.kout, 64) - 1);
+            const float bound = rdlane_f(md, (int)__builtin_ctzll(who | (1ull << 63)));
+            float* wd = wcd + wave * 256;
+            int* wi = wci + wave * 256;
+            M = 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool pass = id[u] != 0x7fffffff && d[u] <= bound;
+                const unsigned long long mask = __ballot(pass);
+                if (pass) {
+                    const int pos = M + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+                    wd[pos] = d[u];
+                    wi[pos] = id[u];
+                }
+                M += __popcll(mask);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (M > 64) generic = true;  // masses of equal distances at the bound
+            sd = lane < M ? wd[lane] : VS_INF;
+            si = lane < M ? wi[lane] : 0x7fffffff;
+        }
+        if (!generic) {
+            const int rank = wave_rank_count(sd, si, min(M, 64));
+            if (lane < M && rank < m.kout) {
+                m.out_d[(int64_t)q * m.kout + rank] = sd;
+                m.out_i[(int64_t)q * m.kout + rank] = m.id_map ? m.id_map[si] : si;
+            }
+            if (lane >= M && lane < m.kout) {
+                m.out_d[(int64_t)q * m.kout + lane] = VS_INF;
+                m.out_i[(int64_t)q * m.kout + lane] = -1;
+            }
+        }
+    }
+    if (generic) {  // (wave-uniform) left to the list kernel, which also clears this query's counters
+        if (lane == 0) glist[1 + atomicAdd(glist, 1)] = q;
+        return;
+    }
+#ifdef VS_STAMPS
+    if (p.diag & 128) return;
+#endif
+    // the group's counters are left zeroed for the next group (see ivf_wide_rank_kernel)
+    if (lane < nsub) p.sink.cnt[(int64_t)lane * p.sink.cnt_sub_stride + qg] = 0;
+    const int batch = q / p.B, sb = batch / p.sb_batches;
+    const int nql = (min(p.n_batches, (sb + 1) * p.sb_batches) - sb * p.sb_batches) * p.B;
+    const int ql = (batch - sb * p.sb_batches) * p.B + q % p.B;
+    for (int c = ql + lane * nql; c < p.nlist; c += 64 * nql)
+        p.zero[sb * ivf_wide_plan_words(p.nlist) + (int64_t)c * kIvfWideCntStride] = 0;
+}
+
+// the queries ivf_wide_rank4_kernel left over: a fixed grid walks the list
+__global__ __launch_bounds__(256) void ivf_wide_rank_list_kernel(const MergeParams m, const MergeLayout L, const IvfWideParams p, int32_t* const glist) {
+    __shared__ float cd[kCompactCap];
+    __shared__ int ci[kCompactCap];
+    const int n = glist[0];
+    const int tid = threadIdx.x;
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        const int q = glist[1 + i];
+        const int qg = (q / p.B) * kMaxBatch + q % p.B;
+        if (p.sink.overflow[0] || p.slow[qg]) ivf_wide_slow_body(p, qg, cd, ci);  // workgroup-uniform
+        else merge_compact_body(m, L, cd, ci, q);
+        __syncthreads();
+#ifdef VS_STAMPS
+        if (p.diag & 128) continue;
+#endif
+        if (tid < p.sink.nsub) p.sink.cnt[(int64_t)tid * p.sink.cnt_sub_stride + qg] = 0;
+        if (tid == 0) p.slow[qg] = 0;
+        const int batch = q / p.B, sb = batch / p.sb_batches;
+        const int nql = (min(p.n_batches, (sb + 1) * p.sb_batches) - sb * p.sb_batches) * p.B;
+        const int ql = (batch - sb * p.sb_batches) * p.B + q % p.B;
+        for (int c = ql + (tid & 63) * nql; c < p.nlist; c += 64 * nql)
+            p.zero[sb * ivf_wide_plan_words(p.nlist) + (int64_t)c * kIvfWideCntStride] = 0;
+        __syncthreads();
+    }
+}
+
+hipError_t launch_ivf_wide_rank(const MergeParams& m, int64_t stride_g, int64_t stride_q, const IvfWideParams& p, hipStream_t s, int32_t* glist) {
     if (m.kout < 1 || m.G < 1 || m.nq != p.n_batches * p.B || (int64_t)m.G * m.kin > kCompactCap || m.q_group_out != p.B || m.q_group_in != kMaxBatch)
         return hipErrorInvalidValue;
     MergeLayout L{stride_g, stride_q};
-    hipLaunchKernelGGL(ivf_wide_rank_kernel, dim3(m.nq), dim3(256), 0, s, m, L, p);
+    // a wave per query where a launch ranks thousands of queries (several super-batches); a workgroup per query otherwise
+    if (glist && m.nq > 2048 && m.G <= 16 && m.flat_len && m.flat_len_sub_stride && !m.flags && !m.tau_out && !m.invalid && !m.run_if) {
+        hipLaunchKernelGGL(ivf_wide_rank4_kernel, dim3((m.nq + 3) / 4), dim3(256), 0, s, m, p, glist);
+        hipLaunchKernelGGL(ivf_wide_rank_list_kernel, dim3(256), dim3(256), 0, s, m, L, p, glist);
+    }
+    else hipLaunchKernelGGL(ivf_wide_rank_kernel, dim3(m.nq), dim3(256), 0, s, m, L, p);
     return hipGetLastError();
 }
 

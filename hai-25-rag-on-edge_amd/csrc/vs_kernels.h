@@ -251,6 +251,7 @@ struct IvfGroup {
     int32_t* w_qterm;                // [n_batches][32]
     int32_t* w_invalid;              // [n_batches]: a query of the batch is not byte valued (written as 0 or 1)
     int32_t* w_overflow;             // [1]: cleared (the wide pipeline's candidate-buffer overflow word)
+    int32_t* w_glist;                // [1]: cleared (count of the ranking's left-over list, see launch_ivf_wide_rank)
     // the pick kernel also enters every (query, probe) pair in its list's slot table
     int32_t* w_cnt;                  // [n_sb][ivf_wide_plan_words] pair counters (pre-set to 0), list c's at word c * kIvfWideCntStride
     int32_t* w_lq;                   // [n_sb][nlist][w_q] slots: 128 * (slot of the query in its super-batch)
@@ -331,7 +332,10 @@ hipError_t launch_ivf_wide_scan(const IvfWideParams& p, int num_cus, hipStream_t
 int ivf_wide_grid_x(int num_cus, int n_sb);  // grid.x of the scan
 int ivf_wide_waves(int num_cus, int n_sb);   // its waves = candidate buffers
 // merge of the candidate lists (flat layout, see launch_merge_layout) or the exact slow path, per query
-hipError_t launch_ivf_wide_rank(const MergeParams& m, int64_t stride_g, int64_t stride_q, const IvfWideParams& p, hipStream_t s);
+// glist (optional): 1 + queries int32 words; with it launches of more than 2048 queries rank one query per wave and leave the
+// few that need a workgroup to a second launch (the list's count, word 0, is cleared by the next group's coarse / prep kernel)
+hipError_t launch_ivf_wide_rank(const MergeParams& m, int64_t stride_g, int64_t stride_q, const IvfWideParams& p, hipStream_t s,
+                                int32_t* glist = nullptr);
 
 struct IvfScanParams {
     const float* vecs;        // [n_rows][128] cluster-reordered (vectors_reordered.npy)

@@ -67,13 +67,13 @@ __device__ __forceinline__ void wave_rank_and_emit(const MergeParams& p, int q, 
 }
 
 // (cd, ci: kCompactCap words of LDS each, from the kernel)
-__device__ __forceinline__ void merge_compact_body(const MergeParams& p, const MergeLayout& L, float* const cd, int* const ci) {
+__device__ __forceinline__ void merge_compact_body(const MergeParams& p, const MergeLayout& L, float* const cd, int* const ci, const int q) {
     __shared__ int cnt;
     __shared__ float wbd[4];
     __shared__ int wbi[4];
     __shared__ int wbp[4];
     __shared__ float outd[kMergeTrack];
-    const int q = blockIdx.x;  // output query; input lists may be grouped in padded batches
+    // (q: the output query; input lists may be grouped in padded batches)
     const int q_in = p.q_group_out > 0 ? (q / p.q_group_out) * p.q_group_in + (q % p.q_group_out) : q;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;

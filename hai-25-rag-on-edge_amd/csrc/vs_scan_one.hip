@@ -62,17 +62,6 @@ __device__ __forceinline__ void wave_rank_rounds(int M, int rounds, int lane, Ge
     }
 }
 
-// Rank by counting: lane e < M holds pair e; returns the number of pairs before it in (dist, id) order (ids are unique).
-__device__ __forceinline__ int wave_rank_count(float d, int id, int M) {
-    int rank = 0;
-    for (int j = 0; j < M; ++j) {
-        const float dj = rdlane_f(d, j);
-        const int ij = __builtin_amdgcn_readlane(id, j);
-        rank += lex_lt(dj, ij, d, id) ? 1 : 0;
-    }
-    return rank;
-}
-
 }  // namespace
 
 #ifdef VS_STAMPS

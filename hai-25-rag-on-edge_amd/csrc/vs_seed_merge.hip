@@ -405,7 +405,7 @@ static hipError_t launch_merge_heads(const MergeParams& p, const MergeLayout& L,
 __global__ __launch_bounds__(256) void merge_compact_kernel(const MergeParams p, const MergeLayout L) {
     __shared__ float cd[kCompactCap];
     __shared__ int ci[kCompactCap];
-    merge_compact_body(p, L, cd, ci);
+    merge_compact_body(p, L, cd, ci, blockIdx.x);
 }
 
 hipError_t launch_merge_layout(const MergeParams& p, int64_t stride_g, int64_t stride_q, hipStream_t s) {
