@@ -150,6 +150,9 @@ def lib():
         "vs_bf_search_sharded": (i32, [vp, vp, vp, i64, i32, vp, vp, C.POINTER(Timing)]),
         "vs_ivf_search_sharded": (i32, [vp, vp, vp, i64, i32, i32, vp, vp, C.POINTER(i64), C.POINTER(Timing)]),
         "vs_ivf_search_dev_sharded": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp]),
+        "vs_ivf_shard_group": (i32, [i32]),
+        "vs_ivf_shard_slice": (i32, [i32, i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
+        "vs_ivf_shard_block_words": (i64, [i32, i32]),
         "vs_ivf_search_dev_vshards": (i32, [C.POINTER(vp), i32, vp, i32, i32, i32, i32, vp, vp, C.POINTER(C.c_double), vp]),
         "vs_q8_create": (i32, [vp, i64, i32, C.POINTER(Q8Encodings), i32, i64, C.POINTER(vp)]),
         "vs_q8_destroy": (None, [vp]),
@@ -606,6 +609,33 @@ def ivf_list_owners(cluster_offsets, world: int) -> np.ndarray:
     out = np.empty(len(off) - 1, dtype=np.int32)
     _check(lib().vs_ivf_list_owners(_p(off), len(off) - 1, world, _p(out)))
     return out
+
+
+class ProbeBlockLayout:
+    """The block a rank contributes to the exchange between the two halves of the cluster-sharded IVF pipeline
+    (vs_ivf_search_dev_sharded): for the `sbb * 32` query slots of its slice (batches padded to 32 queries),
+    probes [slots][nprobe] int32 | bounds [slots] f32 bits | slow marks [slots] int32."""
+
+    def __init__(self, n_batches: int, world: int, nprobe: int):
+        self.world, self.nprobe = world, nprobe
+        sbb, b0, nbs = C.c_int(), C.c_int(), C.c_int()
+        _check(lib().vs_ivf_shard_slice(n_batches, world, 0, C.byref(sbb), C.byref(b0), C.byref(nbs)))
+        self.sbb = sbb.value
+        self.slots = self.sbb * 32
+        self.words = int(lib().vs_ivf_shard_block_words(self.sbb, nprobe))
+        self.tau_offset = self.slots * nprobe
+        self.slow_offset = self.tau_offset + self.slots
+        self.n_batches = n_batches
+
+    def slice_of(self, rank: int):
+        """(first batch, batches) of `rank`'s own slice."""
+        sbb, b0, nbs = C.c_int(), C.c_int(), C.c_int()
+        _check(lib().vs_ivf_shard_slice(self.n_batches, self.world, rank, C.byref(sbb), C.byref(b0), C.byref(nbs)))
+        return b0.value, nbs.value
+
+    def slot(self, batch: int, b: int):
+        """(slice, slot in the slice's block) of query b of batch `batch` of the group."""
+        return batch // self.sbb, (batch % self.sbb) * 32 + b
 
 
 class GatherLayout:

@@ -1063,6 +1063,12 @@ int ivf_group_wide_dev(vs_index* h, int lane, const float* q_dev, int nb, int B,
 // per launch group is therefore what an unsharded index does for ONE slice, except the ranking (all queries, an eighth of
 // the candidates each).
 long long ivf_block_words(int sbb, int nprobe) { return (long long)sbb * 32 * (nprobe + 2); }
+// slice of `rank` in a launch group of nb batches on `world` ranks: sbb batches per slice, its own [b0, b0 + nbs)
+void ivf_slice(int nb, int world, int rank, int& sbb, int& b0, int& nbs) {
+    sbb = (nb + world - 1) / world;
+    b0 = rank * sbb;
+    nbs = std::max(0, std::min(sbb, nb - b0));
+}
 
 // front half on rank h->rank: prepares ALL queries of the group (bytes, terms, norms: the scan needs them for every
 // slice), scores its own slice [b0, b0 + nbs) and writes the slice's block to `blk`
@@ -1732,6 +1738,30 @@ int vs_ivf_list_owners(const int32_t* cluster_offsets, int nlist, int world, int
     for (int i = 0; i < nlist; ++i) owner_out[order[i]] = i % world;
     return VS_OK;
 }
+
+int vs_ivf_shard_group(int world) {
+    if (world < 1) return 0;
+    return world > 1 ? std::min(kIvfGroupMax, 32 * std::min(world, kIvfShardMaxWorld)) : kIvfGroupDefault;
+}
+
+int vs_ivf_shard_slice(int n_batches, int world, int rank, int32_t* slice_batches, int32_t* first_batch, int32_t* own_batches) {
+    if (n_batches < 1 || world < 1 || rank < 0 || rank >= world || !slice_batches || !first_batch || !own_batches) {
+        set_error("vs_ivf_shard_slice: bad arguments");
+        return VS_ERR_INVALID;
+    }
+    int sbb, b0, nbs;
+    ivf_slice(n_batches, world, rank, sbb, b0, nbs);
+    if (sbb > vs::kIvfWideBatches) {
+        set_error("vs_ivf_shard_slice: more than 32 batches per slice (a launch group holds at most vs_ivf_shard_group(world) batches)");
+        return VS_ERR_INVALID;
+    }
+    *slice_batches = sbb;
+    *first_batch = b0;
+    *own_batches = nbs;
+    return VS_OK;
+}
+
+int64_t vs_ivf_shard_block_words(int slice_batches, int nprobe) { return ivf_block_words(slice_batches, nprobe); }
 
 // the replicated heads of a sharded index (see vs_index::d_head_vecs): rows [offsets[c], offsets[c] + min(len, kIvfTauRows))
 // of every list of the WHOLE index, fp32 packed + (when every head row is byte valued) the tiled byte copy
@@ -2816,7 +2846,8 @@ int vs_ivf_search_dev_sharded(vs_index* h, vs_comm* c, const float* queries_dev,
         Grp G;
         G.b0 = g * gb;
         G.nb = std::min(gb, n_batches - G.b0);
-        G.sbb = (G.nb + world - 1) / world;  // batches per slice (<= 32)
+        int b0_, nbs_;
+        ivf_slice(G.nb, world, 0, G.sbb, b0_, nbs_);  // batches per slice (<= 32)
         return G;
     };
     const int n_groups = (n_batches + gb - 1) / gb;
@@ -2850,7 +2881,8 @@ int vs_ivf_search_dev_sharded(vs_index* h, vs_comm* c, const float* queries_dev,
     for (int g = 0; g < n_groups; ++g) {
         const Grp G = group_of(g);
         const int lane = g & 1;
-        const int sb0 = c->rank * G.sbb, nbs = std::max(0, std::min(G.sbb, G.nb - sb0));
+        int sbb_, sb0, nbs;
+        ivf_slice(G.nb, world, c->rank, sbb_, sb0, nbs);
         // (lane's scratch and block buffers: group g - 2's back half is behind on this stream, its exchange was waited for there)
         if ((rc = ivf_shard_front(h, lane, queries_dev + (size_t)G.b0 * B * vs::kDim, G.nb, G.sbb, sb0, nbs, B, k, nprobe, c->d_blk[lane], user)))
             return rc;
@@ -2913,12 +2945,13 @@ int vs_ivf_search_dev_vshards(vs_index* const* shards, int G, const float* queri
             for (int r = 0; r < G; ++r) rank_ms[r] = 0;
         }
         for (int b0 = 0; b0 < n_batches && !rc; b0 += gb) {
-            const int nb = std::min(gb, n_batches - b0), sbb = (nb + G - 1) / G;
+            const int nb = std::min(gb, n_batches - b0), sbb = (nb + G - 1) / G;  // (= ivf_slice's)
             const float* q = queries_dev + (size_t)b0 * B * vs::kDim;
             const size_t n = (size_t)nb * B, words = 2 * n * k;
             const long long bw = ivf_block_words(sbb, nprobe);
             for (int r = 0; r < G && !rc; ++r) {
-                const int sb0 = r * sbb, nbs = std::max(0, std::min(sbb, nb - sb0));
+                int sbb_, sb0, nbs;
+                ivf_slice(nb, G, r, sbb_, sb0, nbs);
                 if (rank_ms) HIPCHK(hipEventRecord(ev[4 * r], s));
                 rc = ivf_shard_front(shards[r], 0, q, nb, sbb, sb0, nbs, B, k, nprobe, h0->vsh_blk + (size_t)r * bw, s);
                 if (rank_ms) HIPCHK(hipEventRecord(ev[4 * r + 1], s));

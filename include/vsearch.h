@@ -315,6 +315,14 @@ VS_API int vs_ivf_search_dev_sharded(vs_index* h, vs_comm* c, const float* queri
  * Virtual ranks: the same pipeline for G shards (vs_ivf_create / vs_ivf_load with rank r, world G) on ONE device, driven
  * by the calling thread, the collectives replaced by writing into the gathered layout.  For tests and for measuring
  * a rank's cost per launch group on one GPU: rank_ms[r] (optional, G doubles) = device time of rank r's two halves. */
+/* Host-side arithmetic of the sliced pipeline (no device needed).  vs_ivf_shard_group: batches per launch group of an index
+ * created with `world`.  vs_ivf_shard_slice: a group of n_batches batches is cut into `world` slices of *slice_batches
+ * batches (the last ones may be short or empty); rank's own slice is [*first_batch, *first_batch + *own_batches).
+ * vs_ivf_shard_block_words: 32-bit words of the block a rank contributes to the exchange between the two halves:
+ * probes [slice_batches * 32][nprobe] (int32, batch padded) | bounds [slice_batches * 32] (f32) | slow marks [.. * 32]. */
+VS_API int vs_ivf_shard_group(int world);
+VS_API int vs_ivf_shard_slice(int n_batches, int world, int rank, int32_t* slice_batches, int32_t* first_batch, int32_t* own_batches);
+VS_API int64_t vs_ivf_shard_block_words(int slice_batches, int nprobe);
 VS_API int vs_ivf_search_dev_vshards(vs_index* const* shards, int G, const float* queries_dev, int n_batches, int B, int k,
                                      int nprobe, int32_t* ids_dev, float* dists_dev, double* rank_ms, void* stream);
 

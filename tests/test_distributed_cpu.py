@@ -39,7 +39,9 @@ def _worker(rank, world, port, mode, out_dir):
         queries = pkg.synth_sift(nq, seed=32)
         lay = pkg.GatherLayout(S, B, K)
         loc = np.zeros(lay.words, dtype=np.int32)
-        if mode == "rows":
+        if mode == "sliced":
+            pass  # (below: it needs the exchange of the slices' blocks first)
+        elif mode == "rows":
             b = pkg.row_shard_bounds(n, world)
             r0, r1 = int(b[rank]), int(b[rank + 1])
             shard = pkg.synth_sift(r1 - r0, seed=31, row_begin=r0)
@@ -69,6 +71,45 @@ def _worker(rank, world, port, mode, out_dir):
                 dd = np.where(ids >= 0, dd, np.inf).astype(np.float32)
                 loc[lay.dist_offset(s):lay.dist_offset(s) + B * K] = dd.view(np.int32).ravel()
                 loc[lay.id_offset(s):lay.id_offset(s) + B * K] = ids.ravel()
+        if mode == "sliced":
+            # The cluster-sharded pipeline's protocol (vs_ivf_search_dev_sharded), the kernels restated with numpy: rank r runs
+            # the per-query stages of ITS slice only -- coarse scores, the nprobe nearest lists -- packs them into its block
+            # (ProbeBlockLayout: probes | bounds | slow marks), ONE all-gather exchanges the blocks, every rank then scans its
+            # resident lists for the queries of ALL slices, and the second all-gather + merge finish the group.
+            nlist, nprobe, nb = 24, 8, S
+            rng = np.random.default_rng(5)
+            cents = base[rng.choice(n, nlist, replace=False)]
+            d = (base ** 2).sum(1)[:, None] - 2 * base @ cents.T + (cents ** 2).sum(1)[None]
+            vr, off, r2o = pkg.ivf_layout_from_assignment(base, d.argmin(1), nlist)
+            owner = pkg.ivf_list_owners(off, world)
+            blk = pkg.ProbeBlockLayout(nb, world, nprobe)
+            b0, nbs = blk.slice_of(rank)
+            mine = np.zeros(blk.words, dtype=np.int32)
+            mine[:blk.tau_offset] = -1
+            for lb in range(nbs):
+                q = queries[(b0 + lb) * B:(b0 + lb + 1) * B].astype(np.float64)
+                cd = (cents.astype(np.float64) ** 2).sum(1)[None] - 2 * q @ cents.astype(np.float64).T
+                pr = np.argsort(cd, axis=1, kind="stable")[:, :nprobe].astype(np.int32)
+                mine[lb * 32 * nprobe:(lb * 32 + B) * nprobe] = pr.ravel()
+                mine[blk.tau_offset + lb * 32:blk.tau_offset + lb * 32 + B] = np.float32(np.inf).view(np.int32)  # (no bound: everything is a candidate)
+            blocks = torch.zeros(world * blk.words, dtype=torch.int32)
+            dist.all_gather_into_tensor(blocks, torch.from_numpy(mine))     # exchange between the two halves
+            blocks = blocks.numpy().reshape(world, blk.words)
+            for s in range(S):
+                for b in range(B):
+                    sl, slot = blk.slot(s, b)
+                    pr = blocks[sl, slot * nprobe:(slot + 1) * nprobe]
+                    assert (pr >= 0).all() and blocks[sl, blk.slow_offset + slot] == 0
+                    rows = np.concatenate([np.arange(off[c], off[c + 1]) for c in pr if owner[c] == rank] or [np.zeros(0, int)]).astype(int)
+                    ex = oracle.exact_int_dists(queries[s * B + b:s * B + b + 1], vr[rows])[0] if len(rows) else np.zeros(0)
+                    order = np.argsort(ex, kind="stable")[:K]
+                    dd = np.full(K, np.inf, dtype=np.float32)
+                    ii = np.full(K, -1, dtype=np.int32)
+                    dd[:len(order)] = ex[order]
+                    ii[:len(order)] = r2o[rows[order]]
+                    o = lay.dist_offset(s) + b * K
+                    loc[o:o + K] = dd.view(np.int32)
+                    loc[lay.id_offset(s) + b * K:lay.id_offset(s) + (b + 1) * K] = ii
         gath = torch.zeros(world * lay.words, dtype=torch.int32)
         dist.all_gather_into_tensor(gath, torch.from_numpy(loc))       # the ONE data-path collective
         md, mi = lay.merge_reference(gath.numpy().reshape(world, lay.words), K)
@@ -78,7 +119,7 @@ def _worker(rank, world, port, mode, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["rows", "lists"])
+@pytest.mark.parametrize("mode", ["rows", "lists", "sliced"])
 def test_two_rank_gloo_shards_merge_to_unsharded(mode, tmp_path):
     sys.path.insert(0, ROOT)
     import __graft_entry__ as ge
@@ -107,6 +148,10 @@ def test_two_rank_gloo_shards_merge_to_unsharded(mode, tmp_path):
         d = (base ** 2).sum(1)[:, None] - 2 * base @ cents.T + (cents ** 2).sum(1)[None]
         vr, off, r2o = pkg.ivf_layout_from_assignment(base, d.argmin(1), nlist)
         ids, dd, _ = oracle.ivf_search(vr, off, r2o, cents, queries, k + 1, 8)
+        same = np.array([np.array_equal(z["d"][q], dd[q]) for q in range(nq)])
+        if mode == "sliced":  # (float64 coarse scores in the test's restatement: a last-bit coarse tie may pick another list)
+            assert same.mean() >= 0.97
+            return
         assert np.array_equal(z["d"], dd)
         for q in range(nq):  # equal distances may order ids differently (position vs original id)
             assert sorted(z["i"][q].tolist()) == sorted(ids[q].tolist())
@@ -132,3 +177,17 @@ def test_shard_bookkeeping(pkg=None):
         assert np.bincount(own, minlength=world).max() - np.bincount(own, minlength=world).min() <= 1
     lay = pkg.GatherLayout(16, 32, 6)
     assert lay.words == 2 * 16 * 32 * 6 and lay.stride_g == lay.words and lay.ids_offset == 16 * 32 * 6
+    # slices of the cluster-sharded pipeline: `world` equal slices of <= 32 batches cover a launch group exactly once
+    L = pkg.lib()
+    assert L.vs_ivf_shard_group(8) == 256 and L.vs_ivf_shard_group(2) == 64 and L.vs_ivf_shard_group(16) == 256
+    for world in (2, 3, 8, 16):
+        for nb in sorted({1, world - 1, world, 31, min(70, 32 * world), L.vs_ivf_shard_group(world)}):
+            blk = pkg.ProbeBlockLayout(nb, world, 32)
+            assert 1 <= blk.sbb <= 32 and blk.words == blk.sbb * 32 * 34
+            cover = []
+            for r in range(world):
+                b0, nbs = blk.slice_of(r)
+                assert 0 <= nbs <= blk.sbb
+                cover += list(range(b0, b0 + nbs))
+            assert cover == list(range(nb))
+            assert blk.slot(nb - 1, 5) == ((nb - 1) // blk.sbb, ((nb - 1) % blk.sbb) * 32 + 5)
