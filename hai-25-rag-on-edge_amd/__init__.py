@@ -150,6 +150,7 @@ def lib():
         "vs_bf_search_sharded": (i32, [vp, vp, vp, i64, i32, vp, vp, C.POINTER(Timing)]),
         "vs_ivf_search_sharded": (i32, [vp, vp, vp, i64, i32, i32, vp, vp, C.POINTER(i64), C.POINTER(Timing)]),
         "vs_ivf_search_dev_sharded": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp]),
+        "vs_bf_search_vshards": (i32, [C.POINTER(vp), i32, vp, i64, i32, vp, vp, C.POINTER(Timing)]),
         "vs_ivf_shard_group": (i32, [i32]),
         "vs_ivf_shard_slice": (i32, [i32, i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
         "vs_ivf_shard_block_words": (i64, [i32, i32]),
@@ -350,6 +351,19 @@ class BruteForceIndex(_Index):
                          flags_ptr: int, stream: int):
         """n_batches consecutive batches of B queries, pipelined over internal streams (vs_bf_search_dev_multi)."""
         _check(lib().vs_bf_search_dev_multi(self._h, q_ptr, n_batches, B, k, ids_ptr, dists_ptr, flags_ptr, stream))
+
+    @staticmethod
+    def search_vshards(shards, queries: np.ndarray, k: int, timing: "Timing | None" = None):
+        """vs_bf_search_vshards: row shards of one base on ONE device (shards[g] = BruteForceIndex(rows of g, id_offset=first row))
+        -> the reference's answer, tie order and fp32 rerun included, as vs_bf_search gives on the unsharded base."""
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        nq = q.shape[0]
+        ids = np.empty((nq, k), dtype=np.int32)
+        dists = np.empty((nq, k), dtype=np.float32)
+        arr = (C.c_void_p * len(shards))(*[s._h for s in shards])
+        _check(lib().vs_bf_search_vshards(arr, len(shards), q.ctypes.data, nq, k, ids.ctypes.data, dists.ctypes.data,
+                                          C.byref(timing) if timing is not None else None))
+        return ids, dists
 
     def search_dev_sharded(self, comm: "Comm", q_ptr: int, n_batches: int, B: int, k: int, ids_ptr: int, dists_ptr: int,
                            flags_ptr: int, stream: int):

@@ -166,6 +166,10 @@ struct vs_index {
     int8_t* d_head_t8 = nullptr;       // byte-valued heads: 16-row tiles, every list padded to a multiple of 16 rows
     int32_t* d_head_rterm_t = nullptr;
     int32_t* d_head_tdelta = nullptr;  // [nlist] padded row - row
+    int32_t* d_sh = nullptr;           // sharded brute force, host-buffer calls: the gathered scratch of the owner (see ShBuf)
+    size_t sh_words = 0;
+    float* d_sh_row = nullptr;         // ... and full distance rows (tie fallback)
+    size_t sh_row_words = 0;
     int32_t* vsh_blk = nullptr;        // virtual ranks (vs_ivf_search_dev_vshards): the gathered blocks / top-k lists, owned by shard 0
     int32_t* vsh_loc = nullptr;
     size_t vsh_loc_words = 0;
@@ -279,7 +283,7 @@ void free_all(vs_index* h) {
                     h->d_out_d, h->d_out_i,
                     h->d_flags, h->d_scores, h->d_probes, h->d_ipart_d, h->d_ipart_i, h->d_cand,
                     h->d_chunk_list, h->d_chunk_row0, h->d_chunk_rows, h->vsh_blk, h->vsh_loc,
-                    h->d_head_vecs, h->d_head_norm, h->d_head_off, h->d_head_t8, h->d_head_rterm_t, h->d_head_tdelta};
+                    h->d_head_vecs, h->d_head_norm, h->d_head_off, h->d_head_t8, h->d_head_rterm_t, h->d_head_tdelta, h->d_sh, h->d_sh_row};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     {
@@ -2639,18 +2643,18 @@ int sharded_groups(vs_index* h, vs_comm* c, int n_batches, int B, int kin, int k
         set_error("index and communicator live on different devices");
         return VS_ERR_INVALID;
     }
-    int rc = comm_reserve(c, (size_t)2 * kMaxMulti * 32 * kin);
+    int rc = comm_reserve(c, (size_t)(2 * kin + 1) * kMaxMulti * 32);
     if (rc) return rc;
     int g = 0;
     for (int b0 = 0; b0 < n_batches; b0 += kMaxMulti, ++g) {
         const int nb = std::min(kMaxMulti, n_batches - b0);
         const int buf = g & 1;
         const size_t n = (size_t)nb * B;         // queries of the group
-        const size_t words = 2 * n * kin;        // per rank
+        const size_t words = 2 * n * kin + (flags_dev ? n : 0);  // per rank: dists | ids | (brute force) the shard's own flags
         if (c->coll_used[buf]) HIPCHK(hipStreamWaitEvent(user, c->ev_coll[buf], 0));  // group g - 2 is done with the buffers
         float* loc_d = reinterpret_cast<float*>(c->d_loc[buf]);
         int32_t* loc_i = c->d_loc[buf] + n * kin;
-        if ((rc = local(b0, nb, loc_d, loc_i, user))) return rc;
+        if ((rc = local(b0, nb, loc_d, loc_i, c->d_loc[buf] + 2 * n * kin, user))) return rc;
         HIPCHK(hipEventRecord(c->ev_scan[buf], user));
         HIPCHK(hipStreamWaitEvent(c->s_coll, c->ev_scan[buf], 0));
         const int32_t* src = c->d_loc[buf];
@@ -2669,6 +2673,10 @@ int sharded_groups(vs_index* h, vs_comm* c, int n_batches, int B, int kin, int k
         m.out_i = ids_dev + (size_t)b0 * B * kout;
         m.flags = flags_dev ? flags_dev + (size_t)b0 * B : nullptr;
         m.flag_empty = 1;
+        if (flags_dev) {  // a shard that skipped a batch (int8 rows, non-byte query) must not go unnoticed: its rows are missing
+            m.shard_flags = src + 2 * n * kin;
+            m.shard_flags_stride = (int64_t)words;
+        }
         HIPCHK(vs::launch_merge_layout(m, (int64_t)words, kin, c->s_coll));
         HIPCHK(hipEventRecord(c->ev_coll[buf], c->s_coll));
         c->coll_used[buf] = true;
@@ -2775,9 +2783,10 @@ int vs_bf_search_dev_sharded(vs_index* h, vs_comm* c, const float* queries_dev, 
     }
     hipStream_t user = static_cast<hipStream_t>(stream);
     if ((rc = order_begin(h, user))) return rc;
+    if (!flags_dev && n_batches <= kMaxMulti) flags_dev = h->d_flags;  // (the shards' flags travel whenever there is room to merge them)
     rc = sharded_groups(h, c, n_batches, B, k1, k1, ids_dev, dists_dev, flags_dev, nullptr, user,
-                        [&](int b0, int nb, float* loc_d, int32_t* loc_i, hipStream_t s) {
-                            return bf_launch(h, h->lane[0], queries_dev + (size_t)b0 * B * vs::kDim, nb, B, k1, loc_d, loc_i, h->d_flags, s);
+                        [&](int b0, int nb, float* loc_d, int32_t* loc_i, int32_t* loc_f, hipStream_t s) {
+                            return bf_launch(h, h->lane[0], queries_dev + (size_t)b0 * B * vs::kDim, nb, B, k1, loc_d, loc_i, loc_f, s);
                         });
     return rc ? rc : order_end(h, user);
 }
@@ -2813,7 +2822,7 @@ int vs_ivf_search_dev_sharded(vs_index* h, vs_comm* c, const float* queries_dev,
     if (!sliced) {
         // every rank runs the whole pipeline on its own lists, one all-gather of top-k lists per launch group
         rc = sharded_groups(h, c, n_batches, B, k, k, ids_dev, dists_dev, nullptr, nullptr, user,
-                            [&](int b0, int nb, float* loc_d, int32_t* loc_i, hipStream_t s) -> int {
+                            [&](int b0, int nb, float* loc_d, int32_t* loc_i, int32_t*, hipStream_t s) -> int {
                                 return ivf_multi_dev(h, queries_dev + (size_t)b0 * B * vs::kDim, nb, B, k, nprobe, loc_d, loc_i, s);
                             });
         return rc ? rc : order_end(h, user);
@@ -2991,59 +3000,366 @@ int vs_ivf_search_dev_vshards(vs_index* const* shards, int G, const float* queri
 
 // Host-buffer forms of the sharded searches (what the CLIs call with --gpus N): every rank passes the same queries and
 // receives the same merged result.  Chunks of kMaxMulti batches: upload, vs_*_search_dev_sharded, download.
+}  // extern "C"
+
+namespace {
+
+// ---- brute force over row shards, host buffers in, the reference's answer out (cpu_baseline.cpp:127-153 tie order included).
+// The shards this process drives are either ONE shard of a collective job (comm: the other ranks run the same code, the
+// exchanges are RCCL all-gathers) or ALL G shards on one device (virtual ranks: an exchange is a no-op, every shard has
+// written its part of the gathered buffer in place).  Everything else -- per-shard device steps, merge, host replay -- is
+// the same code.  Shards are contiguous row ranges in rank order (vs_bf_create(rows of the shard, id_offset = first row)).
+struct BfShards {
+    std::vector<vs_index*> hs;  // the shards driven here; hs[i] is global shard first + i
+    int G = 1, first = 0;
+    vs_comm* c = nullptr;
+    vs_index* owner() const { return hs[0]; }
+    hipStream_t s() const { return hs[0]->stream; }
+    int exchange(int32_t* buf, size_t words) const {  // buf = [G][words], this process's parts in place
+        if (!c || c->world == 1) return VS_OK;
+        NCCLCHK(rccl().AllGather(buf + (size_t)c->rank * words, buf, words, ncclInt32, c->comm, s()));
+        return VS_OK;
+    }
+};
+
+constexpr size_t kShPackWords = 32 + (size_t)2 * 32 * kTieCap;  // filter output of one shard: cnt [32] | rows [32][kTieCap] | dists [32][kTieCap]
+
+// gathered scratch of the owner: main [G][main] | tau [G][32] | dense [G][32 * kTieDense] | pack [G][kShPackWords] | meta [G][2]
+struct ShBuf {
+    int32_t *main, *tau, *dense, *pack, *meta;
+    size_t main_words;
+};
+int sh_reserve(vs_index* o, int G, int k1, ShBuf& B) {
+    const size_t main_words = (size_t)(2 * k1 + 1) * kMaxMulti * 32;
+    const size_t total = (size_t)G * (main_words + 32 + (size_t)32 * kTieDense + kShPackWords + 2);
+    if (o->sh_words < total) {
+        HIPCHK(hipDeviceSynchronize());
+        if (o->d_sh) (void)hipFree(o->d_sh);
+        o->d_sh = nullptr;
+        o->sh_words = 0;
+        int rc = dev_alloc(&o->d_sh, total);
+        if (rc) return rc;
+        o->sh_words = total;
+    }
+    B.main_words = main_words;
+    B.main = o->d_sh;
+    B.tau = B.main + (size_t)G * main_words;
+    B.dense = B.tau + (size_t)G * 32;
+    B.pack = B.dense + (size_t)G * 32 * kTieDense;
+    B.meta = B.pack + (size_t)G * kShPackWords;
+    return VS_OK;
+}
+
+// exact select_topk for the flagged queries of a sharded search (see resolve_ties for the single-shard form and why a
+// row-ordered superset of the rows that change the slot buffer suffices): the dense prefix is shard 0's first rows, its
+// k-th smallest distance bounds the buffer maximum for every later row of every shard, each shard filters its rows under
+// that bound, and the host replays "dense rows, then the shards' candidates in row order".
+int resolve_ties_shards(const BfShards& S, const ShBuf& Bf, const std::vector<int32_t>& meta /*[G][2] rows, id_offset*/,
+                        const float* queries_host, const std::vector<int64_t>& flagged, int k, int32_t* ids, float* dists) {
+    vs_index* o = S.owner();
+    hipStream_t st = S.s();
+    const int G = S.G;
+    const int64_t L0 = std::min<int64_t>(meta[0], kTieDense);
+    const int64_t L0p = (L0 + 15) & ~int64_t(15);
+    for (int g = 1; g < G; ++g)
+        if ((int64_t)meta[2 * g + 1] != (int64_t)meta[2 * (g - 1) + 1] + meta[2 * (g - 1)]) {
+            set_error("sharded tie order needs shards that are contiguous row ranges in rank order");
+            return VS_ERR_UNSUPPORTED;
+        }
+    std::vector<float> qbuf((size_t)32 * vs::kDim), dense((size_t)32 * L0p);
+    std::vector<int32_t> cnt((size_t)G * 32), rows;
+    std::vector<float> cds;
+    int rc;
+    for (size_t f0 = 0; f0 < flagged.size(); f0 += 32) {
+        const int B = (int)std::min<size_t>(32, flagged.size() - f0);
+        for (int b = 0; b < B; ++b)
+            std::memcpy(&qbuf[(size_t)b * vs::kDim], queries_host + flagged[f0 + b] * vs::kDim, vs::kDim * sizeof(float));
+        HIPCHK(hipMemcpyAsync(o->d_q, qbuf.data(), (size_t)B * vs::kDim * sizeof(float), hipMemcpyHostToDevice, st));
+        float* tau0 = reinterpret_cast<float*>(Bf.tau);        // shard 0's part: the bound every shard filters with
+        float* dense0 = reinterpret_cast<float*>(Bf.dense);    // shard 0's part: [B][L0p]
+        if (S.first == 0) {
+            vs_index* h0 = S.hs[0];
+            if ((rc = scores_dev(h0, h0->d_vecs, h0->d_norm, L0, o->d_q, B, dense0, L0p, st))) return rc;
+            HIPCHK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(tau0), 0xff800000u, 32, st));  // -inf: padding queries emit nothing
+            vs::MergeParams m{};
+            m.part_d = dense0;
+            m.G = (int)L0;
+            m.kin = 1;
+            m.nq = B;
+            m.kout = k;
+            m.tau_out = tau0;
+            HIPCHK(vs::launch_merge_layout(m, 1, L0p, st));
+        }
+        if ((rc = S.exchange(Bf.tau, 32)) || (rc = S.exchange(Bf.dense, (size_t)32 * kTieDense))) return rc;
+        for (size_t i = 0; i < S.hs.size(); ++i) {
+            vs_index* h = S.hs[i];
+            const int g = S.first + (int)i;
+            int32_t* pk = Bf.pack + (size_t)g * kShPackWords;
+            HIPCHK(hipMemsetAsync(pk, 0, 32 * sizeof(int32_t), st));
+            const int64_t rb = g == 0 ? L0 : 0;
+            if (h->n_rows <= rb) continue;
+            vs::ScanParams p{};
+            p.base = h->d_vecs;
+            p.bnorm = h->d_norm;
+            p.q = o->d_q;
+            p.n_batches = 1;
+            p.metric = h->metric;
+            p.nq_valid = B;
+            p.k1 = k + 1;
+            p.tau0 = tau0;
+            p.row_begin = rb;  // a multiple of 16 (kTieDense) where rows follow
+            p.row_end = h->n_rows;
+            p.f_cnt = pk;
+            p.f_row = pk + 32;
+            p.f_d = reinterpret_cast<float*>(pk + 32 + (size_t)32 * kTieCap);
+            p.f_cap = kTieCap;
+            int grid, tp;
+            scan_geometry(h->n_rows - rb, h->num_cus, grid, tp);
+            p.tiles_per_wg = tp;
+            HIPCHK(vs::launch_scan(p, grid, 8, 2, vs::kModeFilter, st));
+        }
+        if ((rc = S.exchange(Bf.pack, kShPackWords))) return rc;
+        HIPCHK(hipMemcpyAsync(dense.data(), dense0, (size_t)B * L0p * sizeof(float), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpy2DAsync(cnt.data(), 32 * 4, Bf.pack, kShPackWords * 4, 32 * 4, G, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        int mx = 0;
+        std::vector<int> overflow;
+        for (int b = 0; b < B; ++b) {
+            bool ov = false;
+            for (int g = 0; g < G; ++g) {
+                const int cg = cnt[(size_t)g * 32 + b];
+                if (cg > kTieCap) ov = true;
+                else mx = std::max(mx, cg);
+            }
+            if (ov) overflow.push_back(b);
+        }
+        rows.assign((size_t)G * 32 * std::max(mx, 1), 0);
+        cds.assign((size_t)G * 32 * std::max(mx, 1), 0.f);
+        if (mx > 0) {
+            for (int g = 0; g < G; ++g) {
+                const int32_t* pk = Bf.pack + (size_t)g * kShPackWords;
+                HIPCHK(hipMemcpy2DAsync(&rows[(size_t)g * 32 * mx], (size_t)mx * 4, pk + 32, (size_t)kTieCap * 4, (size_t)mx * 4, B, hipMemcpyDeviceToHost, st));
+                HIPCHK(hipMemcpy2DAsync(&cds[(size_t)g * 32 * mx], (size_t)mx * 4, pk + 32 + (size_t)32 * kTieCap, (size_t)kTieCap * 4, (size_t)mx * 4, B,
+                                        hipMemcpyDeviceToHost, st));
+            }
+            HIPCHK(hipStreamSynchronize(st));
+        }
+        std::vector<int32_t> srow, order;
+        std::vector<float> sdist;
+        for (int b = 0; b < B; ++b) {
+            if (std::find(overflow.begin(), overflow.end(), b) != overflow.end()) continue;
+            srow.clear();
+            sdist.clear();
+            for (int64_t j = 0; j < L0; ++j) {
+                srow.push_back((int32_t)(j + meta[1]));
+                sdist.push_back(dense[(size_t)b * L0p + j]);
+            }
+            for (int g = 0; g < G; ++g) {
+                const int m = cnt[(size_t)g * 32 + b];
+                const int32_t* rr = &rows[((size_t)g * 32 + b) * mx];
+                const float* dd = &cds[((size_t)g * 32 + b) * mx];
+                order.resize((size_t)m);
+                std::iota(order.begin(), order.end(), 0);
+                std::sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return rr[x] < rr[y]; });
+                for (int j = 0; j < m; ++j) {
+                    srow.push_back(rr[order[(size_t)j]] + meta[2 * g + 1]);
+                    sdist.push_back(dd[order[(size_t)j]]);
+                }
+            }
+            const int64_t qi = flagged[f0 + b];
+            vs::select_topk_slots_sparse(srow.data(), sdist.data(), (int64_t)srow.size(), k, ids + qi * k, dists + qi * k);
+        }
+        // masses of rows under the bound (duplicates): the query's full distance row, shard after shard, replayed densely
+        for (int b : overflow) {
+            int64_t ldm = 0, total = 0;
+            for (int g = 0; g < G; ++g) {
+                ldm = std::max<int64_t>(ldm, ((int64_t)meta[2 * g] + 15) & ~int64_t(15));
+                total += meta[2 * g];
+            }
+            if (o->sh_row_words < (size_t)G * ldm) {
+                HIPCHK(hipStreamSynchronize(st));
+                if (o->d_sh_row) (void)hipFree(o->d_sh_row);
+                o->d_sh_row = nullptr;
+                o->sh_row_words = 0;
+                if ((rc = dev_alloc(&o->d_sh_row, (size_t)G * ldm))) return rc;
+                o->sh_row_words = (size_t)G * ldm;
+            }
+            for (size_t i = 0; i < S.hs.size(); ++i) {
+                vs_index* h = S.hs[i];
+                const int g = S.first + (int)i;
+                if ((rc = scores_dev(h, h->d_vecs, h->d_norm, h->n_rows, o->d_q + (size_t)b * vs::kDim, 1, o->d_sh_row + (size_t)g * ldm, ldm, st))) return rc;
+            }
+            if ((rc = S.exchange(reinterpret_cast<int32_t*>(o->d_sh_row), (size_t)ldm))) return rc;
+            std::vector<float> row((size_t)total);
+            int64_t at = 0;
+            for (int g = 0; g < G; ++g) {
+                HIPCHK(hipMemcpyAsync(row.data() + at, o->d_sh_row + (size_t)g * ldm, (size_t)meta[2 * g] * sizeof(float), hipMemcpyDeviceToHost, st));
+                at += meta[2 * g];
+            }
+            HIPCHK(hipStreamSynchronize(st));
+            const int64_t qi = flagged[f0 + b];
+            vs::select_topk_slots_dense(row.data(), total, k, meta[1], ids + qi * k, dists + qi * k);
+        }
+    }
+    return VS_OK;
+}
+
+int bf_search_shards(const BfShards& S, const float* queries_host, int64_t nq, int k, int32_t* ids, float* dists, vs_timing* timing) {
+    vs_index* o = S.owner();
+    hipStream_t st = S.s();
+    const int G = S.G;
+    const double t_start = now_ms();
+    vs_timing tm{};
+    const int k1 = k + 1;
+    if (!pick_kcap(k1)) {
+        set_error("k too large for the compiled scan kernels (k <= 15)");
+        return VS_ERR_UNSUPPORTED;
+    }
+    int rc;
+    ShBuf Bf{};
+    if ((rc = sh_reserve(o, G, k1, Bf))) return rc;
+    // every process needs every shard's (rows, id_offset)
+    std::vector<int32_t> meta((size_t)2 * G, 0);
+    for (size_t i = 0; i < S.hs.size(); ++i) {
+        const int32_t mine[2] = {(int32_t)S.hs[i]->n_rows, (int32_t)S.hs[i]->id_offset};
+        HIPCHK(hipMemcpyAsync(Bf.meta + 2 * (S.first + i), mine, sizeof(mine), hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));  // (`mine` is a stack buffer)
+    }
+    if ((rc = S.exchange(Bf.meta, 2))) return rc;
+    HIPCHK(hipMemcpyAsync(meta.data(), Bf.meta, meta.size() * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    const int batch = o->batch;
+    const int64_t chunk = (int64_t)kMaxMulti * batch;
+    std::vector<float> hd((size_t)chunk * k1);
+    std::vector<int32_t> hi((size_t)chunk * k1), hf((size_t)chunk);
+    std::vector<int64_t> flagged;
+    const float inf = std::numeric_limits<float>::infinity();
+    for (int64_t q0 = 0; q0 < nq; q0 += chunk) {
+        const int64_t n = std::min<int64_t>(chunk, nq - q0);
+        const int full = (int)(n / batch), rem = (int)(n % batch);
+        HIPCHK(hipMemcpyAsync(o->d_q, queries_host + q0 * vs::kDim, (size_t)n * vs::kDim * sizeof(float), hipMemcpyHostToDevice, st));
+        // one part of the chunk (its full batches, or the ragged tail batch): local lists of every shard driven here, the
+        // exchange, the merge into the owner's output buffers
+        auto part = [&](size_t o0, int nb, int B, bool force_f32) -> int {
+            const size_t np = (size_t)nb * B, words = 2 * np * k1 + np;
+            for (size_t i = 0; i < S.hs.size(); ++i) {
+                int32_t* loc = Bf.main + (size_t)(S.first + i) * words;
+                int r2 = bf_launch(S.hs[i], S.hs[i]->lane[0], o->d_q + o0 * vs::kDim, nb, B, k1, reinterpret_cast<float*>(loc),
+                                   loc + np * k1, loc + 2 * np * k1, st, force_f32);
+                if (r2) return r2;
+            }
+            int r2 = S.exchange(Bf.main, words);
+            if (r2) return r2;
+            vs::MergeParams m{};
+            m.part_d = reinterpret_cast<const float*>(Bf.main);
+            m.part_i = Bf.main + np * k1;
+            m.G = G;
+            m.kin = k1;
+            m.nq = (int)np;
+            m.kout = k1;
+            m.out_d = o->d_out_d + o0 * k1;
+            m.out_i = o->d_out_i + o0 * k1;
+            m.flags = o->d_flags + o0;
+            m.flag_empty = 1;
+            m.shard_flags = Bf.main + 2 * np * k1;
+            m.shard_flags_stride = (int64_t)words;
+            HIPCHK(vs::launch_merge_layout(m, (int64_t)words, k1, st));
+            return VS_OK;
+        };
+        auto pass = [&](bool force_f32) -> int {
+            int r2 = VS_OK;
+            if (full) r2 = part(0, full, batch, force_f32);
+            if (!r2 && rem) r2 = part((size_t)full * batch, 1, rem, force_f32);
+            if (r2) return r2;
+            HIPCHK(hipMemcpyAsync(hd.data(), o->d_out_d, (size_t)n * k1 * sizeof(float), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipMemcpyAsync(hi.data(), o->d_out_i, (size_t)n * k1 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipMemcpyAsync(hf.data(), o->d_flags, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            return VS_OK;
+        };
+        if ((rc = pass(false))) return rc;
+        bool rerun = false;
+        for (int64_t b = 0; b < n; ++b) rerun = rerun || hf[(size_t)b] == 2;
+        // a shard's int8 scan skipped a batch (a query that is not an integer in [0, 255]): the merged flag says so on every
+        // rank alike, and every rank reruns the chunk on its fp32 rows
+        if (rerun && (rc = pass(true))) return rc;
+        for (int64_t b = 0; b < n; ++b) {
+            for (int t = 0; t < k; ++t) {
+                const int32_t id = hi[(size_t)b * k1 + t];
+                ids[(q0 + b) * k + t] = id;
+                float d = id >= 0 ? hd[(size_t)b * k1 + t] : inf;
+                if (o->metric == VS_METRIC_IP && id >= 0) d = -d;
+                dists[(q0 + b) * k + t] = d;
+            }
+            if (hf[(size_t)b] == 1) flagged.push_back(q0 + b);
+        }
+    }
+    tm.fine_search_ms = now_ms() - t_start;
+    if (!flagged.empty() && o->metric == VS_METRIC_L2) {
+        const double t0 = now_ms();
+        if ((rc = resolve_ties_shards(S, Bf, meta, queries_host, flagged, k, ids, dists))) return rc;
+        tm.tie_resolve_ms = now_ms() - t0;
+        tm.tie_queries = (int64_t)flagged.size();
+    }
+    tm.total_ms = now_ms() - t_start;
+    if (timing) *timing = tm;
+    return VS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+// Host-buffer forms of the sharded searches (what the CLIs call with --gpus N): every rank passes the same queries and
+// receives the same result -- for brute force the reference's own (select_topk's tie order, fp32 rerun of batches the
+// int8 scan cannot take), like vs_bf_search on one GPU.
 int vs_bf_search_sharded(vs_index* h, vs_comm* c, const float* queries_host, int64_t nq, int k, int32_t* ids, float* dists,
                          vs_timing* timing) {
     if (!h || !c || h->kind != 0 || !queries_host || !ids || !dists || nq < 0 || k < 1) {
         set_error("vs_bf_search_sharded: bad arguments");
         return VS_ERR_INVALID;
     }
+    if (h->device != c->device) {
+        set_error("index and communicator live on different devices");
+        return VS_ERR_INVALID;
+    }
     return guarded([&]() -> int {
         int rc = set_device(h);
         if (rc) return rc;
-        const double t_start = now_ms();
-        vs_timing tm{};
-        const int k1 = k + 1;
-        if (!pick_kcap(k1)) {
-            set_error("k too large for the compiled scan kernels (k <= 15)");
-            return VS_ERR_UNSUPPORTED;
+        if ((rc = order_begin(h, h->stream))) return rc;
+        BfShards S;
+        S.hs = {h};
+        S.G = c->world;
+        S.first = c->rank;
+        S.c = c;
+        return bf_search_shards(S, queries_host, nq, k, ids, dists, timing);
+    });
+}
+
+// Virtual ranks: the same call for G row shards that live on ONE device (shards[g] = vs_bf_create(rows of shard g,
+// id_offset = its first row)), driven by the calling thread; the exchanges are no-ops.  For tests of the sharded tie
+// order / fp32 rerun without a multi-GPU node.
+int vs_bf_search_vshards(vs_index* const* shards, int G, const float* queries_host, int64_t nq, int k, int32_t* ids, float* dists,
+                         vs_timing* timing) {
+    if (!shards || G < 1 || G > 64 || !queries_host || !ids || !dists || nq < 0 || k < 1) {
+        set_error("vs_bf_search_vshards: bad arguments");
+        return VS_ERR_INVALID;
+    }
+    for (int g = 0; g < G; ++g)
+        if (!shards[g] || shards[g]->kind != 0 || shards[g]->device != shards[0]->device || shards[g]->metric != shards[0]->metric ||
+            shards[g]->batch != shards[0]->batch) {
+            set_error("vs_bf_search_vshards: shards must be brute-force indexes on one device with one metric and batch size");
+            return VS_ERR_INVALID;
         }
-        const int64_t chunk = (int64_t)kMaxMulti * h->batch;
-        std::vector<float> hd((size_t)chunk * k1);
-        std::vector<int32_t> hi((size_t)chunk * k1), hf((size_t)chunk);
-        const float inf = std::numeric_limits<float>::infinity();
-        for (int64_t q0 = 0; q0 < nq; q0 += chunk) {
-            const int64_t n = std::min<int64_t>(chunk, nq - q0);
-            const int full = (int)(n / h->batch), rem = (int)(n % h->batch);
-            HIPCHK(hipMemcpyAsync(h->d_q, queries_host + q0 * vs::kDim, (size_t)n * vs::kDim * sizeof(float), hipMemcpyHostToDevice, h->stream));
-            if (full && (rc = vs_bf_search_dev_sharded(h, c, h->d_q, full, h->batch, k, h->d_out_i, h->d_out_d, h->d_flags, h->stream))) return rc;
-            if (rem) {
-                const size_t o = (size_t)full * h->batch;
-                if ((rc = vs_bf_search_dev_sharded(h, c, h->d_q + o * vs::kDim, 1, rem, k, h->d_out_i + o * k1, h->d_out_d + o * k1,
-                                                   h->d_flags + o, h->stream)))
-                    return rc;
-            }
-            HIPCHK(hipMemcpyAsync(hd.data(), h->d_out_d, (size_t)n * k1 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-            HIPCHK(hipMemcpyAsync(hi.data(), h->d_out_i, (size_t)n * k1 * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-            HIPCHK(hipMemcpyAsync(hf.data(), h->d_flags, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-            HIPCHK(hipStreamSynchronize(h->stream));
-            for (int64_t b = 0; b < n; ++b) {
-                if (hf[(size_t)b] == 2) {
-                    set_error("a query batch is not byte valued: call vs_set_precision(h, 1) on every rank (the sharded call has no fp32 rerun)");
-                    return VS_ERR_UNSUPPORTED;
-                }
-                for (int t = 0; t < k; ++t) {
-                    const int32_t id = hi[(size_t)b * k1 + t];
-                    ids[(q0 + b) * k + t] = id;
-                    float d = id >= 0 ? hd[(size_t)b * k1 + t] : inf;
-                    if (h->metric == VS_METRIC_IP && id >= 0) d = -d;
-                    dists[(q0 + b) * k + t] = d;
-                }
-                tm.tie_queries += hf[(size_t)b] == 1;  // reported, not re-resolved: ties come out in (dist, id) order
-            }
-        }
-        tm.total_ms = tm.fine_search_ms = now_ms() - t_start;
-        if (timing) *timing = tm;
-        return VS_OK;
+    return guarded([&]() -> int {
+        int rc = set_device(shards[0]);
+        if (rc) return rc;
+        BfShards S;
+        S.hs.assign(shards, shards + G);
+        S.G = G;
+        for (int g = 0; g < G; ++g)
+            if ((rc = order_begin(shards[g], shards[0]->stream))) return rc;
+        return bf_search_shards(S, queries_host, nq, k, ids, dists, timing);
     });
 }
 

@@ -204,6 +204,8 @@ struct MergeParams {
     int q_group_out, q_group_in;  // output query q reads input query (q / out) * in + q % out (0 = identity)
     const int32_t* invalid;  // optional [nq / q_group_out]: batches skipped by the int8 scan -> flags = 2
     int flag_empty;          // flags = 2 for a query with no finite entry at all (cross-GPU merge: every shard skipped its batch)
+    const int32_t* shard_flags;  // optional (cross-GPU merge): shard g's own flag of output query q at g * shard_flags_stride + q;
+    int64_t shard_flags_stride;  //   a shard that skipped the query's batch (flag 2) makes the merged flag 2: its rows are missing
     const int32_t* run_if;   // optional [1] with run_mode: 1 = run only if *run_if != 0, 2 = only if *run_if == 0 (the other
     int run_mode;            //   launch of the pair writes the outputs)
     const int32_t* flat_len; // optional [queries][G]: list (q, g) holds flat_len[q * G + g] <= kin UNSORTED candidates

@@ -374,6 +374,9 @@ __global__ __launch_bounds__(256) void merge_kernel(const MergeParams p, const M
             for (int i = 0; i + 1 < n; ++i)
                 if (outd[i] == outd[i + 1] && outd[i] < VS_INF) f = 1;
             if (p.flag_empty && !(outd[0] < VS_INF)) f = 2;
+            if (p.shard_flags)
+                for (int g = 0; g < p.G; ++g)
+                    if (p.shard_flags[(int64_t)g * p.shard_flags_stride + q] == 2) f = 2;
             p.flags[q] = f;
         }
         if (p.tau_out) {

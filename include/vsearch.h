@@ -327,13 +327,21 @@ VS_API int vs_ivf_search_dev_vshards(vs_index* const* shards, int G, const float
                                      int nprobe, int32_t* ids_dev, float* dists_dev, double* rank_ms, void* stream);
 
 /* Host-buffer forms (what the CLIs run with --gpus N): same contract, queries and results in host memory on every
- * rank.  Brute force: a tie inside the k+1 best is counted in timing->tie_queries but comes out in (dist, id) order
- * -- the exact select_topk replay needs all rows in one place and is single-GPU only (vs_bf_search).
- * IVF: *total_candidates = rows scanned by THIS rank's shard. */
+ * rank.  Brute force returns what vs_bf_search returns on one GPU -- the reference's answer (cpu_baseline.cpp:127-153):
+ * a chunk whose int8 scan was skipped on some shard (merged flag 2) is rerun on the fp32 rows by every rank, and
+ * queries with a tie inside the k+1 best are re-resolved exactly: shard 0's first rows are taken densely, their k-th
+ * smallest distance bounds select_topk's buffer maximum for every later row, every shard filters its rows under that
+ * bound, the candidates are exchanged (all-gathers of fixed-size buffers) and every rank replays the slots over "dense
+ * rows, then candidates in row order".  Shards must be contiguous row ranges in rank order.
+ * IVF: *total_candidates = rows scanned by THIS rank's shard.
+ * vs_bf_search_vshards: the brute-force call for G shards on ONE device, driven by the calling thread (no collective):
+ * tests of the sharded tie order without a multi-GPU node. */
 VS_API int vs_bf_search_sharded(vs_index* h, vs_comm* c, const float* queries_host, int64_t nq, int k, int32_t* ids,
                                 float* dists, vs_timing* timing);
 VS_API int vs_ivf_search_sharded(vs_index* h, vs_comm* c, const float* queries_host, int64_t nq, int k, int nprobe,
                                  int32_t* ids, float* dists, int64_t* total_candidates, vs_timing* timing);
+VS_API int vs_bf_search_vshards(vs_index* const* shards, int G, const float* queries_host, int64_t nq, int k, int32_t* ids,
+                                float* dists, vs_timing* timing);
 
 /* ------------------------------------------------------------------ profiling */
 /* HIP-event timing of the dominant scan kernel on the stream it is launched on

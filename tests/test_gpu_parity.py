@@ -548,3 +548,61 @@ def test_sift1m_streaming_scan_pairs_batches_exact(gpu_pkg, nb, B):
             # flagged queries (equal distances among the k + 1 best): distances still exact, ids a valid tie order
             assert np.array_equal(gd[:, :5], od)
             assert (np.diff(gd, axis=1) >= 0).all() and (gi >= 0).all()
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_sharded_brute_force_exact_on_virtual_shards(gpu_pkg, world):
+    """vs_bf_search_sharded's host path on virtual ranks (vs_bf_search_vshards: `world` row shards on one GPU, the
+    exchanges no-ops, everything else the code a collective job runs): ids AND distances must equal the oracle's --
+    select_topk's history-dependent tie order (cpu_baseline.cpp:127-153) across shard boundaries included.  Inputs: the
+    heavy-tie set of test_heavy_ties_and_duplicates (duplicates spread over shards), all-equal rows, a descending ramp
+    (worst case for the dense-prefix bound), and the candidate-overflow fallback (masses of duplicates)."""
+    rng = np.random.default_rng(7)
+    base = rng.integers(0, 3, size=(5000, 128)).astype(np.float32)
+    base[1000:1200] = base[0:200]
+    base[3000:3050] = base[0]
+    q = np.concatenate([base[[0, 5, 1000, 3001]], rng.integers(0, 3, size=(36, 128)).astype(np.float32)])
+    ramp = np.zeros((9000, 128), dtype=np.float32)
+    ramp[:, 0] = np.arange(9000, 0, -1) % 251
+    big = np.tile(rng.integers(0, 2, size=(25, 128)).astype(np.float32), (1600, 1))  # 40 000 rows, 25 distinct: > 8192 candidates per query
+    cases = [(base, q, 5), (base, q[:7], 10), (np.tile(base[:1], (300, 1)), q[:3], 5), (ramp, np.zeros((3, 128), dtype=np.float32), 5),
+             (big, np.concatenate([big[[0, 3]], rng.integers(0, 2, size=(3, 128)).astype(np.float32)]), 5)]
+    for data, qq, k in cases:
+        oi, od = oracle.search_bf(data, qq, k)
+        bounds = gpu_pkg.row_shard_bounds(len(data), world) if len(data) >= 16 * world else np.linspace(0, len(data), world + 1).astype(int)
+        shards = [gpu_pkg.BruteForceIndex(data[bounds[g]:bounds[g + 1]], id_offset=int(bounds[g])) for g in range(world) if bounds[g + 1] > bounds[g]]
+        try:
+            for precision in (1, 0):
+                for sh in shards:
+                    sh.set_precision(precision)
+                tm = gpu_pkg.Timing()
+                ids, d = gpu_pkg.BruteForceIndex.search_vshards(shards, qq, k, tm)
+                assert np.array_equal(d, od), f"dists differ (N={len(data)}, world={world}, k={k}, precision={precision})"
+                assert np.array_equal(ids, oi), f"ids differ (N={len(data)}, world={world}, k={k}, precision={precision})"
+                assert tm.tie_queries > 0
+        finally:
+            for sh in shards:
+                sh.close()
+
+
+def test_sharded_shard_that_skips_a_batch_is_rerun_not_dropped(gpu_pkg):
+    """One byte-valued shard (int8 scan) and one that is not (fp32 scan), a batch with a non-integer query: the byte shard's
+    int8 scan skips the batch; the merged flag must say so and the call must rerun the chunk in fp32 on every shard -- never
+    hand back a result that silently lacks the skipping shard's rows."""
+    rng = np.random.default_rng(3)
+    a = rng.integers(0, 200, size=(4000, 128)).astype(np.float32)           # byte valued: int8 copy exists
+    b = rng.integers(0, 200, size=(4000, 128)).astype(np.float32) + 0.5     # not byte valued: fp32 rows only
+    base = np.concatenate([a, b])
+    q = rng.integers(0, 200, size=(40, 128)).astype(np.float32)
+    q[3, 10] += 0.25                                                        # non-integer query in the first batch
+    q[0] = a[17]                                                            # whose neighbours are in the byte shard
+    od = ((q.astype(np.float64)[:, None, :] - base.astype(np.float64)[None]) ** 2).sum(-1)
+    want = np.argsort(od, axis=1, kind="stable")[:, :5]
+    shards = [gpu_pkg.BruteForceIndex(a, id_offset=0), gpu_pkg.BruteForceIndex(b, id_offset=4000)]
+    try:
+        ids, d = gpu_pkg.BruteForceIndex.search_vshards(shards, q, 5)
+        assert np.array_equal(ids, want.astype(np.int32))
+        assert np.allclose(d, np.take_along_axis(od, want, 1), rtol=1e-6)
+    finally:
+        for sh in shards:
+            sh.close()
