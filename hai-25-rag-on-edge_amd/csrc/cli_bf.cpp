@@ -330,8 +330,11 @@ int main(int argc, char* argv[]) {
     if (argc == 7 || argc == 8) {
         // qidk_bruteforce form (main.cpp:73-85); unlike cpu_baseline this one fails loudly (main.cpp:400-403)
         const std::string results_dir = argv[3];
-        const int k = std::stoi(argv[6]);
-        const int batch = argc > 7 ? std::stoi(argv[7]) : 32;
+        int k = 0, batch = 32;
+        if (!vsearch::arg_int(argv[6], k) || (argc > 7 && !vsearch::arg_int(argv[7], batch))) {
+            if (g_ranks.rank == 0) std::cerr << "FATAL ERROR: <top_k> and [batch] must be integers" << std::endl;
+            return vsearch::join_ranks(g_ranks, 1);
+        }
         mkdir(results_dir.c_str(), 0755);
         if (q8) {
             if (g_ranks.world > 1 || !run_q8(argv[5], argv[2], k, results_dir, batch, q8_enc_given ? &q8_enc : nullptr)) {
@@ -343,8 +346,11 @@ int main(int argc, char* argv[]) {
             status = 1;
         }
     } else if (argc >= 5) {
-        const int k = std::stoi(argv[3]);
-        const int batch = argc > 5 ? std::stoi(argv[5]) : 32;
+        int k = 0, batch = 32;
+        if (!vsearch::arg_int(argv[3], k) || (argc > 5 && !vsearch::arg_int(argv[5], batch))) {
+            if (g_ranks.rank == 0) std::cerr << "FATAL ERROR: <k> and [batch] must be integers" << std::endl;
+            return vsearch::join_ranks(g_ranks, 1);
+        }
         run_benchmark(argv[1], argv[1], argv[2], k, argv[4], metrics_name(argv[4]), batch);
     } else {
         const int k = 5;  // cpu_baseline.cpp:329

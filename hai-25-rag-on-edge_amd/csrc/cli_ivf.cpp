@@ -34,10 +34,12 @@ int main(int argc, char* argv[]) {
         return vsearch::join_ranks(ranks, 1);
     }
     const std::string index_dir = argv[1], query_file = argv[2], results_dir = argv[3], backend_path = argv[4];
-    const int TOP_K = std::stoi(argv[5]);
-    const int NPROBE = (argc > 6) ? std::stoi(argv[6]) : 16;  // main_ivf.cpp:76
+    int TOP_K = 0, NPROBE = 16, BATCH_SIZE = 1;  // main_ivf.cpp:76, :78
     const std::string gt_file = (argc > 7) ? argv[7] : "";
-    const int BATCH_SIZE = (argc > 8) ? std::stoi(argv[8]) : 1;  // main_ivf.cpp:78
+    if (!vsearch::arg_int(argv[5], TOP_K) || (argc > 6 && !vsearch::arg_int(argv[6], NPROBE)) || (argc > 8 && !vsearch::arg_int(argv[8], BATCH_SIZE))) {
+        if (ranks.rank == 0) std::cerr << "FATAL ERROR: <top_k>, [nprobe] and [batch] must be integers" << std::endl;
+        return vsearch::join_ranks(ranks, 1);
+    }
     int status = 0;
     try {
         vsearch::connect_ranks(ranks);

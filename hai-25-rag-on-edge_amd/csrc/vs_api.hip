@@ -541,7 +541,15 @@ int g_stream = [] {
 }();
 
 int ensure_wide(vs_index::Lane& L) {
-    if (L.q8) return VS_OK;
+    if (L.wbuf) return VS_OK;  // (the buffer allocated LAST: a call that ran out of memory half way is repeated in full)
+    void* partial[] = {L.q8, L.qterm, L.wcnt, L.wcand_d, L.wcand_i};
+    for (void* q : partial)
+        if (q) (void)hipFree(q);
+    L.q8 = nullptr;
+    L.qterm = nullptr;
+    L.wcnt = nullptr;
+    L.wcand_d = nullptr;
+    L.wcand_i = nullptr;
     int rc;
     if ((rc = dev_alloc(&L.q8, (size_t)kMaxMulti * 32 * vs::kDim))) return rc;
     if ((rc = dev_alloc(&L.qterm, (size_t)kMaxMulti * 32))) return rc;
@@ -582,7 +590,12 @@ int bf_launch(vs_index* h, vs_index::Lane& L, const float* q_dev, int nb, int B,
     // sample tiles are a minority of it); a short call keeps the in-kernel exchange, which needs a few tiles per
     // wave after its warm-up tiles (int8 tiles hold 64 rows)
     const int64_t tiles_total = (h->n_rows + vs::kTileRows - 1) / vs::kTileRows;
-    const bool seeded = nb >= g_seed_min_batches && tiles_total >= 2 * vs::kSeedWaves && g_xchg_first_it >= 0;
+    // The streaming scans' candidate buffers are sized for what survives the seeded bounds: about n_rows * k1 / 32768 rows per
+    // query (the sample is 32 768 rows), in kWideSub sub-lists of kWideCap entries.  A shard on which that expectation passes
+    // half the capacity (5.6 M rows at k = 5) would overflow on nearly every launch and run the fallback scan as well:
+    // it takes the per-batch scan directly.
+    const bool cap_ok = (double)h->n_rows * k1 <= 0.5 * 32768.0 * kWideSub * kWideCap;
+    const bool seeded = nb >= g_seed_min_batches && tiles_total >= 2 * vs::kSeedWaves && g_xchg_first_it >= 0 && cap_ok;
     int grid, tp;
     scan_geometry(h->n_rows, h->num_cus, grid, tp, seeded ? 0 : (u8_path ? 16 : 6) * vs::kScanWaves);
     const bool exchange = !seeded && grid >= 16 && tp >= (u8_path ? 16 : 6) * vs::kScanWaves && g_xchg_first_it >= 0;
@@ -1632,6 +1645,13 @@ int vs_bf_search(vs_index* h, const float* queries_host, int64_t nq, int k, int3
             return VS_ERR_UNSUPPORTED;
         }
         if ((rc = ensure_pipe(h)) || (rc = order_begin(h, h->stream))) return rc;
+        // (a call that failed half way leaves chunks marked in flight: nothing of it may be retired into THIS call's buffers)
+        if (h->pipe[0].q0 >= 0 || h->pipe[1].q0 >= 0) {
+            (void)hipStreamSynchronize(h->stream);
+            (void)hipStreamSynchronize(h->s_h2d);
+            (void)hipStreamSynchronize(h->s_d2h);
+            h->pipe[0].q0 = h->pipe[1].q0 = -1;
+        }
         // Queries go through in chunks of kMaxMulti batches: one persistent scan launch + one merge launch per chunk
         // (the harness loop of main.cpp:201-251 collapsed into a call; a ragged tail batch gets its own launch).  Two
         // chunks are in flight: uploads and downloads run on copy streams beside the other chunk's kernels.

@@ -153,7 +153,8 @@ VS_API int vs_bf_scores_dev(vs_index* h, const float* queries_dev, int B,
 /* The reference's device runner with its uint8 I/O (qidk_bruteforce/android/app/main/jni):
  * QnnRunner ctor (QnnRunner.h:20) bakes the database into the graph as uint8 weights;
  * executeBatchRaw (QnnRunner.cpp:608-645) quantises a [B x d] batch with
- * quantize_buffer_neon (QnnRunner.cpp:13-55: q8 = sat_u8(trunc(x / input_scale + 0.5)),
+ * quantize_buffer_neon (QnnRunner.cpp:13-55: q8 = sat_u8(trunc(x * (1 / input_scale) + 0.5)): a multiplication by the
+ * reciprocal and an addition, rounded separately, as QnnRunner.cpp:544 computes it --
  * offset 0), runs the graph and leaves the raw uint8 [B x N] inner-product scores in
  * its output buffer (getRawOutputBuffer, QnnRunner.h:37); the harness takes the k
  * largest per query (find_top_k_int8, main.cpp:30-57) and prints score * output_scale
