@@ -564,7 +564,8 @@ def main():
                 index.prof_enable(False)
                 iel = median(ireg)
                 info = {"metric": "ivf_qps", "value": round(isteps * BATCH / iel, 1), "ms_per_step": round(iel / isteps * 1e3, 4),
-                        "nlist": nlist, "nprobe": nprobe, "batch": BATCH, "batches_per_call": min(SI, isteps), "steps": isteps}
+                        "nlist": nlist, "nprobe": nprobe, "batch": BATCH, "batches_per_call": min(SI, isteps), "steps": isteps,
+                        "kmeans_iterations": int(n_it)}
                 if world == 1:
                     nrec = 1024
                     ids, _, total = index.searchBatch(queries[:nrec], nrec, K, nprobe)
@@ -697,6 +698,29 @@ def main():
                     for sh_ in shards:
                         sh_.close()
                 ivf_info["shard_1ofG"] = shard_info
+            if world == 1 and not args.no_extras:
+                # the second synthetic distribution (WEAK_MIXTURE: weakly clustered SIFT-range integers): recall well below 1,
+                # so that the figure says something; same shapes, same pipeline, its own index and exact ground truth
+                wbase = pkg.synth_mixture(n_rows, SEED_BASE, **pkg.WEAK_MIXTURE)
+                wq = pkg.synth_mixture(n_queries, SEED_QUERY, **pkg.WEAK_MIXTURE)
+                wvr, woff, wr2o, wcents, w_it = pkg.ivf_build(wbase, nlist, max_iter=args.kmeans_iters, seed=42, device=local_rank)
+                with pkg.BruteForceIndex(wbase, device=local_rank) as wbf:
+                    wgt, _ = wbf.search(wq[:1024], K)
+                del wbase
+                wsizes = np.diff(woff)
+                weak = {"mixture": pkg.WEAK_MIXTURE, "kmeans_iterations": int(w_it), "list_sizes_min_avg_max": [int(wsizes.min()), float(wsizes.mean()), int(wsizes.max())]}
+                with pkg.IVFIndex(vectors_reordered=wvr, centroids=wcents, cluster_offsets=woff, reorder_to_original=wr2o, device=local_rank) as wivf:
+                    wqd = torch.from_numpy(np.tile(wq, ((SI * BATCH + n_queries - 1) // n_queries, 1))[:SI * BATCH].copy()).to(dev)
+                    for npb in (8, NPROBE):
+                        wids, _, wtot = wivf.searchBatch(wq[:1024], 1024, K, npb)
+                        us = ev_us(lambda: wivf.search_dev_multi(wqd.data_ptr(), SI, BATCH, K, npb, iout_i.data_ptr(), iout_d.data_ptr(), sptr))
+                        weak[f"nprobe{npb}"] = {"qps": round(SI * BATCH / us * 1e6, 1),
+                                                "recall_at_1": float(np.mean(wids[:, 0] == wgt[:, 0])),
+                                                "recall_at_5": float(np.mean([len(set(wids[i]) & set(wgt[i])) / K for i in range(1024)])),
+                                                "avg_candidates": wtot / 1024, "nprobe_x_rows_over_nlist": npb * n_rows / nlist}
+                        log(f"IVF, weakly clustered set, nprobe={npb}: {weak[f'nprobe{npb}']['qps']:.0f} QPS, recall@1={weak[f'nprobe{npb}']['recall_at_1']:.4f}, "
+                            f"recall@5={weak[f'nprobe{npb}']['recall_at_5']:.4f}, avg candidates={wtot / 1024:.0f}")
+                ivf_info["weakly_clustered"] = weak
             if world > 1 and not args.no_extras:
                 # N > 1, the other way to use N GPUs for an index that fits one of them (1 M rows are 0.2 % of a GPU's HBM):
                 # every rank holds the WHOLE index and serves its own share of the batches (queries are independent: no

@@ -121,10 +121,12 @@ def lib():
         "vs_ivecs_write": (i32, [C.c_char_p, vp, i64, i32]),
         "vs_results_write": (i32, [C.c_char_p, vp, vp, i64, i32, i32]),
         "vs_synth_sift": (i32, [vp, i64, i64, i32, C.c_uint64]),
+        "vs_synth_mixture": (i32, [vp, i64, i64, i32, C.c_uint64, i32, C.c_double, C.c_double]),
         "vs_select_topk_slots": (i32, [vp, vp, i64, i32, vp, vp]),
         "vs_bf_create": (i32, [vp, i64, i32, i32, i32, i64, C.POINTER(vp)]),
         "vs_set_batch": (i32, [vp, i32]),
         "vs_set_precision": (i32, [vp, i32]),
+        "vs_ivf_set_metric": (i32, [vp, i32]),
         "vs_bf_search": (i32, [vp, vp, i64, i32, vp, vp, C.POINTER(Timing)]),
         "vs_bf_search_dev": (i32, [vp, vp, i32, i32, vp, vp, vp, vp]),
         "vs_bf_search_dev_multi": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp]),
@@ -250,6 +252,17 @@ def synth_sift(rows: int, seed: int, dim: int = 128, row_begin: int = 0) -> np.n
     out = np.empty((rows, dim), dtype=np.float32)
     _check(lib().vs_synth_sift(_p(out), row_begin, rows, dim, seed))
     return out
+
+
+def synth_mixture(rows: int, seed: int, n_centers: int, center_sigma: float, row_sigma: float, dim: int = 128, row_begin: int = 0) -> np.ndarray:
+    """vs_synth_mixture: synth_sift's generator with the mixture as parameters (weakly clustered data for IVF recall tests)."""
+    out = np.empty((rows, dim), dtype=np.float32)
+    _check(lib().vs_synth_mixture(_p(out), row_begin, rows, dim, seed, n_centers, center_sigma, row_sigma))
+    return out
+
+
+# the second synthetic distribution (SIFT-range integers, weakly clustered): IVF recall well below 1 at small nprobe
+WEAK_MIXTURE = dict(n_centers=65536, center_sigma=40.0, row_sigma=12.0)
 
 
 def select_topk_slots(rows, dists, k: int):
@@ -528,6 +541,10 @@ class IVFIndex(_Index):
                            dists_ptr: int, stream: int):
         """Collective: this rank's lists + ONE RCCL all-gather of top-k lists per launch group + device merge."""
         _check(lib().vs_ivf_search_dev_sharded(self._h, comm._c, q_ptr, n_batches, B, k, nprobe, ids_ptr, dists_ptr, stream))
+
+    def set_metric(self, metric: int):
+        """0 = squared L2 (the north-star's), 1 = inner product (the reference's own ranking, IVFIndex.cpp:449-496)."""
+        _check(lib().vs_ivf_set_metric(self._h, metric))
 
     @staticmethod
     def search_dev_vshards(shards, q_ptr: int, n_batches: int, B: int, k: int, nprobe: int, ids_ptr: int, dists_ptr: int,

@@ -936,7 +936,7 @@ vs::IvfWideParams wide_params(vs_index* h, vs_index::IvfWide& W, const float* q_
 #endif
     wp.vecs = h->d_vecs;
     wp.vnorm = h->d_norm;
-    if (h->d_vecs_u8 && h->precision != 1) {
+    if (h->d_vecs_u8 && h->precision != 1 && h->metric == VS_METRIC_L2) {
         wp.vecs_u8 = h->d_vecs_u8;
         wp.rterm = h->d_rterm;
         wp.vecs_t8 = h->d_vecs_t8;
@@ -1129,7 +1129,7 @@ int ivf_shard_front(vs_index* h, int lane, const float* q_dev, int nb, int sbb, 
         wp.vecs = h->d_head_vecs;
         wp.vnorm = h->d_head_norm;
         wp.offsets = h->d_head_off;
-        const bool bytes = h->d_head_t8 && h->precision != 1;
+        const bool bytes = h->d_head_t8 && h->precision != 1 && h->metric == VS_METRIC_L2;
         wp.vecs_u8 = bytes ? h->d_head_t8 : nullptr;  // (non-null = "byte rows exist"; the tiled copy is what is read)
         wp.rterm = nullptr;
         wp.vecs_t8 = bytes ? h->d_head_t8 : nullptr;
@@ -1567,6 +1567,15 @@ static int bf_create_impl(const float* base_host, int64_t n_rows, int dim, int m
         }
     }
     *out = h;
+    return VS_OK;
+}
+
+int vs_ivf_set_metric(vs_index* h, int metric) {
+    if (!h || h->kind != 1 || (metric != VS_METRIC_L2 && metric != VS_METRIC_IP)) {
+        set_error("vs_ivf_set_metric: an IVF index and VS_METRIC_L2 or VS_METRIC_IP");
+        return VS_ERR_INVALID;
+    }
+    h->metric = metric;  // (inner product: centroid scores, bounds, list scan and ranking on -q.v over the fp32 rows)
     return VS_OK;
 }
 
@@ -2450,7 +2459,7 @@ int vs_ivf_search(vs_index* h, const float* queries_host, int64_t nq, int k, int
             for (int64_t i = 0; i < S.n * k; ++i) {
                 const int32_t id = hi[i];
                 ids[S.q0 * k + i] = id;
-                dists[S.q0 * k + i] = id >= 0 ? hd[i] : inf;
+                dists[S.q0 * k + i] = id >= 0 ? (h->metric == VS_METRIC_IP ? -hd[i] : hd[i]) : inf;  // (IP: the score q.v, as IVFIndex returns it)
             }
             S.q0 = -1;
             return VS_OK;

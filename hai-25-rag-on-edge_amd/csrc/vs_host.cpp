@@ -382,32 +382,32 @@ constexpr int kCenters = 4096;
 constexpr uint64_t kCenterSeed = 0x53494654ull;  // "SIFT": base and query files share the mixture
 }  // namespace
 
-static void synth_centers(int dim, std::vector<float>& centers) {
-    centers.resize((size_t)kCenters * dim);
-    Xoshiro rng(kCenterSeed);
+static void synth_centers(int dim, std::vector<float>& centers, int n_centers = kCenters, double sigma = 40.0) {
+    centers.resize((size_t)n_centers * dim);
+    Xoshiro rng(kCenterSeed + (n_centers == kCenters ? 0 : (uint64_t)n_centers));
     for (size_t i = 0; i < centers.size(); i += 2) {
         double a, b;
         rng.normal2(a, b);
-        centers[i] = (float)std::fabs(40.0 * a);
-        if (i + 1 < centers.size()) centers[i + 1] = (float)std::fabs(40.0 * b);
+        centers[i] = (float)std::fabs(sigma * a);
+        if (i + 1 < centers.size()) centers[i + 1] = (float)std::fabs(sigma * b);
     }
 }
 
 static void synth_rows(float* dst, int64_t row_begin, int64_t rows, int dim, uint64_t seed,
-                       const std::vector<float>& centers) {
+                       const std::vector<float>& centers, int n_centers = kCenters, double sigma = 18.0) {
     for (int64_t i = 0; i < rows; ++i) {
         const uint64_t gi = (uint64_t)(row_begin + i);
         Xoshiro rng(seed * 0xD1342543DE82EF95ull + gi * 0x9E3779B97F4A7C15ull + 0x2545F4914F6CDD1Dull);
-        const int u = (int)(rng.next() % kCenters);
+        const int u = (int)(rng.next() % (uint64_t)n_centers);
         const float* c = centers.data() + (size_t)u * dim;
         float* out = dst + i * dim;
         for (int t = 0; t < dim; t += 2) {
             double a, b;
             rng.normal2(a, b);
-            double x0 = std::nearbyint(c[t] + 18.0 * a);
+            double x0 = std::nearbyint(c[t] + sigma * a);
             out[t] = (float)std::min(218.0, std::max(0.0, x0));
             if (t + 1 < dim) {
-                double x1 = std::nearbyint(c[t + 1] + 18.0 * b);
+                double x1 = std::nearbyint(c[t + 1] + sigma * b);
                 out[t + 1] = (float)std::min(218.0, std::max(0.0, x1));
             }
         }
@@ -485,10 +485,10 @@ int vs_results_write(const char* path, const int32_t* ids, const float* dists, i
     return out.good() ? VS_OK : VS_ERR_IO;
 }
 
-int vs_synth_sift(float* dst, int64_t row_begin, int64_t rows, int dim, uint64_t seed) {
-    if (!dst || rows < 0 || dim <= 0) { vs::set_error("bad arguments"); return VS_ERR_INVALID; }
+static int synth_impl(float* dst, int64_t row_begin, int64_t rows, int dim, uint64_t seed, int n_centers, double center_sigma, double row_sigma) {
+    if (!dst || rows < 0 || dim <= 0 || n_centers < 1 || !(center_sigma >= 0) || !(row_sigma >= 0)) { vs::set_error("bad arguments"); return VS_ERR_INVALID; }
     std::vector<float> centers;
-    vs::synth_centers(dim, centers);
+    vs::synth_centers(dim, centers, n_centers, center_sigma);
     unsigned nt = std::thread::hardware_concurrency();
     nt = std::max(1u, std::min(nt, 32u));
     if (rows < 4096) nt = 1;
@@ -497,10 +497,18 @@ int vs_synth_sift(float* dst, int64_t row_begin, int64_t rows, int dim, uint64_t
     for (unsigned t = 0; t < nt; ++t) {
         const int64_t b = (int64_t)t * per, e = std::min(rows, b + per);
         if (b >= e) break;
-        th.emplace_back([=, &centers] { vs::synth_rows(dst + b * dim, row_begin + b, e - b, dim, seed, centers); });
+        th.emplace_back([=, &centers] { vs::synth_rows(dst + b * dim, row_begin + b, e - b, dim, seed, centers, n_centers, row_sigma); });
     }
     for (auto& x : th) x.join();
     return VS_OK;
+}
+
+int vs_synth_sift(float* dst, int64_t row_begin, int64_t rows, int dim, uint64_t seed) {
+    return synth_impl(dst, row_begin, rows, dim, seed, vs::kCenters, 40.0, 18.0);
+}
+
+int vs_synth_mixture(float* dst, int64_t row_begin, int64_t rows, int dim, uint64_t seed, int n_centers, double center_sigma, double row_sigma) {
+    return synth_impl(dst, row_begin, rows, dim, seed, n_centers, center_sigma, row_sigma);
 }
 
 int vs_select_topk_slots(const int32_t* rows, const float* dists, int64_t m, int k, int32_t* out_ids, float* out_dists) {

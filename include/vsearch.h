@@ -90,6 +90,12 @@ VS_API int vs_results_write(const char* path, const int32_t* ids, const float* d
  * f32 in [0, 218], clustered.  Row i depends only on (seed, i), so any slice
  * can be generated independently.  row_begin lets ranks generate shards. */
 VS_API int vs_synth_sift(float* dst, int64_t row_begin, int64_t rows, int dim, uint64_t seed);
+/* The same generator with the mixture as parameters: x = clip(rint(c_u + N(0, row_sigma^2)), 0, 218), u uniform over
+ * n_centers centres c = |N(0, center_sigma^2)| (vs_synth_sift = 4096 centres, 40, 18: strongly clustered, an IVF index
+ * reaches recall ~ 1 with a handful of probes).  Many centres and a wide row_sigma give weakly clustered data on which
+ * recall falls well below 1: the second distribution of the IVF tests and bench. */
+VS_API int vs_synth_mixture(float* dst, int64_t row_begin, int64_t rows, int dim, uint64_t seed, int n_centers,
+                            double center_sigma, double row_sigma);
 
 /* The reference's select_topk (cpu_baseline.cpp:127-153) applied to a sparse,
  * row-ordered candidate list; exposed so the tie resolver can be unit-tested. */
@@ -115,8 +121,13 @@ VS_API int vs_set_batch(vs_index* h, int batch);
  * computed in int32 and are the same integers the fp32 path produces exactly, at a quarter of the memory
  * traffic.  A batch containing a non-integer query is detected on the device, skipped and rerun in fp32
  * (vs_bf_search does that itself; the *_dev calls report it as flags == 2).  1 = force fp32 (the reference
- * arithmetic, cblas_sgemm + epilogue); 2 = require int8 (VS_ERR_UNSUPPORTED when the base does not allow it). */
+ * arithmetic, cblas_sgemm + epilogue); 2 = require int8 (VS_ERR_UNSUPPORTED when the base does not allow it).
+ * IVF indexes alike: 1 = the list scan reads the fp32 rows (IVFIndex.cpp:270-358's arithmetic). */
 VS_API int vs_set_precision(vs_index* h, int precision);
+/* IVF indexes are created with the north-star's squared L2; VS_METRIC_IP selects the reference's own ranking (IVFIndex.cpp:
+ * 449-496, :697-723): nprobe lists of LARGEST q.c, k candidates of largest q.v (fp32 rows; the int8 copies are an L2 device).
+ * The host call returns the scores q.v (descending); the *_dev calls return -q.v (ascending), like brute force. */
+VS_API int vs_ivf_set_metric(vs_index* h, int metric);
 
 /* Host-buffer search with the reference's exact semantics: ids/dists are
  * [nq x k], ascending distance, ties ordered exactly as select_topk leaves

@@ -60,6 +60,9 @@ def lib():
         L.vo_ivf_search.restype = C.c_int64
         L.vo_ivf_search.argtypes = [_f32p, _f32p, C.c_int64, C.c_int, _f32p, C.c_int, _i32p, C.c_void_p,
                                     _f32p, C.c_int64, C.c_int, C.c_int, _i32p, _f32p, C.c_void_p]
+        L.vo_ivf_search_metric.restype = C.c_int64
+        L.vo_ivf_search_metric.argtypes = [_f32p, _f32p, C.c_int64, C.c_int, _f32p, C.c_int, _i32p, C.c_void_p,
+                                           _f32p, C.c_int64, C.c_int, C.c_int, C.c_int, _i32p, _f32p, C.c_void_p]
         L.vo_recall.restype = C.c_double
         L.vo_recall.argtypes = [_i32p, C.c_int, _i32p, C.c_int, C.c_int]
         L.vo_num_threads.restype = C.c_int
@@ -150,8 +153,9 @@ def write_results(path: str, idx: np.ndarray, dist: np.ndarray) -> None:
         raise IOError(path)
 
 
-def ivf_search(vectors_reordered, offsets, reorder_to_original, centroids, queries, k, nprobe, return_probes=False):
-    """IVFIndex::searchBatch (reordered mode) restated with L2. Returns ids, dists, total_candidates[, probes]."""
+def ivf_search(vectors_reordered, offsets, reorder_to_original, centroids, queries, k, nprobe, return_probes=False, metric=0):
+    """IVFIndex::searchBatch (reordered mode) restated with L2 (metric 0) or the reference's own inner product (metric 1:
+    dists = -q.v, smallest first).  Returns ids, dists, total_candidates[, probes]."""
     v = _f32(vectors_reordered)
     cen = _f32(centroids)
     q = _f32(queries)
@@ -168,8 +172,8 @@ def ivf_search(vectors_reordered, offsets, reorder_to_original, centroids, queri
         r2o = np.ascontiguousarray(reorder_to_original, dtype=np.int32)
         r2o_p = r2o.ctypes.data_as(C.c_void_p)
     probes = np.empty((nq, npb), dtype=np.int32) if return_probes else None
-    total = lib().vo_ivf_search(v, vn, v.shape[0], v.shape[1], cen, nlist, off, r2o_p, q, nq, k, nprobe, idx, dd,
-                                probes.ctypes.data_as(C.c_void_p) if probes is not None else None)
+    total = lib().vo_ivf_search_metric(v, vn, v.shape[0], v.shape[1], cen, nlist, off, r2o_p, q, nq, k, nprobe, int(metric), idx, dd,
+                                       probes.ctypes.data_as(C.c_void_p) if probes is not None else None)
     if return_probes:
         return idx, dd, int(total), probes
     return idx, dd, int(total)

@@ -268,11 +268,29 @@ static int vo_pair_cmp(const void* a, const void* b) {
     return (x->id > y->id) - (x->id < y->id);
 }
 
+/* metric 0 = the north-star's L2 (above); metric 1 = the reference's own inner product: coarse = the nprobe LARGEST q.c
+ * (IVFIndex.cpp:697-723), candidates scored by q.v (:738-747), the k largest kept (heap :449-496, :754-766) and sorted
+ * descending (:771).  Restated on s = -dot, smallest first, ties by (s, reordered position); out_dist holds s. */
+VO_API int64_t vo_ivf_search_metric(const float* vectors_reordered, const float* vec_norms, int64_t N, int dim,
+                                    const float* centroids, int nlist, const int32_t* offsets,
+                                    const int32_t* reorder_to_original,
+                                    const float* queries, int64_t nq, int k, int nprobe, int metric,
+                                    int* out_idx, float* out_dist, int32_t* out_probes /* nq*nprobe or NULL */);
+
 VO_API int64_t vo_ivf_search(const float* vectors_reordered, const float* vec_norms, int64_t N, int dim,
                              const float* centroids, int nlist, const int32_t* offsets,
                              const int32_t* reorder_to_original,
                              const float* queries, int64_t nq, int k, int nprobe,
                              int* out_idx, float* out_dist, int32_t* out_probes /* nq*nprobe or NULL */) {
+    return vo_ivf_search_metric(vectors_reordered, vec_norms, N, dim, centroids, nlist, offsets, reorder_to_original, queries, nq, k,
+                                nprobe, 0, out_idx, out_dist, out_probes);
+}
+
+VO_API int64_t vo_ivf_search_metric(const float* vectors_reordered, const float* vec_norms, int64_t N, int dim,
+                                    const float* centroids, int nlist, const int32_t* offsets,
+                                    const int32_t* reorder_to_original,
+                                    const float* queries, int64_t nq, int k, int nprobe, int metric,
+                                    int* out_idx, float* out_dist, int32_t* out_probes /* nq*nprobe or NULL */) {
     if (nprobe > nlist) nprobe = nlist;
     float* cn = (float*)malloc(sizeof(float) * (size_t)nlist);
     vo_compute_norms(centroids, nlist, dim, cn);
@@ -283,7 +301,8 @@ VO_API int64_t vo_ivf_search(const float* vectors_reordered, const float* vec_no
         float qn = vo_norm_one(q, dim);
         vo_pair* cs = (vo_pair*)malloc(sizeof(vo_pair) * (size_t)nlist);
         for (int c = 0; c < nlist; ++c) {
-            cs[c].d = fmaf(-2.0f, vo_dot(q, centroids + (int64_t)c * dim, dim), qn + cn[c]);
+            const float cdot = vo_dot(q, centroids + (int64_t)c * dim, dim);
+            cs[c].d = metric ? -cdot : fmaf(-2.0f, cdot, qn + cn[c]);
             cs[c].id = c;
         }
         qsort(cs, (size_t)nlist, sizeof(vo_pair), vo_pair_cmp);
@@ -297,7 +316,7 @@ VO_API int64_t vo_ivf_search(const float* vectors_reordered, const float* vec_no
             if (out_probes) out_probes[b * nprobe + p] = c;
             for (int32_t r = offsets[c]; r < offsets[c + 1]; ++r) {
                 float dot = vo_dot(q, vectors_reordered + (int64_t)r * dim, dim);
-                all[m].d = fmaf(-2.0f, dot, qn + vec_norms[r]);
+                all[m].d = metric ? -dot : fmaf(-2.0f, dot, qn + vec_norms[r]);
                 all[m].id = r;
                 ++m;
             }
