@@ -608,7 +608,8 @@ def main():
                     frac = round(ach / HBM_PEAK_GBS, 4) if ach else None
                     assert frac is None or frac <= 1.0, ("the byte model does not describe the kernel", frac)
                     info["roofline"] = {"bound": "hbm", "achieved": round(ach, 1) if ach else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                        "frac": frac, "traffic_static_from_profiles": itraffic,
+                                        "frac": frac, "traffic": itraffic,
+                                        "traffic_source": "static: profiles/traffic_ivf_list_scan.json (rocprofv3 --pmc passes, not measured in this run)",
                                         "kernel": "vs::ivf_scan_wide_kernel", "kernel_us": round(ks_launch * 1e6, 2),
                                         "launches": int(okern_n), "batches_per_launch": round(sum(window) / max(len(window), 1), 2),
                                         "algorithmic_bytes_per_launch": int(ib), "row_bytes": rb,
@@ -826,6 +827,7 @@ def main():
             "ms_per_step_min_max": [round(min(regions) / steps * 1e3, 5), round(max(regions) / steps * 1e3, 5)],
             "roofline": ({"bound": "mfma", "achieved": round(mfma_tflops, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                           "frac": round(mfma_tflops / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic,
+                          "traffic_source": "static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same command, summarised in profiles/traffic_bf_scan.json (not measured in this run)",
                           "kernel": "vs::scan_f32s_kernel<2>", "kernel_us": round(kern_avg_s * 1e6, 2),
                           "kernel_us_per_batch": round(kern_per_batch_s * 1e6, 2),
                           "algorithmic_flops_per_launch": int(2 * BATCH * rows_local * DIM * S),
@@ -836,6 +838,7 @@ def main():
                          if pair else
                          {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                          "traffic_source": "static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same command, summarised in profiles/traffic_bf_scan.json (not measured in this run)",
                           "kernel": "vs::scan_f32s_kernel<1>", "kernel_us": round(kern_avg_s * 1e6, 2),
                           "kernel_us_per_batch": round(kern_per_batch_s * 1e6, 2),
                           "algorithmic_bytes_per_launch": algo_bytes,

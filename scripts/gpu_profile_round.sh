@@ -2,10 +2,10 @@
 # One gpurun call that produces everything profiles/ is built from (run from the repo root on the GPU box):
 #   scripts/gpu_profile_round.sh <tag>
 # -> gpurun_out/<tag>/{pytest.log, bench_default.json, bench_driver.json, bench_stats.json, kernel_stats.csv,
-#    pmc_traffic.csv, sq_counters.txt}.  The rocpd databases are summarised here and deleted (they exceed what gpurun
-#    carries back).
+#    pmc_traffic.csv, sq_counters.txt, b1_*, ivf_*, shard.txt}.  The rocpd databases are summarised here and deleted
+#    (they exceed what gpurun carries back).
 set -o pipefail
-tag=${1:-r02}
+tag=${1:-r03}
 out=gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
@@ -20,15 +20,22 @@ PB="python3 bench.py --steps 64 --warmup 32 --no-cpu --no-extras --no-prof --rep
 timeout -k 10 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/fetch -o f -- $PB > /dev/null 2> $out/fetch.err; echo "fetch rc=$?"
 timeout -k 10 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out/write -o w -- $PB > /dev/null 2> $out/write.err; echo "write rc=$?"
 python3 scripts/pmc_summary.py "$(db $out/fetch)" "$(db $out/write)" $out/pmc_traffic.csv; rm -rf $out/fetch $out/write
+# the single-call scan (B = 1) and the IVF list scan on the fp32 rows: their own kernel statistics and HBM traffic
+for leg in "b1 scripts/b1_bench.py 1" "ivf_i8 scripts/ivf_bench.py 0" "ivf_f32 scripts/ivf_bench.py 1"; do
+  set -- $leg; name=$1; shift
+  timeout -k 10 300 python3 "$@" > $out/$name.txt 2> $out/$name.err; echo "$name rc=$?"; cat $out/$name.txt
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out/${name}_s -o s -- python3 "$@" > /dev/null 2> $out/${name}_s.err
+  python3 scripts/prof_summary.py "$(db $out/${name}_s)" $out/${name}_kernel_stats.csv; rm -rf $out/${name}_s
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/${name}_f -o f -- python3 "$@" > /dev/null 2> $out/${name}_f.err
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out/${name}_w -o w -- python3 "$@" > /dev/null 2> $out/${name}_w.err
+  python3 scripts/pmc_summary.py "$(db $out/${name}_f)" "$(db $out/${name}_w)" $out/${name}_pmc_traffic.csv; rm -rf $out/${name}_f $out/${name}_w
+done
+# what a rank of a cluster-sharded job does per launch group (virtual ranks)
+timeout -k 10 400 python3 scripts/ivf_shard_bench.py > $out/shard.txt 2> $out/shard.err; echo "shard rc=$?"
 # the UFIXED_POINT_8 runner on its own (bench.py runs it among the extras, which the PMC passes above skip)
 timeout -k 10 200 python3 scripts/q8_bench.py > $out/q8_bench.txt 2> $out/q8_bench.err; echo "q8 bench rc=$?"
-timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/q8f -o f -- python3 scripts/q8_bench.py > /dev/null 2> $out/q8f.err; echo "q8 fetch rc=$?"
-timeout -k 10 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out/q8w -o w -- python3 scripts/q8_bench.py > /dev/null 2> $out/q8w.err; echo "q8 write rc=$?"
-python3 scripts/pmc_summary.py "$(db $out/q8f)" "$(db $out/q8w)" $out/q8_pmc_traffic.csv; rm -rf $out/q8f $out/q8w
 SB="python3 bench.py --steps 64 --warmup 32 --no-cpu --no-extras --no-prof --repeats 1"
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_INSTS_VALU -d $out/sq1 -o a -- $SB > /dev/null 2> $out/sq1.err; echo "sq1 rc=$?"
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES -d $out/sq2 -o b -- $SB > /dev/null 2> $out/sq2.err; echo "sq2 rc=$?"
 python3 scripts/pmc_counters.py "$(db $out/sq1)" "$(db $out/sq2)" > $out/sq_counters.txt; rm -rf $out/sq1 $out/sq2
-# what the fp32 MFMA pipe delivers in the scan's issue pattern without the scan's other work
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/mfma_f32_ceiling scripts/microbench/mfma_f32_ceiling.hip 2> $out/mfma_ceiling.err && timeout -k 5 60 /tmp/mfma_f32_ceiling > $out/mfma_ceiling.txt; echo "mfma ceiling rc=$?"
 grep "^\[bench\]" $out/bench_default.err
