@@ -200,6 +200,7 @@ struct vs_index {
     int n_chunks = 0;
     int32_t max_list = 0;              // longest resident list
     int max_grid = 0;
+    unsigned one_calls = 0;            // single-call scans issued so far (they alternate the direction of their pass)
 
     // host-buffer API (vs_bf_search / vs_ivf_search): two slots of pinned staging + device I/O buffers, so that chunk
     // c + 1's query upload and chunk c - 1's result download run beside chunk c's kernels (copy streams + events)
@@ -619,6 +620,7 @@ int bf_launch(vs_index* h, vs_index::Lane& L, const float* q_dev, int nb, int B,
             op.nq_valid = B;
             op.k1 = k1;
             op.metric = h->metric;
+            op.reverse = (int)(h->one_calls++ & 1u);
             op.id_offset = (int32_t)h->id_offset;
             op.part_d = L.part_d;
             op.part_i = L.part_i;

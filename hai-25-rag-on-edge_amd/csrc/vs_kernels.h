@@ -175,6 +175,7 @@ struct OneParams {
     int64_t n_rows;
     const float* q;          // [nq_valid][128] raw queries
     int nq_valid, k1, metric;
+    int reverse;             // walk the base from its end (calls alternate: see scan_one_kernel)
     int32_t id_offset;
     float* part_d;           // scratch [32][grid][k1]
     int32_t* part_i;
