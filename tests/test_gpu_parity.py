@@ -606,3 +606,37 @@ def test_sharded_shard_that_skips_a_batch_is_rerun_not_dropped(gpu_pkg):
     finally:
         for sh in shards:
             sh.close()
+
+
+_TOGGLE_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+import __graft_entry__ as ge, oracle
+pkg = ge.load_package()
+base = pkg.synth_sift(300000, seed=11)
+q = pkg.synth_sift(5 * 32, seed=12)
+q[3] = base[123456]
+oi, od = oracle.search_bf(base, q, 5)
+with pkg.BruteForceIndex(base) as idx:
+    for precision in (1, 0):
+        idx.set_precision(precision)
+        ids, d = idx.search(q, 5)
+        assert np.array_equal(ids, oi) and np.array_equal(d, od), precision
+print("TOGGLE_OK")
+"""
+
+
+@pytest.mark.parametrize("env", [{"VSEARCH_STREAM": "0"}, {"VSEARCH_F32_PAIR": "0"}, {"VSEARCH_F32_PAIR": "2"}, {"VSEARCH_I8_WIDE": "4"},
+                                 {"VSEARCH_I8_WIDE": "0"}, {"VSEARCH_SEED_MIN": "0"}, {"VSEARCH_SEED_I8": "0"}, {"VSEARCH_XCHG_IT": "-1"},
+                                 {"VSEARCH_GRID_CUS": "64"}, {"VSEARCH_LANES": "2"}])
+def test_tuning_toggles_keep_results(gpu_pkg, env):
+    """Every code path a VSEARCH_* knob of the brute-force scans selects (read when the library is loaded,
+    hence one subprocess each) must reproduce the oracle bit for bit: a 300 000-row base (seeded launches), 5 batches, both
+    data paths.  A knob nobody tests is a shipped kernel nobody has verified."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, "-c", _TOGGLE_SCRIPT, root], env=e, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "TOGGLE_OK" in r.stdout, (env, r.stdout[-400:], r.stderr[-1200:])
