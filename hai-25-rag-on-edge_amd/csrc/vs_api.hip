@@ -156,6 +156,7 @@ struct vs_index {
     int ivf_gb = 32;                   // batches per launch group (multiple of 32) the wide pipeline's scratch is sized for
     int ivf_nsb = 1;                   // ... in at most this many super-batches (sharded: one per rank)
     int ivf_lanes = 2;                 // streams the launch groups of one device call are dealt to
+    bool ivf_bounds_query = false;     // VSEARCH_IVF_BOUNDS=query: bounds by one wave per query (ivf_tau_body) instead of list-major
     int64_t ivf_host_cap = 0;          // queries per chunk the host-buffer call's staging slots hold
     // sharded index: the first kIvfTauRows rows of EVERY list (resident or not), replicated on every rank: a query's bound
     // then comes from its two nearest lists wherever they live -- the bounds of the unsharded index (a bound from the
@@ -182,6 +183,9 @@ struct vs_index {
         int32_t* units = nullptr;   // [n_sb_max][units_cap][4]
         int units_cap = 0;
         float* tau = nullptr;       // [1024]
+        int32_t* tq = nullptr;      // [nlist][group queries] bound tables (ivf_bounds_list_body)
+        float* tk = nullptr;        // [group queries][2][16]
+        int32_t* nseg = nullptr;    // [group queries]
         float* qnorm = nullptr;     // [1024]
         int8_t* q8 = nullptr;       // [1024][128]
         int32_t* qterm = nullptr;   // [1024]
@@ -895,6 +899,11 @@ int ensure_ivf_wide(vs_index* h, int lane) {
     W.units_cap = (int)std::min<int64_t>(2 * h->n_units_max + 4096, 0x7fffffff / 16);
     if ((rc = dev_alloc(&W.units, (size_t)n_sb_max * W.units_cap * 4))) return rc;
     if ((rc = dev_alloc(&W.tau, nq))) return rc;
+    if (!h->ivf_bounds_query && nq <= 0x10000) {
+        if ((rc = dev_alloc(&W.tq, (size_t)h->nlist * nq))) return rc;
+        if ((rc = dev_alloc(&W.tk, nq * 32))) return rc;
+        if ((rc = dev_alloc(&W.nseg, nq))) return rc;
+    }
     if ((rc = dev_alloc(&W.qnorm, nq))) return rc;
     if ((rc = dev_alloc(&W.q8, nq * vs::kDim))) return rc;
     if ((rc = dev_alloc(&W.qterm, nq))) return rc;
@@ -974,6 +983,10 @@ vs::IvfWideParams wide_params(vs_index* h, vs_index::IvfWide& W, const float* q_
     wp.units = W.units;
     wp.units_sb_stride = (long long)W.units_cap * 4;
     wp.units_cap = W.units_cap;
+    wp.tq = W.tq;
+    wp.tq_cap = (int)nq;
+    wp.tk = W.tk;
+    wp.nseg = W.nseg;
     wp.tau = W.tau;
     wp.slow = z.slow;
     wp.sink.wbuf = W.wbuf;
@@ -1009,6 +1022,11 @@ vs::IvfGroup wide_group(vs_index* h, vs_index::IvfWide& W, int sbb, int B) {
     grp.w_cnt = z.plan;
     grp.w_lq = W.lq;
     grp.w_q = vs::kIvfWideQ;
+    grp.w_tq = W.tq;
+    grp.w_tq_cap = h->ivf_gb * 32;
+    grp.w_tcnt = z.plan;
+    grp.w_nseg = W.nseg;
+    grp.t_offsets = h->d_offsets;
 #ifdef VS_STAMPS
     grp.dbg = g_dbg ? g_dbg + 4096 * 16 : nullptr;
 #endif
@@ -1115,6 +1133,7 @@ int ivf_shard_front(vs_index* h, int lane, const float* q_dev, int nb, int sbb, 
     fg.w_cnt = nullptr;  // (slot tables are filled after the exchange, for all slices)
     fg.w_lq = nullptr;
     fg.mb.probes = (long long)32 * nprobe * sizeof(int32_t);
+    fg.t_offsets = h->d_head_vecs ? h->d_head_off : h->d_offsets;  // (the rows the bounds come from, see below)
     const float* qs = q_dev + (size_t)b0 * B * vs::kDim;
     HIPCHK(vs::launch_ivf_coarse_pick(qs, B, h->d_centroids, h->d_cnorm, h->nlist, nprobe, h->metric,
                                       reinterpret_cast<float*>(W.slab + W.off_scores), (h->nlist + 63) & ~63, blk, fg, s, nbs));
@@ -2014,6 +2033,10 @@ static int ivf_create_impl(const float* vectors, int64_t n_rows, int dim, const 
     // slice of up to 32 batches per rank (ivf_shard_front / ivf_shard_back)
     h->ivf_gb = world > 1 ? std::min(kIvfGroupMax, 32 * std::min(world, kIvfShardMaxWorld)) : ivf_group_batches();
     h->ivf_lanes = ivf_wide_lanes();
+    {
+        const char* e = getenv("VSEARCH_IVF_BOUNDS");
+        h->ivf_bounds_query = e && !strcmp(e, "query");
+    }
     h->ivf_nsb = world > 1 ? std::max(h->ivf_gb / 32, std::min(world, kIvfShardMaxWorld)) : h->ivf_gb / 32;
     if (h->nlist <= vs::kIvfFastNlist && h->n_chunks > 0) {
         // the wide pipeline's scratch (two lanes), streams and host staging now rather than inside the first search:

@@ -174,6 +174,16 @@ __device__ __forceinline__ float f32_unordered(unsigned u) {
     return __builtin_bit_cast(float, b);
 }
 
+// minimum over the four lanes l, l ^ 16, l ^ 32, l ^ 48 (the four rows of a column in an MFMA 16x16 result), in every one
+// of them.  gfx950's row swaps: v_permlane32_swap(a, b) exchanges a's upper half with b's lower half -- with a = b = x that
+// leaves (lo, lo) and (hi, hi); v_permlane16_swap does the same with odd / even rows of 16.  Plain VALU, no LDS round trip.
+__device__ __forceinline__ unsigned col4_min_u32(unsigned x) {
+    const auto h = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+    const unsigned m = min(h[0], h[1]);
+    const auto q = __builtin_amdgcn_permlane16_swap(m, m, false, false);
+    return min(q[0], q[1]);
+}
+
 }  // namespace vs
 
 // time stamps of diagnostic builds (-DVS_STAMPS): p.dbg[workgroup][16]

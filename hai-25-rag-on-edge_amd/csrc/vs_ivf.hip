@@ -347,11 +347,26 @@ __global__ __launch_bounds__(256) void ivf_pick_kernel(const float* __restrict__
         s_probe[c] = -1;
     }
     PICK_STAMP(3);
+    __syncthreads();
+    if (grp.w_tq && tid < 64) {
+        // the bound's tables (see ivf_bounds_list_body): the query enters itself with the first two of its probed lists
+        // that hold rows, as segment 0 and 1 (looked for among the nearest 64)
+        const int c = tid < nprobe ? s_probe[tid] : -1;
+        const bool rows = c >= 0 && grp.t_offsets[c + 1] > grp.t_offsets[c];
+        const unsigned long long mask = __ballot(rows);
+        const unsigned long long rest = mask & (mask - 1);
+        const int first = mask ? __builtin_ctzll(mask) : -1, second = rest ? __builtin_ctzll(rest) : -1;
+        const int qg = (int)blockIdx.y * kMaxBatch + b;
+        if (tid == first || tid == second) {
+            const int slot = atomicAdd(grp.w_tcnt + (int64_t)c * kIvfWideCntStride + 1, 1);  // < w_tq_cap: once per query
+            grp.w_tq[(int64_t)c * grp.w_tq_cap + slot] = qg | (tid == second ? 1 << 16 : 0);
+        }
+        if (tid == 0) grp.w_nseg[qg] = min(__builtin_popcountll(mask), 2);
+    }
     if (!grp.w_cnt) return;  // probes only (sharded front half: the slot tables are filled after the exchange)
     {
         // every (query, probe) pair takes a slot in its list's table (one global atomic per pair; a list without rows
         // here has no records in the plan, its table is simply never read)
-        __syncthreads();
         const int c = tid < nprobe ? s_probe[tid] : -1;
         if (c >= 0) {
             const int sb = (int)blockIdx.y / grp.sb_batches;
@@ -756,6 +771,213 @@ __device__ __forceinline__ void ivf_tau_body(const IvfWideParams& p, const int w
     }
 }
 
+// The same bound, list-major (what runs when the pick kernel filled the bound tables, IvfWideParams::tq).  One query per
+// wave uses one of the MFMA's 16 columns and reads 64 KB of rows; a list's first rows are the same for every query that
+// probes it.  So: the pick kernel enters each query in the tables of its two lists, and here a workgroup takes 16 ENTRIES
+// of one list as the 16 columns ("unit").  The workgroup copies the list's first 256 rows (32 KB of the tiled byte copy)
+// to LDS in ONE round trip, with the unit's entries and their query bytes requested beside it; wave w scores tiles w, w + 4,
+// ... (two int8 MFMAs per tile score all 16 columns), keeps the k smallest of its 64 rows per column (k rounds of a
+// minimum over the lane's 16 registers and the column's four lanes), and wave 0 merges the four waves' lists.  They go to
+// tk[query][segment][0..k); ivf_tau_combine_kernel merges a query's two segments into its bound.
+// A workgroup's life is a chain of three cache misses and about a microsecond per unit: all of a launch group's lists are
+// meant to be in flight together (see ivf_bounds_plan_kernel).  (list, part): the units of a list are dealt to kBoundParts
+// workgroups.
+constexpr int kBoundParts = 2;
+constexpr int kBoundLds = kIvfTauRows * kDim + kIvfTauRows * 4 + 4 * 16 * 16 * 4;  // rows | row terms | the waves' lists
+__device__ __forceinline__ void ivf_bounds_list_body(const IvfWideParams& p, const int c, const int part, char* const lds) {
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+#ifdef VS_STAMPS
+#define BL_STAMP(i) do { if (p.dbg && threadIdx.x == 0 && part == 0 && c < 1024) p.dbg[(16384 + c) * 16 + (i)] = (int)(__builtin_amdgcn_s_memrealtime() & 0x7fffffff); } while (0)
+#else
+#define BL_STAMP(i)
+#endif
+    BL_STAMP(0);
+    // first round trip: the list's entry count and extent, the batches' flags
+    const int n = min(p.zero[(int64_t)c * kIvfWideCntStride + 1], p.tq_cap);
+    const int start = p.offsets[c];
+    const int rows = min(p.offsets[c + 1] - start, kIvfTauRows);
+    const int td = p.tdelta ? p.tdelta[c] : 0;
+    int inv = 0;
+    for (int b = lane; b < p.n_batches; b += 64) inv |= p.invalid[b];
+    const int n_units = (n + 15) >> 4;
+    BL_STAMP(1);
+    if (part >= n_units) return;  // (most lists have a unit or two: the other parts' workgroups end here)
+    const int tiles = (rows + 15) >> 4;
+    // (a batch that is not byte valued sends the whole group to the fp32 rows here: the columns of a unit come from any batch)
+    const bool i8 = p.vecs_t8 && p.metric == 0 && __ballot(inv != 0) == 0;
+    const int32_t* tq = p.tq + (int64_t)c * p.tq_cap;
+    i32x4* rows_s = reinterpret_cast<i32x4*>(lds);
+    int* rt_s = reinterpret_cast<int*>(lds + kIvfTauRows * kDim);
+    unsigned* cand_s = reinterpret_cast<unsigned*>(lds + kIvfTauRows * kDim + kIvfTauRows * 4);  // [wave][column][16]
+    constexpr unsigned kNone = 0xffffffffu;
+    constexpr int NT = kIvfTauRows / 16 / 4;  // tiles per wave at most
+    constexpr int PIECES = kIvfTauRows * kDim / 16 / 256;  // 16-byte pieces of the rows per thread
+    const int tstart = start + td;
+    // second round trip: the first unit's entries and the rows (byte path); third: the entries' query bytes, requested
+    // before the rows are waited for
+    // (a workgroup's further units: their entries and query bytes are requested one unit ahead)
+    int e = tq[min(part * 16 + r, n - 1)];
+    int e_nx = tq[min((part + kBoundParts) * 16 + r, n - 1)];
+    i32x4 b0 = {0, 0, 0, 0}, b1 = {0, 0, 0, 0};
+    int qt = 0;
+    if (i8) {
+        i32x4 piece[PIECES];
+        const i32x4* src = reinterpret_cast<const i32x4*>(p.vecs_t8 + (int64_t)tstart * kDim);
+#pragma unroll
+        for (int j = 0; j < PIECES; ++j) piece[j] = src[min(tid + 256 * j, tiles * 128 - 1)];
+        const int rt_v = p.rterm_t[tstart + min(tid, tiles * 16 - 1)];
+        const int qg = e & 0xffff;
+        b0 = *reinterpret_cast<const i32x4*>(p.q8 + (int64_t)qg * kDim + 16 * g);
+        b1 = *reinterpret_cast<const i32x4*>(p.q8 + (int64_t)qg * kDim + 64 + 16 * g);
+        qt = p.qterm[qg];
+#pragma unroll
+        for (int j = 0; j < PIECES; ++j) rows_s[tid + 256 * j] = piece[j];
+        rt_s[tid] = rt_v;
+        __syncthreads();
+    }
+    for (int u = part; u < n_units; u += kBoundParts) {
+        const int ei = u * 16 + r;
+        const bool has = ei < n;
+        i32x4 nb0 = {0, 0, 0, 0}, nb1 = {0, 0, 0, 0};
+        int nqt = 0, e_nx2 = 0;
+        if (u + kBoundParts < n_units) {  // (workgroup-uniform)
+            if (i8) {
+                const int qn = e_nx & 0xffff;
+                nb0 = *reinterpret_cast<const i32x4*>(p.q8 + (int64_t)qn * kDim + 16 * g);
+                nb1 = *reinterpret_cast<const i32x4*>(p.q8 + (int64_t)qn * kDim + 64 + 16 * g);
+                nqt = p.qterm[qn];
+            }
+            e_nx2 = tq[min((u + 2 * kBoundParts) * 16 + r, n - 1)];
+        }
+        const int qg = e & 0xffff, seg = e >> 16;
+        // a distance is kept as a 32-bit key that is unique in its column: value | row in the low byte.  Byte rows: the
+        // distance is an integer below 2^23, the key holds it exactly.  fp32 rows: the ordered bits of the float without
+        // their low byte (the bound is rounded up again when it is read back).
+        unsigned v[4 * NT];
+        if (i8) {
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const int t = wave + 4 * i;
+                if (t < tiles) {
+                    const i32x4 a0 = rows_s[t * 128 + lane], a1 = rows_s[t * 128 + 64 + lane];
+                    const i32x4 rt = *reinterpret_cast<const i32x4*>(rt_s + 16 * t + 4 * g);
+                    i32x4 acc = {0, 0, 0, 0};
+                    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b0, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b1, acc, 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        v[4 * i + j] = 16 * t + 4 * g + j < rows ? ((unsigned)(qt + rt[j] - 2 * acc[j]) << 8 | (unsigned)(16 * t + 4 * g + j)) : kNone;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[4 * i + j] = kNone;
+                }
+            }
+        } else {
+            const float* qsrc = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.q) + (long long)(qg >> 5) * p.q_batch_bytes) + (qg & 31) * kDim;
+            f32x4 qf[8];
+#pragma unroll
+            for (int cc = 0; cc < 8; ++cc) qf[cc] = *reinterpret_cast<const f32x4*>(qsrc + 16 * cc + 4 * g);
+            const float qn = p.qnorm[qg];
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const int t = wave + 4 * i;
+                if (t < tiles) {
+                    const int row = min(start + 16 * t + r, start + rows - 1);
+                    f32x4 a[8];
+#pragma unroll
+                    for (int cc = 0; cc < 8; ++cc) a[cc] = *reinterpret_cast<const f32x4*>(p.vecs + (int64_t)row * kDim + 16 * cc + 4 * g);
+                    const f32x4 bn = *reinterpret_cast<const f32x4_u*>(p.vnorm + start + 16 * t + 4 * g);  // padded by 64
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int cc = 0; cc < 8; ++cc)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cc][j], qf[cc][j], acc, 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float d = p.metric ? -acc[j] : fmaf(-2.0f, acc[j], qn + bn[j]);
+                        v[4 * i + j] = 16 * t + 4 * g + j < rows ? ((f32_ordered(d) & ~0xffu) | (unsigned)(16 * t + 4 * g + j)) : kNone;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[4 * i + j] = kNone;
+                }
+            }
+        }
+        BL_STAMP(2);
+        // the wave's k smallest per column, ascending
+        for (int round = 0; round < p.k; ++round) {
+            unsigned m = v[0];
+#pragma unroll
+            for (int i = 1; i < 4 * NT; ++i) m = min(m, v[i]);
+            const unsigned x = col4_min_u32(m);
+#pragma unroll
+            for (int i = 0; i < 4 * NT; ++i) v[i] = v[i] == x ? kNone : v[i];  // (it has one holder)
+            if (g == 0) cand_s[(wave * 16 + r) * 16 + round] = x;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            // four-way merge: lane (column, w) walks wave w's list
+            const unsigned* mine = cand_s + (g * 16 + r) * 16;
+            int idx = 0;
+            unsigned head = mine[0];
+            float* out = p.tk + ((int64_t)qg * 2 + seg) * 16;
+            for (int round = 0; round < p.k; ++round) {
+                const unsigned x = col4_min_u32(head);
+                if (head == x && x != kNone) {
+                    ++idx;
+                    head = idx < p.k ? mine[idx] : kNone;
+                }
+                if (g == 0 && has) out[round] = x >= 0xff800000u ? VS_INF : i8 ? (float)(x >> 8) : f32_unordered(x | 0xffu);
+            }
+        }
+        __syncthreads();
+        e = e_nx;
+        e_nx = e_nx2;
+        b0 = nb0;
+        b1 = nb1;
+        qt = nqt;
+        BL_STAMP(3);
+#ifdef VS_STAMPS
+        if (p.dbg && threadIdx.x == 0 && part == 0 && c < 1024) {
+            p.dbg[(16384 + c) * 16 + 8] = n;
+            p.dbg[(16384 + c) * 16 + 9] = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7);       // XCC_ID
+            p.dbg[(16384 + c) * 16 + 10] = (int)__builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4);  // HW_ID low 16 bits
+        }
+#endif
+    }
+}
+
+// A query's bound from its segments' k smallest distances (ivf_bounds_list_body): the k-th smallest of their union, with
+// the slack ivf_tau_body gives it.  One thread per query; the launch also leaves the bound tables' counters zeroed.
+__global__ __launch_bounds__(256) void ivf_tau_combine_kernel(const IvfWideParams p) {
+    const int qg = blockIdx.x * 256 + threadIdx.x;
+    for (int c = qg; c < p.nlist; c += (int)gridDim.x * 256) p.zero[(int64_t)c * kIvfWideCntStride + 1] = 0;
+    const int batch = qg >> 5, qi = qg & 31;
+    if (batch >= p.n_batches || qi >= p.B) return;
+    const int ns = p.nseg[qg];
+    const float* a = p.tk + (int64_t)qg * 32;
+    const float* b = a + 16;
+    int i = 0, j = 0;
+    float kth = VS_INF;
+    for (int t = 0; t < p.k; ++t) {
+        const float av = (ns >= 1 && i < p.k) ? a[i] : VS_INF, bv = (ns >= 2 && j < p.k) ? b[j] : VS_INF;
+        if (av <= bv) {
+            kth = av;
+            ++i;
+        } else {
+            kth = bv;
+            ++j;
+        }
+    }
+    const bool i8 = p.vecs_u8 && p.metric == 0 && p.invalid[batch] == 0;
+    const float tb = i8 ? next_up(kth) : kth + 1e-4f * fabsf(kth) + 1e-30f;
+    p.tau[qg] = kth < VS_INF ? tb : VS_INF;
+    if (!(kth < VS_INF)) p.slow[qg] = 1;
+}
+
 // Work plan of one super-batch (blockIdx.y), several workgroups each (see ivf_group_plan_kernel): records of bounded cost.
 // A record is one kIvfWideUnit-row unit of a chunk whose list is probed, times one range of at most S of the slots of
 // the list's query table: (first row, chunk end, list, first slot | end slot << 16).  S = 256 (a record costs between 1
@@ -764,15 +986,18 @@ __device__ __forceinline__ void ivf_tau_body(const IvfWideParams& p, const int w
 constexpr int kIvfWideTiles = kIvfWideUnit / 16;  // 16-row MFMA tiles per unit
 constexpr int kIvfWideSplits = 3;  // S = 256 << i
 constexpr int kPlanThreads = 256, kPlanWaves = kPlanThreads / 64, kPlanClasses = 16;
-__device__ __forceinline__ void ivf_plan_body(const IvfWideParams& p, const int sb, const int slice, const int nsl) {
-    __shared__ int cnt_s[kIvfFastNlist];
-    __shared__ int s_carry;
-    __shared__ int s_tot[kPlanWaves][kIvfWideSplits];
-    __shared__ int s_ctot[kPlanClasses + 1], s_cpre[kPlanClasses + 1], s_cpos[kPlanClasses + 1];
-    __shared__ int s_shift;
+constexpr int kPlanLds = (kIvfFastNlist + 2 + kPlanWaves * kIvfWideSplits + 3 * (kPlanClasses + 1)) * 4;
+__device__ __forceinline__ void ivf_plan_body(const IvfWideParams& p, const int sb, const int slice, const int nsl, char* const lds) {
+    int* const cnt_s = reinterpret_cast<int*>(lds);  // [kIvfFastNlist]
+    int& s_carry = cnt_s[kIvfFastNlist];
+    int& s_shift = cnt_s[kIvfFastNlist + 1];
+    int (*s_tot)[kIvfWideSplits] = reinterpret_cast<int (*)[kIvfWideSplits]>(cnt_s + kIvfFastNlist + 2);  // [kPlanWaves]
+    int* const s_ctot = cnt_s + kIvfFastNlist + 2 + kPlanWaves * kIvfWideSplits;  // [kPlanClasses + 1] each
+    int* const s_cpre = s_ctot + kPlanClasses + 1;
+    int* const s_cpos = s_cpre + kPlanClasses + 1;
     const int tid = threadIdx.x;
 #ifdef VS_STAMPS
-#define PLAN_STAMP(i) do { if (p.dbg && tid == 0) p.dbg[(6144 + slice) * 16 + (i)] = (int)(__builtin_amdgcn_s_memrealtime() & 0x7fffffff); } while (0)
+#define PLAN_STAMP(i) do { if (p.dbg && tid == 0) p.dbg[(20480 + sb * 16 + slice) * 16 + (i)] = (int)(__builtin_amdgcn_s_memrealtime() & 0x7fffffff); } while (0)
 #else
 #define PLAN_STAMP(i)
 #endif
@@ -783,25 +1008,33 @@ __device__ __forceinline__ void ivf_plan_body(const IvfWideParams& p, const int 
     // Everything read from global memory is requested before the first barrier (one cache round trip, not one per phase):
     // the pair counters, the chunk table entries of the all-chunks pass (eight per thread in registers, more only for
     // very large indexes) and this thread's chunk of the workgroup's own slice.
+    // (every load is unconditional, at a clamped index: a load under a per-lane condition is waited for on the spot, and the
+    // dozen of them here were a dozen round trips, one after the other -- 9 of the body's 21 us)
     constexpr int EARLY = 8;
     int e_list[EARLY], e_rows[EARLY];
+    const int last_chunk = max(p.n_chunks - 1, 0);  // (n_chunks > 0: the wide pipeline is not used on an index without rows)
 #pragma unroll
     for (int i = 0; i < EARLY; ++i) {
-        const int chunk = tid + kPlanThreads * i;
-        e_list[i] = chunk < p.n_chunks ? p.chunk_list[chunk] : 0;
-        e_rows[i] = chunk < p.n_chunks ? p.chunk_rows[chunk] : 0;
+        const int chunk = min(tid + kPlanThreads * i, last_chunk);
+        e_list[i] = p.chunk_list[chunk];
+        e_rows[i] = p.chunk_rows[chunk];
     }
-    const int own = c0 + tid;
-    const int o_list = own < c1 ? p.chunk_list[own] : 0, o_rows = own < c1 ? p.chunk_rows[own] : 0, o_row0 = own < c1 ? p.chunk_trow0[own] : 0;
+    const int own = min(c0 + tid, last_chunk);
+    const int o_list = p.chunk_list[own], o_rows = p.chunk_rows[own], o_row0 = p.chunk_trow0[own];
     long long cand = 0;
     {
         constexpr int CPT = kIvfFastNlist / kPlanThreads;  // counters per thread: loaded together, then stored
         int n[CPT], len[CPT];
+        const bool want_len = p.cand_count && slice == 0;  // (workgroup-uniform)
 #pragma unroll
         for (int i = 0; i < CPT; ++i) {
-            const int c = tid + kPlanThreads * i;
-            n[i] = c < p.nlist ? p.zero[sb * ivf_wide_plan_words(p.nlist) + (int64_t)c * kIvfWideCntStride] : 0;
-            len[i] = (p.cand_count && slice == 0 && c < p.nlist) ? p.offsets[c + 1] - p.offsets[c] : 0;
+            if (kPlanThreads * i >= p.nlist) {  // (uniform)
+                n[i] = len[i] = 0;
+                continue;
+            }
+            const int c = min(tid + kPlanThreads * i, p.nlist - 1);
+            n[i] = p.zero[sb * ivf_wide_plan_words(p.nlist) + (int64_t)c * kIvfWideCntStride];
+            len[i] = want_len ? p.offsets[c + 1] - p.offsets[c] : 0;
         }
 #pragma unroll
         for (int i = 0; i < CPT; ++i) {
@@ -813,8 +1046,8 @@ __device__ __forceinline__ void ivf_plan_body(const IvfWideParams& p, const int 
                 // is filled up with the dummy slot (one workgroup does it; the entries are stale otherwise)
                 if (slice == 0)
                     for (int sl = nq; sl < ((nq + 15) & ~15); ++sl) p.lq[((int64_t)sb * p.nlist + c) * kIvfWideQ + sl] = kIvfWideQ * kDim;
+                cand += (long long)nq * len[i];
             }
-            cand += (long long)min(n[i], kIvfWideQ) * len[i];
         }
     }
     if (p.cand_count && slice == 0) {  // the candidate statistic (IVFIndex.cpp: total_candidates), one atomic per wave
@@ -891,6 +1124,7 @@ __device__ __forceinline__ void ivf_plan_body(const IvfWideParams& p, const int 
         }
         __syncthreads();
     }
+    PLAN_STAMP(4);
     for (int base = c0; base < c1; base += kPlanThreads) {
         const int chunk = base + tid;
         if (chunk >= c1) break;
@@ -916,9 +1150,18 @@ __device__ __forceinline__ void ivf_plan_body(const IvfWideParams& p, const int 
 // Bounds and plan in ONE launch (both need the pick kernel's output only and take about 10 us each: side by side instead
 // of one after the other).  The first n_plan * n_sb workgroups plan, the rest compute bounds, two queries each.
 __global__ __launch_bounds__(256) void ivf_tau_plan_kernel(const IvfWideParams p, const int n_plan, const int n_sb) {
+    __shared__ __attribute__((aligned(16))) char lds[kPlanLds];
     const int wg = blockIdx.x;
-    if (wg < n_plan * n_sb) ivf_plan_body(p, wg / n_plan, wg % n_plan, n_plan);
+    if (wg < n_plan * n_sb) ivf_plan_body(p, wg / n_plan, wg % n_plan, n_plan, lds);
     else ivf_tau_body(p, wg - n_plan * n_sb);
+}
+// ... with list-major bounds.  Four workgroups per CU: the bounds' workgroups are one short chain of cache misses each,
+// all of a launch group's lists should be in flight together.
+__global__ __launch_bounds__(256, 4) void ivf_bounds_plan_kernel(const IvfWideParams p, const int n_plan, const int n_sb) {
+    __shared__ __attribute__((aligned(16))) char lds[kBoundLds > kPlanLds ? kBoundLds : kPlanLds];
+    const int wg = blockIdx.x;
+    if (wg < n_plan * n_sb) ivf_plan_body(p, wg / n_plan, wg % n_plan, n_plan, lds);
+    else ivf_bounds_list_body(p, (wg - n_plan * n_sb) % p.nlist, (wg - n_plan * n_sb) / p.nlist, lds);
 }
 
 // The list-major scan of one super-batch (blockIdx.y).  A workgroup stages the super-batch's queries once (as bytes: 128
@@ -1329,10 +1572,19 @@ int ivf_wide_waves(int num_cus, int n_sb) { return ivf_wide_grid_x(num_cus, n_sb
 hipError_t launch_ivf_wide_bounds_plan(const IvfWideParams& p, hipStream_t s, int what) {
     if (p.nlist > kIvfFastNlist || p.nprobe > kIvfMaxProbe || p.k > 16 || p.sb_batches < 1 || p.sb_batches > kIvfWideBatches) return hipErrorInvalidValue;
     const int n_sb = (p.n_batches + p.sb_batches - 1) / p.sb_batches;
-    const int n_plan = (what & 2) ? std::max(4, 16 / n_sb) : 0;  // (every planning workgroup reads all pair counters, a cache line each)
-    const int n_tau = (what & 1) ? (p.n_batches * kMaxBatch + 1) / 2 : 0;
+    static const int plan_wgs = getenv("VSEARCH_PLAN_WGS") ? atoi(getenv("VSEARCH_PLAN_WGS")) : 8;  // (tuning knob)
+    const int n_plan = (what & 2) ? std::max(plan_wgs, 16 / n_sb) : 0;  // (every planning workgroup reads all pair counters, a cache line each)
+    const int n_tau = !(what & 1) ? 0 : p.tq ? p.nlist * kBoundParts : (p.n_batches * kMaxBatch + 1) / 2;
     if (n_plan * n_sb + n_tau == 0) return hipSuccess;
-    hipLaunchKernelGGL(ivf_tau_plan_kernel, dim3(n_plan * n_sb + n_tau), dim3(256), 0, s, p, n_plan, n_sb);
+    if ((what & 1) && p.tq && (p.n_batches * kMaxBatch > 0x10000 || p.n_batches * kMaxBatch > p.tq_cap)) return hipErrorInvalidValue;
+    static const bool split = getenv("VSEARCH_SPLIT_BP") != nullptr;  // (diagnostic: the two halves as launches of their own)
+    if (!p.tq || !(what & 1)) hipLaunchKernelGGL(ivf_tau_plan_kernel, dim3(n_plan * n_sb + n_tau), dim3(256), 0, s, p, n_plan, n_sb);
+    else if (split && n_plan) {
+        hipLaunchKernelGGL(ivf_bounds_plan_kernel, dim3(n_tau), dim3(256), 0, s, p, 0, n_sb);
+        hipLaunchKernelGGL(ivf_bounds_plan_kernel, dim3(n_plan * n_sb), dim3(256), 0, s, p, n_plan, n_sb);
+    } else
+        hipLaunchKernelGGL(ivf_bounds_plan_kernel, dim3(n_plan * n_sb + n_tau), dim3(256), 0, s, p, n_plan, n_sb);
+    if ((what & 1) && p.tq) hipLaunchKernelGGL(ivf_tau_combine_kernel, dim3((p.n_batches * kMaxBatch + 255) / 256), dim3(256), 0, s, p);
     return hipGetLastError();
 }
 

@@ -259,6 +259,12 @@ struct IvfGroup {
     int32_t* w_cnt;                  // [n_sb][ivf_wide_plan_words] pair counters (pre-set to 0), list c's at word c * kIvfWideCntStride
     int32_t* w_lq;                   // [n_sb][nlist][w_q] slots: 128 * (slot of the query in its super-batch)
     int w_q;
+    // ... and enters the query in the bound tables of its two nearest lists that hold rows (ivf_bounds_list_body)
+    int32_t* w_tq;                   // [nlist][w_tq_cap] entries: query of the launch group | segment << 16
+    int w_tq_cap;
+    int32_t* w_tcnt;                 // list c's entry counter at word c * kIvfWideCntStride + 1 (pre-set to 0)
+    int32_t* w_nseg;                 // [n_batches][32] segments the query has (0..2)
+    const int32_t* t_offsets;        // [nlist + 1] extents of the rows the bounds are taken from
     int32_t* dbg;                    // diagnostic builds (-DVS_STAMPS) only: time stamps of the pick kernel
 };
 
@@ -321,6 +327,11 @@ struct IvfWideParams {
     int32_t* units;           // [n_sb][units_cap][4] records (first row, chunk end, list, first slot | end slot << 16)
     long long units_sb_stride;  // in int32 (= 4 units_cap)
     int units_cap;            // records per super-batch the plan may hold (>= the index's units: the unsplit plan fits)
+    // bounds, list-major: entries of the pick kernel (see IvfGroup), entry counter of list c at zero[c * kIvfWideCntStride + 1]
+    const int32_t* tq;        // [nlist][tq_cap]
+    int tq_cap;
+    float* tk;                // [n_batches][32][2][16] the k smallest distances per (query, segment), ascending
+    const int32_t* nseg;      // [n_batches][32]
     float* tau;               // [n_batches][32] bounds
     int32_t* slow;            // [n_batches][32] (pre-set to 0): no bound could be had -> exact slow path
     CandSink sink;
