@@ -184,7 +184,7 @@ struct vs_index {
         int units_cap = 0;
         float* tau = nullptr;       // [1024]
         int32_t* tq = nullptr;      // [nlist][group queries] bound tables (ivf_bounds_list_body)
-        float* tk = nullptr;        // [group queries][2][16]
+        float* tk = nullptr;        // [group queries][kBoundSegs][16]
         int32_t* nseg = nullptr;    // [group queries]
         float* qnorm = nullptr;     // [1024]
         int8_t* q8 = nullptr;       // [1024][128]
@@ -901,7 +901,7 @@ int ensure_ivf_wide(vs_index* h, int lane) {
     if ((rc = dev_alloc(&W.tau, nq))) return rc;
     if (!h->ivf_bounds_query && nq <= 0x10000) {
         if ((rc = dev_alloc(&W.tq, (size_t)h->nlist * nq))) return rc;
-        if ((rc = dev_alloc(&W.tk, nq * 32))) return rc;
+        if ((rc = dev_alloc(&W.tk, nq * vs::kBoundSegs * 16))) return rc;
         if ((rc = dev_alloc(&W.nseg, nq))) return rc;
     }
     if ((rc = dev_alloc(&W.qnorm, nq))) return rc;

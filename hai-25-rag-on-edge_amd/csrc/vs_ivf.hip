@@ -111,54 +111,62 @@ __device__ __forceinline__ T* mb_adv(T* ptr, long long bytes) {
 // global memory: the centroids are L2 resident) and the batch's <= 32 queries as two 16-column B operands -- the same
 // v_mfma_f32_16x16x4_f32 chain and epilogue as the brute-force scan, so a centroid score is the number that scan
 // would produce.  1024 x 1024 x 128 per group of 32 batches: a few microseconds.
-__global__ __launch_bounds__(256) void ivf_coarse_mfma_kernel(const float* __restrict__ q, int B, const float* __restrict__ cents,
+__global__ __launch_bounds__(256) void ivf_coarse_mfma_kernel(const float* __restrict__ q_all, int B, const float* __restrict__ cents,
                                                              const float* __restrict__ cnorm, int nlist, int metric,
-                                                             float* __restrict__ scores, int ld, IvfMulti mb, IvfGroup grp, int prep_only) {
-    {
-        const long long y = blockIdx.y;
-        q = mb_adv(q, y * mb.q);
-        scores = mb_adv(scores, y * mb.slab);
-    }
+                                                             float* __restrict__ scores_all, int ld, IvfMulti mb, IvfGroup grp, int prep_only,
+                                                             int nct) {
+    // A workgroup keeps its batch's queries (LDS, then both 16-column B operands in registers, with their norms) for `nct`
+    // tiles of 64 centroids in a row: blockIdx.x = group of nct tiles.  One tile per workgroup read 48 KB for half a MFLOP
+    // of MFMA work and worked out the same 32 norms in every one of the 16 workgroups of a batch: 8192 queries cost 44 us,
+    // three times what the arithmetic takes.  The next tile's centroids are in flight while this one is scored.
+    const int y = blockIdx.y;
+    const float* q = mb_adv(q_all, (long long)y * mb.q);
+    float* scores = mb_adv(scores_all, (long long)y * mb.slab);
+    const int n_tiles = (nlist + 63) >> 6;
+    const int t0 = (int)blockIdx.x * nct, t1 = min(n_tiles, t0 + nct);
+#ifdef VS_STAMPS
+#define CO_STAMP(i) do { if (grp.dbg && threadIdx.x == 0 && !prep_only) grp.dbg[(20480 + (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x) * 16 + (i)] = (int)(__builtin_amdgcn_s_memrealtime() & 0x7fffffff); } while (0)
+#else
+#define CO_STAMP(i)
+#endif
+    CO_STAMP(0);
     __shared__ float qn_s[kMaxBatch];
-    // Both operands go through LDS: the workgroup's 64 centroids and the batch's queries are read from global memory as
+    // Both operands go through LDS: the 64 centroids of a tile and the batch's queries are read from global memory as
     // whole rows (a wave instruction = 1 KB in one piece) and the MFMA fragments are cut out of LDS.  Read as fragments
     // straight from memory, every load instruction touched 64 separate 16-byte pieces 512 bytes apart, and the address
     // unit, not the arithmetic, set the kernel's time (13 us).  Rows are 132 floats apart in LDS: fragment reads of
     // 8 neighbouring rows then fall into different banks.
     constexpr int LD = kDim + 4;
-    __shared__ __attribute__((aligned(16))) float q_s[kMaxBatch * LD];
+    // (one place for both: the queries are in registers when the first tile is written -- 34 KB, four workgroups per CU)
     __shared__ __attribute__((aligned(16))) float c_s[64 * LD];
+    float* const q_s = c_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
-    const int row0 = ((int)blockIdx.x * 4 + wave) * 16;  // this wave's centroid tile (the centroid array has kScanPadRows spare rows)
-    {
-        f32x4 vc[8], vq[4];
+    f32x4 vc[8], cn_nx = {0.f, 0.f, 0.f, 0.f};
+    auto load_tile = [&](int t) {  // (every load unconditional: the centroid array has kScanPadRows spare rows, the norms 64)
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int idx = tid + 256 * i;  // float4 (row, column) of the 64 x 32 tile
-            vc[i] = *reinterpret_cast<const f32x4*>(cents + ((int64_t)blockIdx.x * 64 + (idx >> 5)) * kDim + 4 * (idx & 31));
+            vc[i] = *reinterpret_cast<const f32x4*>(cents + ((int64_t)t * 64 + (idx >> 5)) * kDim + 4 * (idx & 31));
         }
+        cn_nx = *reinterpret_cast<const f32x4*>(cnorm + t * 64 + wave * 16 + 4 * g);
+    };
+    {
+        f32x4 vq[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i;  // float4 (row, column) of the 32 x 32 tile
+            vq[i] = *reinterpret_cast<const f32x4*>(q + min(idx >> 5, B - 1) * kDim + 4 * (idx & 31));
+        }
+        if (!prep_only) load_tile(t0);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int idx = tid + 256 * i;
-            vq[i] = (idx >> 5) < B ? *reinterpret_cast<const f32x4*>(q + (idx >> 5) * kDim + 4 * (idx & 31)) : (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int idx = tid + 256 * i;
-            *reinterpret_cast<f32x4*>(c_s + (idx >> 5) * LD + 4 * (idx & 31)) = vc[i];
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int idx = tid + 256 * i;
-            *reinterpret_cast<f32x4*>(q_s + (idx >> 5) * LD + 4 * (idx & 31)) = vq[i];
+            *reinterpret_cast<f32x4*>(q_s + (idx >> 5) * LD + 4 * (idx & 31)) = (idx >> 5) < B ? vq[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
     }
-    const f32x4 cn = *reinterpret_cast<const f32x4*>(cnorm + row0 + 4 * g);  // padded by 64
     __syncthreads();
-    f32x4 a[8], qf[2][8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) a[c] = *reinterpret_cast<const f32x4*>(c_s + (wave * 16 + r) * LD + 16 * c + 4 * g);
+    f32x4 qf[2][8];
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -178,11 +186,11 @@ __global__ __launch_bounds__(256) void ivf_coarse_mfma_kernel(const float* __res
 #pragma unroll
         for (int u = 1; u < 8; ++u) sum = sum + __shfl(acc, b8 + u);
         if (j == 0) qn_s[row] = row < B ? sum : 0.f;
-        // wide pipeline: the first block of every batch also writes the queries as bytes, their constant terms and the
+        // wide pipeline: one of the batch's workgroups also writes the queries as bytes, their constant terms and the
         // batch's "byte valued" verdict (what seed_qnorm_kernel does for the brute-force scans); a thread converts 16
         // neighbouring components and stores them as one 16-byte word
-        if (grp.w_q8 != nullptr && blockIdx.x == 0) {
-            const int64_t qslot = (int64_t)blockIdx.y * kMaxBatch + row;
+        if (grp.w_q8 != nullptr && y % (int)gridDim.x == (int)blockIdx.x) {  // (workgroup-uniform)
+            const int64_t qslot = (int64_t)y * kMaxBatch + row;
             int part = 0;
             bool q_ok = true;
             int w[4] = {0, 0, 0, 0};
@@ -209,35 +217,80 @@ __global__ __launch_bounds__(256) void ivf_coarse_mfma_kernel(const float* __res
             }
             // (written as 0 or 1, never left over from the previous group: nobody has to clear it)
             const int bad = __syncthreads_or(q_ok ? 0 : 1);  // (workgroup-uniform branch: every thread is here)
-            if (tid == 0) grp.w_invalid[blockIdx.y] = bad ? 1 : 0;
-            if (tid == 0 && blockIdx.y == 0 && grp.w_overflow) grp.w_overflow[0] = 0;  // the previous group's verdict has been read
-            if (tid == 0 && blockIdx.y == 0 && grp.w_glist) grp.w_glist[0] = 0;        // ... and so has its list of left-over queries
+            if (tid == 0) grp.w_invalid[y] = bad ? 1 : 0;
+            if (tid == 0 && y == 0 && grp.w_overflow) grp.w_overflow[0] = 0;  // the previous group's verdict has been read
+            if (tid == 0 && y == 0 && grp.w_glist) grp.w_glist[0] = 0;        // ... and so has its list of left-over queries
         }
     }
     __syncthreads();
+    CO_STAMP(1);
     if (prep_only) return;  // (sharded front half: the queries of ALL slices are prepared on every rank, scored only on their own)
+    const float qn[2] = {qn_s[r], qn_s[16 + r]};
+    f32x4 d_out[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};  // the wave's scores of a tile: 16 centroids x 2 x 16 queries
+    auto store_scores = [&](int t) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int qrow = h * 16 + r;
-        if (h * 16 >= B) break;  // workgroup-uniform
-        const bool qv = qrow < B;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int h = 0; h < 2; ++h)
+            if (h * 16 + r < B) *reinterpret_cast<f32x4*>(scores + (int64_t)(h * 16 + r) * ld + t * 64 + wave * 16 + 4 * g) = d_out[h];
+    };
+    for (int t = t0; t < t1; ++t) {
 #pragma unroll
-        for (int c = 0; c < 8; ++c)
+        for (int i = 0; i < 8; ++i) {
+            const int idx = tid + 256 * i;
+            *reinterpret_cast<f32x4*>(c_s + (idx >> 5) * LD + 4 * (idx & 31)) = vc[i];
+        }
+        const f32x4 cn = cn_nx;
+        __syncthreads();
+        if (t == t0 + 1) CO_STAMP(3);
+        if (t + 1 < t1) load_tile(t + 1);  // (workgroup-uniform)
+        // The previous tile's scores are stored HERE, a tile late: stores and loads share one in-order counter, and the
+        // wait for the next tile's centroids at the top of the loop was also a wait for stores issued a moment before it
+        // (a microsecond per tile).  Now everything it waits for was issued a whole tile earlier.
+        if (t > t0) store_scores(t - 1);
+        f32x4 a[8];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][i], qf[h][c][i], acc, 0, 0, 0);
-        if (qv) {
-            const float qn = qn_s[qrow];
-            f32x4 d;
+        for (int c = 0; c < 8; ++c) a[c] = *reinterpret_cast<const f32x4*>(c_s + (wave * 16 + r) * LD + 16 * c + 4 * g);
+        const int row0 = t * 64 + wave * 16;  // this wave's 16 centroids
+        if (t == t0 + 1) CO_STAMP(4);
+        // (the two column blocks' chains are interleaved: a chain alone waits a few cycles between dependent MFMAs)
+        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        if (B > 16) {  // workgroup-uniform
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][i], qf[0][c][i], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][i], qf[1][c][i], acc[1], 0, 0, 0);
+                }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][i], qf[0][c][i], acc[0], 0, 0, 0);
+        }
+        if (t == t0 + 1) CO_STAMP(5);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float v = metric ? -acc[j] : fmaf(-2.0f, acc[j], qn + cn[j]);
+                float v = metric ? -acc[h][j] : fmaf(-2.0f, acc[h][j], qn[h] + cn[j]);
                 if (!(v == v) || row0 + 4 * g + j >= nlist) v = VS_INF;  // NaN never wins; rows past nlist are padding
-                d[j] = v;
+                d_out[h][j] = v;
             }
-            *reinterpret_cast<f32x4*>(scores + (int64_t)qrow * ld + row0 + 4 * g) = d;
         }
+        if (t == t0) CO_STAMP(2);
+        if (t == t0 + 1) CO_STAMP(6);
+        __syncthreads();  // (the tile's place is written again)
+        if (t == t0 + 1) CO_STAMP(8);
     }
+    store_scores(t1 - 1);
+    CO_STAMP(7);
+}
+
+// tiles of 64 centroids a workgroup of the coarse kernel takes in a row: as many as leave the launch 512 workgroups (two per
+// CU), 8 at most
+static int coarse_nct(int tiles, int n_batches) {
+    static const int forced = getenv("VSEARCH_COARSE_NCT") ? atoi(getenv("VSEARCH_COARSE_NCT")) : 0;  // (tuning knob)
+    return forced > 0 ? forced : std::max(1, std::min(8, tiles * n_batches / 512));
 }
 
 // Coarse stage, part 2 (std::nth_element at IVFIndex.cpp:711, made deterministic: ascending (dist, id)): one 256-thread
@@ -354,14 +407,13 @@ __global__ __launch_bounds__(256) void ivf_pick_kernel(const float* __restrict__
         const int c = tid < nprobe ? s_probe[tid] : -1;
         const bool rows = c >= 0 && grp.t_offsets[c + 1] > grp.t_offsets[c];
         const unsigned long long mask = __ballot(rows);
-        const unsigned long long rest = mask & (mask - 1);
-        const int first = mask ? __builtin_ctzll(mask) : -1, second = rest ? __builtin_ctzll(rest) : -1;
+        const int seg = __builtin_popcountll(mask & ((1ull << tid) - 1));  // lists with rows before this one
         const int qg = (int)blockIdx.y * kMaxBatch + b;
-        if (tid == first || tid == second) {
+        if (rows && seg < kBoundSegs) {
             const int slot = atomicAdd(grp.w_tcnt + (int64_t)c * kIvfWideCntStride + 1, 1);  // < w_tq_cap: once per query
-            grp.w_tq[(int64_t)c * grp.w_tq_cap + slot] = qg | (tid == second ? 1 << 16 : 0);
+            grp.w_tq[(int64_t)c * grp.w_tq_cap + slot] = qg | seg << 16;
         }
-        if (tid == 0) grp.w_nseg[qg] = min(__builtin_popcountll(mask), 2);
+        if (tid == 0) grp.w_nseg[qg] = min(__builtin_popcountll(mask), kBoundSegs);
     }
     if (!grp.w_cnt) return;  // probes only (sharded front half: the slot tables are filled after the exchange)
     {
@@ -501,8 +553,9 @@ __global__ __launch_bounds__(256) void ivf_scan_kernel(const IvfScanParams p) {
 hipError_t launch_ivf_coarse_pick(const float* q, int B, const float* cents, const float* cnorm, int nlist, int nprobe,
                                   int metric, float* scores, int ld, int32_t* probes, const IvfGroup& grp, hipStream_t s, int n_batches) {
     if (nprobe > 256 || nlist > kIvfFastNlist || ld < ((nlist + 63) & ~63)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(ivf_coarse_mfma_kernel, dim3((nlist + 63) / 64, n_batches), dim3(256), 0, s, q, B, cents, cnorm, nlist, metric,
-                       scores, ld, grp.mb, grp, 0);
+    const int tiles = (nlist + 63) / 64, nct = coarse_nct(tiles, n_batches);
+    hipLaunchKernelGGL(ivf_coarse_mfma_kernel, dim3((tiles + nct - 1) / nct, n_batches), dim3(256), 0, s, q, B, cents, cnorm, nlist, metric,
+                       scores, ld, grp.mb, grp, 0, nct);
     if (nlist <= 1024) hipLaunchKernelGGL(ivf_pick_kernel<4>, dim3(B, n_batches), dim3(256), 0, s, scores, ld, nlist, nprobe, probes, grp);
     else if (nlist <= 2048) hipLaunchKernelGGL(ivf_pick_kernel<8>, dim3(B, n_batches), dim3(256), 0, s, scores, ld, nlist, nprobe, probes, grp);
     else hipLaunchKernelGGL(ivf_pick_kernel<16>, dim3(B, n_batches), dim3(256), 0, s, scores, ld, nlist, nprobe, probes, grp);
@@ -513,7 +566,7 @@ hipError_t launch_ivf_coarse_pick(const float* q, int B, const float* cents, con
 hipError_t launch_ivf_prep_queries(const float* q, int B, const float* cents, const float* cnorm, int nlist, const IvfGroup& grp,
                                    hipStream_t s, int n_batches) {
     if (!grp.w_q8 || !grp.w_qterm || !grp.w_qnorm || !grp.w_invalid) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(ivf_coarse_mfma_kernel, dim3(1, n_batches), dim3(256), 0, s, q, B, cents, cnorm, nlist, 0, (float*)nullptr, 0, grp.mb, grp, 1);
+    hipLaunchKernelGGL(ivf_coarse_mfma_kernel, dim3(1, n_batches), dim3(256), 0, s, q, B, cents, cnorm, nlist, 0, (float*)nullptr, 0, grp.mb, grp, 1, 1);
     return hipGetLastError();
 }
 
@@ -784,7 +837,7 @@ __device__ __forceinline__ void ivf_tau_body(const IvfWideParams& p, const int w
 // workgroups.
 constexpr int kBoundParts = 2;
 constexpr int kBoundLds = kIvfTauRows * kDim + kIvfTauRows * 4 + 4 * 16 * 16 * 4;  // rows | row terms | the waves' lists
-__device__ __forceinline__ void ivf_bounds_list_body(const IvfWideParams& p, const int c, const int part, char* const lds) {
+__device__ __forceinline__ void ivf_bounds_list_body(const IvfWideParams& p, const int c, const int part, char* const lds, const int pad_sb) {
     typedef int i32x4 __attribute__((ext_vector_type(4)));
     typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -803,6 +856,14 @@ __device__ __forceinline__ void ivf_bounds_list_body(const IvfWideParams& p, con
     int inv = 0;
     for (int b = lane; b < p.n_batches; b += 64) inv |= p.invalid[b];
     const int n_units = (n + 15) >> 4;
+    if (part == 0 && tid < 16 * pad_sb) {
+        // on the side (the plan's job otherwise, one store after the other): the scan takes a list's slot table 16 entries at
+        // a time without looking at the count, the last block of every super-batch's table is filled up with the dummy slot
+        const int sb = tid >> 4;
+        const int nq = min(p.zero[sb * ivf_wide_plan_words(p.nlist) + (int64_t)c * kIvfWideCntStride], kIvfWideQ);
+        const int sl = (nq & ~15) + (tid & 15);
+        if (sl >= nq && (nq & 15)) p.lq[((int64_t)sb * p.nlist + c) * kIvfWideQ + sl] = kIvfWideQ * kDim;
+    }
     BL_STAMP(1);
     if (part >= n_units) return;  // (most lists have a unit or two: the other parts' workgroups end here)
     const int tiles = (rows + 15) >> 4;
@@ -835,7 +896,7 @@ __device__ __forceinline__ void ivf_bounds_list_body(const IvfWideParams& p, con
         qt = p.qterm[qg];
 #pragma unroll
         for (int j = 0; j < PIECES; ++j) rows_s[tid + 256 * j] = piece[j];
-        rt_s[tid] = rt_v;
+        if (tid < kIvfTauRows) rt_s[tid] = rt_v;
         __syncthreads();
     }
     for (int u = part; u < n_units; u += kBoundParts) {
@@ -923,7 +984,7 @@ __device__ __forceinline__ void ivf_bounds_list_body(const IvfWideParams& p, con
             const unsigned* mine = cand_s + (g * 16 + r) * 16;
             int idx = 0;
             unsigned head = mine[0];
-            float* out = p.tk + ((int64_t)qg * 2 + seg) * 16;
+            float* out = p.tk + ((int64_t)qg * kBoundSegs + seg) * 16;
             for (int round = 0; round < p.k; ++round) {
                 const unsigned x = col4_min_u32(head);
                 if (head == x && x != kNone) {
@@ -958,19 +1019,30 @@ __global__ __launch_bounds__(256) void ivf_tau_combine_kernel(const IvfWideParam
     const int batch = qg >> 5, qi = qg & 31;
     if (batch >= p.n_batches || qi >= p.B) return;
     const int ns = p.nseg[qg];
-    const float* a = p.tk + (int64_t)qg * 32;
-    const float* b = a + 16;
-    int i = 0, j = 0;
+    const float* lists = p.tk + (int64_t)qg * kBoundSegs * 16;
+    int pos[kBoundSegs];
+    float head[kBoundSegs];
+#pragma unroll
+    for (int sgm = 0; sgm < kBoundSegs; ++sgm) {
+        pos[sgm] = 0;
+        head[sgm] = sgm < ns ? lists[sgm * 16] : VS_INF;
+    }
     float kth = VS_INF;
-    for (int t = 0; t < p.k; ++t) {
-        const float av = (ns >= 1 && i < p.k) ? a[i] : VS_INF, bv = (ns >= 2 && j < p.k) ? b[j] : VS_INF;
-        if (av <= bv) {
-            kth = av;
-            ++i;
-        } else {
-            kth = bv;
-            ++j;
-        }
+    for (int t = 0; t < p.k; ++t) {  // k steps of a merge of the segments' ascending lists
+        int best = 0;
+#pragma unroll
+        for (int sgm = 1; sgm < kBoundSegs; ++sgm)
+            if (head[sgm] < head[best]) best = sgm;
+        kth = head[0];
+#pragma unroll
+        for (int sgm = 1; sgm < kBoundSegs; ++sgm)
+            if (sgm == best) kth = head[sgm];
+#pragma unroll
+        for (int sgm = 0; sgm < kBoundSegs; ++sgm)
+            if (sgm == best) {
+                ++pos[sgm];
+                head[sgm] = (sgm < ns && pos[sgm] < p.k) ? lists[sgm * 16 + pos[sgm]] : VS_INF;
+            }
     }
     const bool i8 = p.vecs_u8 && p.metric == 0 && p.invalid[batch] == 0;
     const float tb = i8 ? next_up(kth) : kth + 1e-4f * fabsf(kth) + 1e-30f;
@@ -987,7 +1059,8 @@ constexpr int kIvfWideTiles = kIvfWideUnit / 16;  // 16-row MFMA tiles per unit
 constexpr int kIvfWideSplits = 3;  // S = 256 << i
 constexpr int kPlanThreads = 256, kPlanWaves = kPlanThreads / 64, kPlanClasses = 16;
 constexpr int kPlanLds = (kIvfFastNlist + 2 + kPlanWaves * kIvfWideSplits + 3 * (kPlanClasses + 1)) * 4;
-__device__ __forceinline__ void ivf_plan_body(const IvfWideParams& p, const int sb, const int slice, const int nsl, char* const lds) {
+__device__ __forceinline__ void ivf_plan_body(const IvfWideParams& p, const int sb, const int slice, const int nsl, char* const lds,
+                                              const bool pad_tables = true) {
     int* const cnt_s = reinterpret_cast<int*>(lds);  // [kIvfFastNlist]
     int& s_carry = cnt_s[kIvfFastNlist];
     int& s_shift = cnt_s[kIvfFastNlist + 1];
@@ -1044,7 +1117,8 @@ __device__ __forceinline__ void ivf_plan_body(const IvfWideParams& p, const int 
                 cnt_s[c] = nq;
                 // the scan takes a list's slot table 16 entries at a time without looking at the count: the last block
                 // is filled up with the dummy slot (one workgroup does it; the entries are stale otherwise)
-                if (slice == 0)
+                // (the list-major bounds' workgroups do it instead when they run in the same launch)
+                if (slice == 0 && pad_tables)
                     for (int sl = nq; sl < ((nq + 15) & ~15); ++sl) p.lq[((int64_t)sb * p.nlist + c) * kIvfWideQ + sl] = kIvfWideQ * kDim;
                 cand += (long long)nq * len[i];
             }
@@ -1157,11 +1231,11 @@ __global__ __launch_bounds__(256) void ivf_tau_plan_kernel(const IvfWideParams p
 }
 // ... with list-major bounds.  Four workgroups per CU: the bounds' workgroups are one short chain of cache misses each,
 // all of a launch group's lists should be in flight together.
-__global__ __launch_bounds__(256, 4) void ivf_bounds_plan_kernel(const IvfWideParams p, const int n_plan, const int n_sb) {
+__global__ __launch_bounds__(256, 4) void ivf_bounds_plan_kernel(const IvfWideParams p, const int n_plan, const int n_sb, const bool pad_here) {
     __shared__ __attribute__((aligned(16))) char lds[kBoundLds > kPlanLds ? kBoundLds : kPlanLds];
     const int wg = blockIdx.x;
-    if (wg < n_plan * n_sb) ivf_plan_body(p, wg / n_plan, wg % n_plan, n_plan, lds);
-    else ivf_bounds_list_body(p, (wg - n_plan * n_sb) % p.nlist, (wg - n_plan * n_sb) / p.nlist, lds);
+    if (wg < n_plan * n_sb) ivf_plan_body(p, wg / n_plan, wg % n_plan, n_plan, lds, pad_here);
+    else ivf_bounds_list_body(p, (wg - n_plan * n_sb) % p.nlist, (wg - n_plan * n_sb) / p.nlist, lds, pad_here ? 0 : n_sb);
 }
 
 // The list-major scan of one super-batch (blockIdx.y).  A workgroup stages the super-batch's queries once (as bytes: 128
@@ -1572,18 +1646,19 @@ int ivf_wide_waves(int num_cus, int n_sb) { return ivf_wide_grid_x(num_cus, n_sb
 hipError_t launch_ivf_wide_bounds_plan(const IvfWideParams& p, hipStream_t s, int what) {
     if (p.nlist > kIvfFastNlist || p.nprobe > kIvfMaxProbe || p.k > 16 || p.sb_batches < 1 || p.sb_batches > kIvfWideBatches) return hipErrorInvalidValue;
     const int n_sb = (p.n_batches + p.sb_batches - 1) / p.sb_batches;
-    static const int plan_wgs = getenv("VSEARCH_PLAN_WGS") ? atoi(getenv("VSEARCH_PLAN_WGS")) : 8;  // (tuning knob)
+    static const int plan_wgs = getenv("VSEARCH_PLAN_WGS") ? atoi(getenv("VSEARCH_PLAN_WGS")) : 16;  // (tuning knob)
     const int n_plan = (what & 2) ? std::max(plan_wgs, 16 / n_sb) : 0;  // (every planning workgroup reads all pair counters, a cache line each)
     const int n_tau = !(what & 1) ? 0 : p.tq ? p.nlist * kBoundParts : (p.n_batches * kMaxBatch + 1) / 2;
     if (n_plan * n_sb + n_tau == 0) return hipSuccess;
     if ((what & 1) && p.tq && (p.n_batches * kMaxBatch > 0x10000 || p.n_batches * kMaxBatch > p.tq_cap)) return hipErrorInvalidValue;
     static const bool split = getenv("VSEARCH_SPLIT_BP") != nullptr;  // (diagnostic: the two halves as launches of their own)
+    // (who pads the slot tables: the bounds' workgroups if the tables are complete when they run, i.e. with the plan beside them)
     if (!p.tq || !(what & 1)) hipLaunchKernelGGL(ivf_tau_plan_kernel, dim3(n_plan * n_sb + n_tau), dim3(256), 0, s, p, n_plan, n_sb);
     else if (split && n_plan) {
-        hipLaunchKernelGGL(ivf_bounds_plan_kernel, dim3(n_tau), dim3(256), 0, s, p, 0, n_sb);
-        hipLaunchKernelGGL(ivf_bounds_plan_kernel, dim3(n_plan * n_sb), dim3(256), 0, s, p, n_plan, n_sb);
+        hipLaunchKernelGGL(ivf_bounds_plan_kernel, dim3(n_tau), dim3(256), 0, s, p, 0, n_sb, n_sb > 16);
+        hipLaunchKernelGGL(ivf_bounds_plan_kernel, dim3(n_plan * n_sb), dim3(256), 0, s, p, n_plan, n_sb, n_sb > 16);
     } else
-        hipLaunchKernelGGL(ivf_bounds_plan_kernel, dim3(n_plan * n_sb + n_tau), dim3(256), 0, s, p, n_plan, n_sb);
+        hipLaunchKernelGGL(ivf_bounds_plan_kernel, dim3(n_plan * n_sb + n_tau), dim3(256), 0, s, p, n_plan, n_sb, n_plan == 0 || n_sb > 16);
     if ((what & 1) && p.tq) hipLaunchKernelGGL(ivf_tau_combine_kernel, dim3((p.n_batches * kMaxBatch + 255) / 256), dim3(256), 0, s, p);
     return hipGetLastError();
 }

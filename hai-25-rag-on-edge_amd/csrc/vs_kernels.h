@@ -263,7 +263,7 @@ struct IvfGroup {
     int32_t* w_tq;                   // [nlist][w_tq_cap] entries: query of the launch group | segment << 16
     int w_tq_cap;
     int32_t* w_tcnt;                 // list c's entry counter at word c * kIvfWideCntStride + 1 (pre-set to 0)
-    int32_t* w_nseg;                 // [n_batches][32] segments the query has (0..2)
+    int32_t* w_nseg;                 // [n_batches][32] segments the query has (0..kBoundSegs)
     const int32_t* t_offsets;        // [nlist + 1] extents of the rows the bounds are taken from
     int32_t* dbg;                    // diagnostic builds (-DVS_STAMPS) only: time stamps of the pick kernel
 };
@@ -285,7 +285,14 @@ hipError_t launch_ivf_fill(const int32_t* gathered, long long blk_words, int B, 
 // list), survivors to a CandSink, ranking by merge_compact_kernel -- no candidate-score arrays, no selection kernel.
 constexpr int kIvfWideBatches = 32;  // batches per super-batch at most: every resident list is read once per 1024 queries
 constexpr int kIvfWideQ = kIvfWideBatches * kMaxBatch;  // query slots per super-batch
-constexpr int kIvfTauRows = 256;                         // rows of the nearest list that seed a query's bound
+#ifndef VS_BOUND_SEGS
+#define VS_BOUND_SEGS 2
+#endif
+constexpr int kBoundSegs = VS_BOUND_SEGS;               // lists a query takes its bound from (list-major bounds; <= 4)
+#ifndef VS_TAU_ROWS
+#define VS_TAU_ROWS 256
+#endif
+constexpr int kIvfTauRows = VS_TAU_ROWS;                 // rows of a list that seed its queries' bounds (a multiple of 64)
 #ifndef VS_WIDE_UNIT
 #define VS_WIDE_UNIT 32
 #endif
@@ -330,7 +337,7 @@ struct IvfWideParams {
     // bounds, list-major: entries of the pick kernel (see IvfGroup), entry counter of list c at zero[c * kIvfWideCntStride + 1]
     const int32_t* tq;        // [nlist][tq_cap]
     int tq_cap;
-    float* tk;                // [n_batches][32][2][16] the k smallest distances per (query, segment), ascending
+    float* tk;                // [n_batches][32][kBoundSegs][16] the k smallest distances per (query, segment), ascending
     const int32_t* nseg;      // [n_batches][32]
     float* tau;               // [n_batches][32] bounds
     int32_t* slow;            // [n_batches][32] (pre-set to 0): no bound could be had -> exact slow path

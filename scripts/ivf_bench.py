@@ -7,6 +7,8 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as ge
 pkg = ge.load_package()
+if os.environ.get("VSEARCH_LIB"):  # (a variant build of the library, for A/B runs)
+    pkg.LIB_PATH = os.path.abspath(os.environ["VSEARCH_LIB"])
 precision = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 nprobe = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 K, B, NB = 5, 32, 256
