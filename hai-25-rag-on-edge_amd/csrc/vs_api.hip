@@ -646,7 +646,10 @@ int bf_launch(vs_index* h, vs_index::Lane& L, const float* q_dev, int nb, int B,
     // one zeroed block per launch: [0] overflow word | [16, 48) batches the int8 path has to skip | [64, ...) list counters
     int32_t* const overflow = L.wcnt;
     int32_t* const invalid = L.wcnt ? L.wcnt + 16 : nullptr;
-    if (L.wcnt) HIPCHK(hipMemsetAsync(L.wcnt, 0, (64 + (stream ? (size_t)nb * 32 * kWideSub : 0)) * sizeof(int32_t), s));
+    // (cleared by the seed's query-preparation launch where there is one and nobody else writes the batches' verdict words)
+    const size_t zero_words = 64 + (stream ? (size_t)nb * 32 * kWideSub : 0);
+    const bool zero_in_seed = seeded && (!use_u8 || i8_seed);
+    if (L.wcnt && !zero_in_seed) HIPCHK(hipMemsetAsync(L.wcnt, 0, zero_words * sizeof(int32_t), s));
     if (seeded) {
         vs::SeedParams sp{};
         sp.base = h->d_vecs;
@@ -669,6 +672,10 @@ int bf_launch(vs_index* h, vs_index::Lane& L, const float* q_dev, int nb, int B,
         sp.qnorm = L.seed_qnorm;
         sp.wmin = L.seed_wmin;
         sp.tau0 = L.tau0;
+        if (zero_in_seed) {
+            sp.zero = L.wcnt;
+            sp.zero_words = (int)zero_words;
+        }
         sp.qfrag = L.qfrag;
         if (i8_seed) {  // queries as bytes + constant terms + the "not byte valued" verdict: int8 seed and wide int8 scan
             sp.q8 = L.q8;

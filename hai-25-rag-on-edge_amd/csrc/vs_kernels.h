@@ -83,6 +83,8 @@ struct SeedParams {
     float* qnorm;            // scratch [n_batches][32]
     float* wmin;             // scratch [n_batches][64 groups][32]
     float* tau0;             // out [n_batches][32]
+    int32_t* zero;           // optional: zero_words words cleared by the query-preparation launch (except [16, 48) when `invalid` is set)
+    int zero_words;
     // optional outputs of the query-preparation launch for the wide int8 scan (launch_scan_i8_wide): the queries as
     // bytes (x - 128), qterm = ||q||^2 - 256 sum(q - 128) - 2 * 128^3 per query, invalid[batch] = 1 when a query of the
     // batch is not an integer in [0, 255] (pre-set to 0)

@@ -14,9 +14,50 @@ namespace vs {
 // of a query's 64 group minima.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void seed_qnorm_kernel(const SeedParams p) {
-    const int batch = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    // blockIdx.y = which of the batch's outputs: 0 norms (+ bytes, terms, verdict), 1 the fp32 fragments, 2 the byte fragments
+    // (one workgroup doing all three was three memory round trips in a row on every call's critical path)
+    const int batch = blockIdx.x, what = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
     const int row = tid >> 3, j = tid & 7;
     const float* qb = p.q + (int64_t)batch * p.q_batch_stride;
+    if (what == 3) {
+        // the launch's zeroed block (overflow word, list counters: see bf_launch) -- a memset launch of its own otherwise.
+        // The batches' "not byte valued" words [16, 48) belong to the workgroups of part 0, which write them as 0 or 1.
+        const int per = (p.zero_words + (int)gridDim.x - 1) / (int)gridDim.x;
+        for (int i = batch * per + tid; i < min(p.zero_words, (batch + 1) * per); i += 256)
+            if (!p.invalid || i < 16 || i >= 48) p.zero[i] = 0;
+        return;
+    }
+    if (what == 1) {
+        if (!p.qfrag) return;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {  // B-fragment order for the fp32 streaming scan (see SeedParams)
+            const int idx = tid + 256 * u;  // (h, c, lane)
+            const int fl = idx & 63, c = (idx >> 6) & 7, hh = idx >> 9;
+            const int qrow = 16 * hh + (fl & 15);
+            f32x4 v = *reinterpret_cast<const f32x4*>(qb + min(qrow, p.nq_valid - 1) * kDim + 16 * c + 4 * (fl >> 4));
+            if (qrow >= p.nq_valid) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(p.qfrag + ((int64_t)batch * 1024 + idx) * 4) = v;
+        }
+        return;
+    }
+    if (what == 2) {
+        if (!p.q8frag) return;
+        // the byte queries in B-fragment order (see SeedParams): thread = (h, half, lane), 16 bytes each
+        const int fl = tid & 63, half = (tid >> 6) & 1, hh = tid >> 7;
+        const int qrow = 16 * hh + (fl & 15);
+        int w[4] = {0, 0, 0, 0};
+        f32x4 x[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) x[v] = *reinterpret_cast<const f32x4*>(qb + min(qrow, p.nq_valid - 1) * kDim + 64 * half + 16 * (fl >> 4) + 4 * v);
+        if (qrow < p.nq_valid) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w[v] |= (((int)x[v][e] - 128) & 0xff) << (8 * e);
+        }
+        *reinterpret_cast<int4*>(p.q8frag + ((int64_t)batch * 256 + tid) * 16) = make_int4(w[0], w[1], w[2], w[3]);
+        return;
+    }
     float acc = 0.f;
     int part = 0;        // sum(q - 128) over this thread's 16 elements
     bool q_ok = true;    // ... all of them integers in [0, 255]
@@ -41,37 +82,15 @@ __global__ __launch_bounds__(256) void seed_qnorm_kernel(const SeedParams p) {
 #pragma unroll
     for (int u = 1; u < 8; ++u) sum = sum + __shfl(acc, b8 + u);
     if (j == 0) p.qnorm[batch * kMaxBatch + row] = sum;
-    if (p.qfrag) {  // B-fragment order for the fp32 streaming scan (see SeedParams)
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int idx = tid + 256 * u;  // (h, c, lane)
-            const int fl = idx & 63, c = (idx >> 6) & 7, hh = idx >> 9;
-            const int qrow = 16 * hh + (fl & 15);
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (qrow < p.nq_valid) v = *reinterpret_cast<const f32x4*>(qb + qrow * kDim + 16 * c + 4 * (fl >> 4));
-            *reinterpret_cast<f32x4*>(p.qfrag + ((int64_t)batch * 1024 + idx) * 4) = v;
-        }
-    }
     if (p.q8) {
         part += __shfl_xor(part, 1);
         part += __shfl_xor(part, 2);
         part += __shfl_xor(part, 4);
         if (j == 0) p.qterm[batch * kMaxBatch + row] = (int)sum - 256 * part - 4194304;
-        if (!q_ok) p.invalid[batch] = 1;  // same value from every thread that sees a bad element
     }
-    if (p.q8frag) {  // the byte queries in B-fragment order (see SeedParams): thread = (h, half, lane), 16 bytes each
-        const int fl = tid & 63, half = (tid >> 6) & 1, hh = tid >> 7;
-        const int qrow = 16 * hh + (fl & 15);
-        int w[4] = {0, 0, 0, 0};
-        if (qrow < p.nq_valid) {
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const f32x4 x = *reinterpret_cast<const f32x4*>(qb + qrow * kDim + 64 * half + 16 * (fl >> 4) + 4 * v);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) w[v] |= (((int)x[e] - 128) & 0xff) << (8 * e);
-            }
-        }
-        *reinterpret_cast<int4*>(p.q8frag + ((int64_t)batch * 256 + tid) * 16) = make_int4(w[0], w[1], w[2], w[3]);
+    if (p.invalid) {  // (workgroup-uniform) written as 0 or 1: nobody has to clear it before
+        const int bad = __syncthreads_or(q_ok ? 0 : 1);
+        if (tid == 0) p.invalid[batch] = bad ? 1 : 0;
     }
 }
 
@@ -197,6 +216,27 @@ __device__ __forceinline__ void seed_body_i8(const SeedParams& p, int batch, int
     }
 }
 
+// A batch's bounds from its 64 group minima per query: a wave per query (n_waves waves share the 32 queries), lane l holds
+// group minimum l, k1 rounds of a wave minimum.
+__device__ __forceinline__ void seed_tau_body(const SeedParams& p, const int batch, const int lane, const int wave, const int n_waves) {
+    const float* src = p.wmin + (int64_t)batch * kSeedChunks * kMaxBatch;
+    const int per = kMaxBatch / n_waves;
+    float v[8];  // (per <= 8)
+#pragma unroll
+    for (int qq = 0; qq < 8; ++qq) v[qq] = qq < per ? src[lane * kMaxBatch + per * wave + qq] : VS_INF;
+#pragma unroll
+    for (int qq = 0; qq < 8; ++qq) {
+        if (qq >= per) break;
+        float kth = VS_INF;
+        for (int round = 0; round < p.k1; ++round) {
+            kth = wave_min_f32(v[qq]);
+            const unsigned long long msk = __ballot(v[qq] == kth);
+            if (msk != 0ull && lane == __builtin_ctzll(msk)) v[qq] = VS_INF;  // drop exactly one instance
+        }
+        if (lane == 0) p.tau0[batch * kMaxBatch + per * wave + qq] = kth < VS_INF ? next_up(kth) : VS_INF;
+    }
+}
+
 // One workgroup per (batch, group of 32 sample tiles); its four waves take 8 tiles each (a quarter of the serial chain
 // of one wave per group) and fold their minima through LDS.  A batch whose queries are byte valued uses the exact int8
 // copy of the rows when there is one; any other batch (workgroup-uniform choice) the fp32 rows.
@@ -223,24 +263,12 @@ __global__ __launch_bounds__(256) void seed_kernel(const SeedParams p) {
         float* dst = p.wmin + ((int64_t)batch * kSeedChunks + chunk) * kMaxBatch;  // 128 contiguous bytes per group
         dst[threadIdx.x] = fminf(fminf(wm[0][threadIdx.x], wm[1][threadIdx.x]), fminf(wm[2][threadIdx.x], wm[3][threadIdx.x]));
     }
+    // (The bounds by the batch's last-arriving workgroup instead of seed_tau_kernel's launch was measured: agent-scope stores,
+    // the wait for them and 64 atomics per batch made this kernel take 28 instead of 14 us per 20 batches.)
 }
 
 __global__ __launch_bounds__(1024) void seed_tau_kernel(const SeedParams p) {
-    // one wave per query (two queries per wave): lane l holds group minimum l; k1 rounds of wave minimum
-    const int batch = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const float* src = p.wmin + (int64_t)batch * kSeedChunks * kMaxBatch;
-#pragma unroll
-    for (int qq = 0; qq < 2; ++qq) {
-        const int q = 2 * wave + qq;
-        float v = src[lane * kMaxBatch + q];
-        float kth = VS_INF;
-        for (int round = 0; round < p.k1; ++round) {
-            kth = wave_min_f32(v);
-            const unsigned long long msk = __ballot(v == kth);
-            if (msk != 0ull && lane == __builtin_ctzll(msk)) v = VS_INF;  // drop exactly one instance
-        }
-        if (lane == 0) p.tau0[batch * kMaxBatch + q] = kth < VS_INF ? next_up(kth) : VS_INF;
-    }
+    seed_tau_body(p, blockIdx.x, threadIdx.x & 63, threadIdx.x >> 6, 16);
 }
 
 // Gathers sample tile blockIdx.x of the shard into the compact, fragment-ordered arrays of SeedParams (index creation).
@@ -279,7 +307,7 @@ hipError_t launch_seed_sample(const float* base, const float* bnorm, const int8_
 }
 
 hipError_t launch_seed(const SeedParams& p, hipStream_t s) {
-    hipLaunchKernelGGL(seed_qnorm_kernel, dim3(p.n_batches), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(seed_qnorm_kernel, dim3(p.n_batches, p.zero ? 4 : 3), dim3(256), 0, s, p);
     const int wgs = p.n_batches * kSeedChunks;  // one workgroup per (batch, group of sample tiles)
     hipLaunchKernelGGL(seed_kernel, dim3(wgs), dim3(256), 0, s, p);
     hipLaunchKernelGGL(seed_tau_kernel, dim3(p.n_batches), dim3(1024), 0, s, p);
