@@ -1725,72 +1725,79 @@ __global__ __launch_bounds__(256) void ivf_wide_rank4_kernel(const MergeParams m
     const int qg = (q / p.B) * kMaxBatch + q % p.B;
     const int nsub = p.sink.nsub, cap = p.sink.cap;
     bool generic = p.sink.overflow[0] != 0 || p.slow[qg] != 0;
-    // the sub-lists' lengths (lanes 0 .. nsub - 1), their running sum, the candidates in all
+    // The sub-lists' lengths (lanes 0 .. nsub - 1).  Four lanes walk a sub-list (lane = sub-list + 16 t takes its entries t,
+    // t + 4, ...): no table of where entry e of the concatenation lives, every lane's addresses are its sub-list's own.
     int len = 0;
     if (lane < nsub) len = min(p.sink.cnt[(int64_t)lane * p.sink.cnt_sub_stride + qg], cap + 1);
     generic = generic || __any(len > cap);  // (a sub-list that overflowed marks the query `slow` as well)
-    int incl = len;
+    int T = len, longest = len;
 #pragma unroll
     for (int o = 1; o < 16; o <<= 1) {
-        const int t = __shfl_up(incl, o);
-        if (lane >= o) incl += t;
+        T += __shfl_xor(T, o);
+        longest = max(longest, __shfl_xor(longest, o));
     }
-    const int T = __builtin_amdgcn_readlane(incl, 15);
-    generic = generic || T > 256;
+    T = __builtin_amdgcn_readfirstlane(T);              // candidates in all
+    longest = __builtin_amdgcn_readfirstlane(longest);  // the longest sub-list
     if (!generic) {
-        float d[4];
-        int id[4];
+        constexpr int V = 8;  // candidates per lane and step
+        float d[V];
+        int id[V];
+        const int my_len = __shfl(len, lane & 15), my_t = lane >> 4;
+        const int64_t my_src = ((int64_t)qg * nsub + (lane & 15)) * cap;
+        auto load_step = [&](const int first) {  // entries first + t + 4 u (u < V) of the lane's sub-list
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int e = lane + 64 * u;
-            d[u] = VS_INF;
-            id[u] = 0x7fffffff;
-            if (64 * u < T) {  // wave-uniform
-                int sub = 0, start = 0;
-#pragma unroll
-                for (int s2 = 0; s2 < 16; ++s2) {
-                    const int end = __builtin_amdgcn_readlane(incl, s2);
-                    if (s2 < nsub && end <= e) {
-                        sub = s2 + 1;
-                        start = end;
-                    }
-                }
-                if (e < T) {
-                    const int64_t src = ((int64_t)qg * nsub + sub) * cap + (e - start);
-                    d[u] = m.part_d[src];
-                    id[u] = m.part_i[src];
+            for (int u = 0; u < V; ++u) {
+                const int e = first + my_t + 4 * u;
+                d[u] = VS_INF;
+                id[u] = 0x7fffffff;
+                if (first + 4 * u < longest && e < my_len) {  // (the first condition is wave-uniform)
+                    d[u] = m.part_d[my_src + e];
+                    id[u] = m.part_i[my_src + e];
                 }
             }
-        }
-        float sd = d[0];
-        int si = id[0];
-        int M = T;
-        if (T > 64) {
-            // bound: the k-th smallest of the 64 lane minima (k distinct candidates are at least that close)
-            float md = d[0];
-            int mi = id[0];
+        };
+        load_step(0);
+        float sd = VS_INF;
+        int si = 0x7fffffff;
+        int M = 0;
+        {
+            // bound: the k-th smallest of the 64 lane minima of the first step (k distinct candidates are at least that
+            // close); with 64 candidates or fewer there is nothing to filter
+            float bound = VS_INF;
+            if (T > 64) {
+                float md = d[0];
+                int mi = id[0];
 #pragma unroll
-            for (int u = 1; u < 4; ++u)
-                if (lex_lt(d[u], id[u], md, mi)) {
-                    md = d[u];
-                    mi = id[u];
-                }
-            const int mrank = wave_rank_count(md, mi, 64);
-            const unsigned long long who = __ballot(mrank == min(m.kout, 64) - 1);
-            const float bound = rdlane_f(md, (int)__builtin_ctzll(who | (1ull << 63)));
+                for (int u = 1; u < V; ++u)
+                    if (lex_lt(d[u], id[u], md, mi)) {
+                        md = d[u];
+                        mi = id[u];
+                    }
+                const int mrank = wave_rank_count(md, mi, 64);
+                const unsigned long long who = __ballot(mrank == min(m.kout, 64) - 1);
+                bound = rdlane_f(md, (int)__builtin_ctzll(who | (1ull << 63)));
+            }
             float* wd = wcd + wave * 256;
             int* wi = wci + wave * 256;
-            M = 0;
+            // (a query with hundreds of candidates -- a loose bound: one in fifty -- takes its bound from the first step and
+            // filters the rest step by step; it used to wait for the list kernel behind this one, 17 us for a handful)
+            for (int first = 0; first < longest; first += 4 * V) {
+                if (first) load_step(first);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const bool pass = id[u] != 0x7fffffff && d[u] <= bound;
-                const unsigned long long mask = __ballot(pass);
-                if (pass) {
-                    const int pos = M + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
-                    wd[pos] = d[u];
-                    wi[pos] = id[u];
+                for (int u = 0; u < V; ++u) {
+                    if (first + 4 * u >= longest) break;  // wave-uniform
+                    const bool pass = id[u] != 0x7fffffff && d[u] <= bound;
+                    const unsigned long long mask = __ballot(pass);
+                    if (pass) {
+                        const int pos = M + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+                        if (pos < 256) {
+                            wd[pos] = d[u];
+                            wi[pos] = id[u];
+                        }
+                    }
+                    M += __popcll(mask);
                 }
-                M += __popcll(mask);
+                if (M > 64) break;  // (masses of equal distances at the bound: the list kernel's)
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -1859,7 +1866,8 @@ hipError_t launch_ivf_wide_rank(const MergeParams& m, int64_t stride_g, int64_t 
     // a wave per query where a launch ranks thousands of queries (several super-batches); a workgroup per query otherwise
     if (glist && m.nq > 2048 && m.G <= 16 && m.flat_len && m.flat_len_sub_stride && !m.flags && !m.tau_out && !m.invalid && !m.run_if) {
         hipLaunchKernelGGL(ivf_wide_rank4_kernel, dim3((m.nq + 3) / 4), dim3(256), 0, s, m, p, glist);
-        hipLaunchKernelGGL(ivf_wide_rank_list_kernel, dim3(256), dim3(256), 0, s, m, L, p, glist);
+        static const int list_wgs = getenv("VSEARCH_RANK_LIST_WGS") ? atoi(getenv("VSEARCH_RANK_LIST_WGS")) : 256;  // (tuning knob)
+        hipLaunchKernelGGL(ivf_wide_rank_list_kernel, dim3(list_wgs), dim3(256), 0, s, m, L, p, glist);
     }
     else hipLaunchKernelGGL(ivf_wide_rank_kernel, dim3(m.nq), dim3(256), 0, s, m, L, p);
     return hipGetLastError();
