@@ -625,6 +625,37 @@ def test_wide_slow_path_duplicates_and_tiny_lists(gpu_pkg):
     assert all(len(set(r[r >= 0])) == (r >= 0).sum() for r in gi)   # no row twice
 
 
+@pytest.mark.parametrize("nprobe", [4, 32])
+def test_probe_selection_with_masses_of_equal_scores(gpu_pkg, nprobe):
+    """400 of the 512 centroids are copies of one point: every query near it sees 400 equal coarse scores, far more
+    than nprobe.  The reference's order among equal scores is ascending list id (deterministic restatement of
+    std::nth_element, IVFIndex.cpp:711); the selection's bound-then-rank must give exactly that, and the bound tables
+    must cope with probed lists that are nearly all empty.  Results must equal the oracle's query by query."""
+    import torch
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(77)
+    base = gpu_pkg.synth_sift(20000, seed=91)
+    cents = base[rng.choice(20000, 512, replace=False)].copy()
+    cents[100:500] = cents[100]                       # 400 identical centroids (lists 101 .. 499 end up empty)
+    d = (base ** 2).sum(1)[:, None] - 2 * base @ cents.T + (cents ** 2).sum(1)[None]
+    vr, off, r2o = gpu_pkg.ivf_layout_from_assignment(base, d.argmin(1), len(cents))
+    nb, k = 33, 5
+    q = gpu_pkg.synth_sift(32 * nb, seed=92)
+    q[:600] = np.clip(cents[100] + rng.integers(-3, 4, (600, 128)), 0, 255)   # the copies are these queries' nearest lists
+    qd = torch.from_numpy(q).to(dev)
+    s = torch.cuda.current_stream().cuda_stream
+    oi, od, _ = oracle.ivf_search(vr, off, r2o, cents, q, k, nprobe)
+    with gpu_pkg.IVFIndex(vectors_reordered=vr, centroids=cents, cluster_offsets=off, reorder_to_original=r2o) as ivf:
+        got_i = torch.full((nb * 32, k), -7, dtype=torch.int32, device=dev)
+        got_d = torch.zeros((nb * 32, k), dtype=torch.float32, device=dev)
+        ivf.search_dev_multi(qd.data_ptr(), nb, 32, k, nprobe, got_i.data_ptr(), got_d.data_ptr(), s)
+        torch.cuda.synchronize()
+    gd = got_d.cpu().numpy()
+    same = np.array([np.array_equal(gd[i], od[i]) for i in range(len(q))])
+    assert same[:600].all(), np.nonzero(~same[:600])[0][:10]   # (all-equal scores: no last-bit coarse ties to excuse)
+    assert same.mean() >= 0.97
+
+
 @pytest.mark.parametrize("world,nb,B", [(2, 5, 32), (2, 150, 32), (4, 37, 32), (8, 70, 20), (8, 3, 32), (8, 256, 32)])
 def test_sliced_pipeline_virtual_ranks_equal_unsharded(gpu_pkg, world, nb, B):
     """The cluster-sharded pipeline (BASELINE configs[4]) on virtual ranks: `world` shards of one index on one GPU go
