@@ -606,9 +606,16 @@ def main():
                     if os.path.exists(ipath) and n_rows == N_BASE and nprobe == NPROBE and set(window) == {SI}:
                         itraffic = json.load(open(ipath)).get(tkey)   # (PMC figure of a launch of SI batches, profiles/README.md)
                     frac = round(ach / HBM_PEAK_GBS, 4) if ach else None
-                    assert frac is None or frac <= 1.0, ("the byte model does not describe the kernel", frac)
+                    above_hbm = None
+                    if frac is not None and frac > 1.0:
+                        # Only possible where the rows stay in the Infinity Cache between launches (the 132 MB byte copy):
+                        # the algorithmic bytes then arrive faster than HBM could deliver them and a fraction of the HBM
+                        # peak says nothing -- reported as null with the ratio beside it.  On the fp32 rows (466 MB per
+                        # super-batch) the HBM roof binds and a value above 1 would mean the byte model is wrong.
+                        assert rb < 512, ("the byte model does not describe the kernel", frac)
+                        above_hbm, frac = frac, None
                     info["roofline"] = {"bound": "hbm", "achieved": round(ach, 1) if ach else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                        "frac": frac, "traffic": itraffic,
+                                        "frac": frac, "algorithmic_rate_over_hbm_peak_cache_resident": above_hbm, "traffic": itraffic,
                                         "traffic_source": "static: profiles/traffic_ivf_list_scan.json (rocprofv3 --pmc passes, not measured in this run)",
                                         "kernel": "vs::ivf_scan_wide_kernel", "kernel_us": round(ks_launch * 1e6, 2),
                                         "launches": int(okern_n), "batches_per_launch": round(sum(window) / max(len(window), 1), 2),

@@ -156,7 +156,6 @@ struct vs_index {
     int ivf_gb = 32;                   // batches per launch group (multiple of 32) the wide pipeline's scratch is sized for
     int ivf_nsb = 1;                   // ... in at most this many super-batches (sharded: one per rank)
     int ivf_lanes = 2;                 // streams the launch groups of one device call are dealt to
-    bool ivf_bounds_query = false;     // VSEARCH_IVF_BOUNDS=query: bounds by one wave per query (ivf_tau_body) instead of list-major
     int64_t ivf_host_cap = 0;          // queries per chunk the host-buffer call's staging slots hold
     // sharded index: the first kIvfTauRows rows of EVERY list (resident or not), replicated on every rank: a query's bound
     // then comes from its two nearest lists wherever they live -- the bounds of the unsharded index (a bound from the
@@ -906,11 +905,9 @@ int ensure_ivf_wide(vs_index* h, int lane) {
     W.units_cap = (int)std::min<int64_t>(2 * h->n_units_max + 4096, 0x7fffffff / 16);
     if ((rc = dev_alloc(&W.units, (size_t)n_sb_max * W.units_cap * 4))) return rc;
     if ((rc = dev_alloc(&W.tau, nq))) return rc;
-    if (!h->ivf_bounds_query && nq <= 0x10000) {
-        if ((rc = dev_alloc(&W.tq, (size_t)h->nlist * nq))) return rc;
-        if ((rc = dev_alloc(&W.tk, nq * vs::kBoundSegs * 16))) return rc;
-        if ((rc = dev_alloc(&W.nseg, nq))) return rc;
-    }
+    if ((rc = dev_alloc(&W.tq, (size_t)h->nlist * nq))) return rc;
+    if ((rc = dev_alloc(&W.tk, nq * vs::kBoundSegs * 16))) return rc;
+    if ((rc = dev_alloc(&W.nseg, nq))) return rc;
     if ((rc = dev_alloc(&W.qnorm, nq))) return rc;
     if ((rc = dev_alloc(&W.q8, nq * vs::kDim))) return rc;
     if ((rc = dev_alloc(&W.qterm, nq))) return rc;
@@ -2040,10 +2037,6 @@ static int ivf_create_impl(const float* vectors, int64_t n_rows, int dim, const 
     // slice of up to 32 batches per rank (ivf_shard_front / ivf_shard_back)
     h->ivf_gb = world > 1 ? std::min(kIvfGroupMax, 32 * std::min(world, kIvfShardMaxWorld)) : ivf_group_batches();
     h->ivf_lanes = ivf_wide_lanes();
-    {
-        const char* e = getenv("VSEARCH_IVF_BOUNDS");
-        h->ivf_bounds_query = e && !strcmp(e, "query");
-    }
     h->ivf_nsb = world > 1 ? std::max(h->ivf_gb / 32, std::min(world, kIvfShardMaxWorld)) : h->ivf_gb / 32;
     if (h->nlist <= vs::kIvfFastNlist && h->n_chunks > 0) {
         // the wide pipeline's scratch (two lanes), streams and host staging now rather than inside the first search:

@@ -619,223 +619,12 @@ hipError_t launch_ivf_fill(const int32_t* gathered, long long blk_words, int B, 
 // ------------------------------------------------------------------------------------------------
 // Wide IVF pipeline (see IvfWideParams).
 // ------------------------------------------------------------------------------------------------
-// Bound of a query = k-th smallest distance among the first kIvfTauRows rows of each of its two nearest resident lists
+// Bound of a query = k-th smallest distance among the first kIvfTauRows rows of each of its two nearest lists that hold rows
 // (those rows are candidates, so k of them at most that far bound the k-th best of all candidates; two lists because the
-// query's own neighbourhood is not always in the nearest one).  One wave per query: 16-row MFMA tiles with the query in
-// column 0 of the B operand, distances through LDS, k rounds of a wave minimum.  Fewer than k rows: tau = +inf and the
-// query is marked for the exact slow path.
-__device__ __forceinline__ void ivf_tau_body(const IvfWideParams& p, const int wg) {
-    typedef int i32x4 __attribute__((ext_vector_type(4)));
-    typedef int i32x4_u __attribute__((ext_vector_type(4), aligned(4)));
-    typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
-    constexpr int NSEG = 2;                      // lists sampled per query
-    constexpr int SEGR = kIvfTauRows;            // rows per list
-    constexpr int NR = NSEG * SEGR;              // distance slots per query
-    // a workgroup = 2 queries x NSEG waves: wave (slot, sgm) scores segment sgm of its query, the segment-0 wave selects
-    __shared__ __attribute__((aligned(16))) float dist[2][NR];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#ifdef VS_STAMPS
-#define TAU_STAMP(i) do { if (p.dbg && threadIdx.x == 0) p.dbg[(7168 + wg) * 16 + (i)] = (int)(__builtin_amdgcn_s_memrealtime() & 0x7fffffff); } while (0)
-#else
-#define TAU_STAMP(i)
-#endif
-    TAU_STAMP(0);
-    const int slot = wave >> 1, myseg = wave & 1;
-    const int qg = wg * 2 + slot;
-    const int batch = qg >> 5, qi = qg & 31;
-    const bool valid = batch < p.n_batches && qi < p.B;  // wave-uniform
-    const int r = lane & 15, g = lane >> 4;
-    int seg_start[NSEG], seg_rows[NSEG], seg_td[NSEG];
-    int nseg = 0, total_rows = 0;
-#pragma unroll
-    for (int sgm = 0; sgm < NSEG; ++sgm) seg_start[sgm] = seg_rows[sgm] = seg_td[sgm] = 0;
-    if (valid) {
-        const int32_t* pr = reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(p.probes) + (long long)batch * p.probes_batch_bytes) + qi * p.nprobe;
-        // the first NSEG probed lists that are resident here: their first SEGR rows each (k rows in all are needed).  The
-        // first LOOK probes and their lists' extents are fetched together (one after the other: a chain of cache round trips)
-        constexpr int LOOK = 4;
-        int cs[LOOK], o0[LOOK], o1[LOOK], td[LOOK];
-#pragma unroll
-        for (int i = 0; i < LOOK; ++i) cs[i] = i < p.nprobe ? pr[i] : -1;
-#pragma unroll
-        for (int i = 0; i < LOOK; ++i) {
-            const int c = max(cs[i], 0);
-            o0[i] = p.offsets[c];
-            o1[i] = p.offsets[c + 1];
-            td[i] = p.tdelta ? p.tdelta[c] : 0;
-        }
-        auto take_list = [&](int start, int len, int delta) {
-            const int take = min(len, SEGR);
-#pragma unroll
-            for (int sgm = 0; sgm < NSEG; ++sgm)
-                if (sgm == nseg) {
-                    seg_start[sgm] = start;
-                    seg_rows[sgm] = take;
-                    seg_td[sgm] = delta;
-                }
-            ++nseg;
-            total_rows += take;
-        };
-#pragma unroll
-        for (int i = 0; i < LOOK; ++i)
-            if (cs[i] >= 0 && o1[i] > o0[i] && nseg < NSEG) take_list(o0[i], o1[i] - o0[i], td[i]);
-        for (int pp = LOOK; pp < p.nprobe && nseg < NSEG; ++pp) {  // (rare: lists without rows here among the nearest)
-            const int c = pr[pp];
-            if (c < 0) continue;
-            const int len = p.offsets[c + 1] - p.offsets[c];
-            if (len > 0) take_list(p.offsets[c], len, p.tdelta ? p.tdelta[c] : 0);
-        }
-    }
-    const bool usable = valid && total_rows >= p.k;
-    TAU_STAMP(1);
-    for (int i = lane; i < SEGR; i += 64) dist[slot][myseg * SEGR + i] = VS_INF;
-    if (usable) {
-    const bool i8 = p.vecs_u8 && p.metric == 0 && p.invalid[batch] == 0;
-    i32x4 b0 = {0, 0, 0, 0}, b1 = {0, 0, 0, 0};
-    f32x4 qf[8];
-    int qt = 0;
-    float qn = 0.f;
-    if (i8) {
-        if (r == 0) {
-            b0 = *reinterpret_cast<const i32x4*>(p.q8 + (int64_t)qg * kDim + 16 * g);
-            b1 = *reinterpret_cast<const i32x4*>(p.q8 + (int64_t)qg * kDim + 64 + 16 * g);
-        }
-        qt = p.qterm[qg];
-    } else {
-        const float* qsrc = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.q) + (long long)batch * p.q_batch_bytes) + qi * kDim;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            qf[c] = *reinterpret_cast<const f32x4*>(qsrc + 16 * c + 4 * g);
-            if (r != 0) qf[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-        qn = p.qnorm[qg];
-    }
-    {
-        const int start = myseg ? seg_start[1] : seg_start[0], rows = myseg ? seg_rows[1] : seg_rows[0];
-        const int tiles = (rows + 15) >> 4;
-        float* dseg = &dist[slot][myseg * SEGR];
-        if (i8 && p.vecs_t8) {
-            // the tiled copy (see IvfWideParams): a list starts on a tile boundary there and a load is 1 KB in one piece
-            const int tstart = start + (myseg ? seg_td[1] : seg_td[0]);
-            const int8_t* rows_t = p.vecs_t8 + (int64_t)tstart * kDim + 16 * lane;
-            constexpr int U = 8;  // tiles whose loads go out together
-            for (int t0 = 0; t0 < tiles; t0 += U) {
-                i32x4 a0[U], a1[U], rt[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int t = min(t0 + u, tiles - 1);
-                    a0[u] = *reinterpret_cast<const i32x4*>(rows_t + (int64_t)t * 16 * kDim);
-                    a1[u] = *reinterpret_cast<const i32x4*>(rows_t + (int64_t)t * 16 * kDim + 1024);
-                    rt[u] = *reinterpret_cast<const i32x4*>(p.rterm_t + tstart + 16 * t + 4 * g);
-                }
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int t = t0 + u;
-                    if (t >= tiles) break;
-                    i32x4 acc = {0, 0, 0, 0};
-                    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0[u], b0, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1[u], b1, acc, 0, 0, 0);
-                    if (r == 0) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (16 * t + 4 * g + j < rows) dseg[16 * t + 4 * g + j] = (float)(qt + rt[u][j] - 2 * acc[j]);
-                    }
-                }
-            }
-        } else if (i8) {
-            constexpr int U = 4;  // tiles whose loads go out together
-            for (int t0 = 0; t0 < tiles; t0 += U) {
-                i32x4 a0[U], a1[U], rt[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int t = min(t0 + u, tiles - 1);
-                    const int row = min(start + 16 * t + r, start + rows - 1);
-                    a0[u] = *reinterpret_cast<const i32x4*>(p.vecs_u8 + (int64_t)row * kDim + 16 * g);
-                    a1[u] = *reinterpret_cast<const i32x4*>(p.vecs_u8 + (int64_t)row * kDim + 64 + 16 * g);
-                    rt[u] = *reinterpret_cast<const i32x4_u*>(p.rterm + start + 16 * t + 4 * g);  // padded by 64
-                }
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int t = t0 + u;
-                    if (t >= tiles) break;
-                    i32x4 acc = {0, 0, 0, 0};
-                    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0[u], b0, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1[u], b1, acc, 0, 0, 0);
-                    if (r == 0) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (16 * t + 4 * g + j < rows) dseg[16 * t + 4 * g + j] = (float)(qt + rt[u][j] - 2 * acc[j]);
-                    }
-                }
-            }
-        } else {
-            for (int t = 0; t < tiles; ++t) {
-                const int row = min(start + 16 * t + r, start + rows - 1);
-                f32x4 a[8];
-#pragma unroll
-                for (int c = 0; c < 8; ++c) a[c] = *reinterpret_cast<const f32x4*>(p.vecs + (int64_t)row * kDim + 16 * c + 4 * g);
-                const f32x4 bn = *reinterpret_cast<const f32x4_u*>(p.vnorm + start + 16 * t + 4 * g);  // padded by 64
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int c = 0; c < 8; ++c)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][i], qf[c][i], acc, 0, 0, 0);
-                if (r == 0) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (16 * t + 4 * g + j < rows) dseg[16 * t + 4 * g + j] = p.metric ? -acc[j] : fmaf(-2.0f, acc[j], qn + bn[j]);
-                }
-            }
-        }
-    }
-    }
-    __syncthreads();
-    TAU_STAMP(2);
-    if (!valid || myseg != 0) return;
-    if (!usable) {
-        if (lane == 0) {
-            p.tau[qg] = VS_INF;
-            p.slow[qg] = 1;
-        }
-        return;
-    }
-    const bool i8 = p.vecs_u8 && p.metric == 0 && p.invalid[batch] == 0;
-    // k-th smallest of the NR slots: k rounds of a wave minimum over the lanes' private values
-    float v[NR / 64];
-#pragma unroll
-    for (int i = 0; i < NR / 64; ++i) v[i] = dist[slot][i * 64 + lane];
-    float kth = VS_INF;
-    for (int round = 0; round < p.k; ++round) {
-        float m = v[0];
-#pragma unroll
-        for (int i = 1; i < NR / 64; ++i) m = fminf(m, v[i]);
-        const float wm = wave_min_f32(m);
-        kth = wm;
-        if (!(wm < VS_INF)) break;
-        const unsigned long long mask = __ballot(m == wm);
-        if (lane == __builtin_ctzll(mask)) {  // drop exactly one instance
-            bool done = false;
-#pragma unroll
-            for (int i = 0; i < NR / 64; ++i)
-                if (!done && v[i] == wm) {
-                    v[i] = VS_INF;
-                    done = true;
-                }
-        }
-    }
-    TAU_STAMP(3);
-    if (lane == 0) {
-        // integer distances (int8 path) are exact: the bound may sit right above the k-th value; fp32 rows are scored
-        // with the same MFMA chain as the scan here, but leave slack anyway (the bound only filters)
-        const float t = i8 ? next_up(kth) : kth + 1e-4f * fabsf(kth) + 1e-30f;
-        p.tau[qg] = kth < VS_INF ? t : VS_INF;
-        if (!(kth < VS_INF)) p.slow[qg] = 1;
-    }
-}
-
-// The same bound, list-major (what runs when the pick kernel filled the bound tables, IvfWideParams::tq).  One query per
-// wave uses one of the MFMA's 16 columns and reads 64 KB of rows; a list's first rows are the same for every query that
-// probes it.  So: the pick kernel enters each query in the tables of its two lists, and here a workgroup takes 16 ENTRIES
+// query's own neighbourhood is not always in the nearest one).  Fewer than k rows: tau = +inf and the query is marked for the
+// exact slow path.  List-major: with one query per wave (rounds 2 and 3a) a query used one of the MFMA's 16 columns and read
+// 64 KB of rows -- 537 MB out of the caches per 8192 queries, 69 us -- while a list's first rows are the same for every
+// query that probes it.  So: the pick kernel enters each query in the tables of its two lists, and here a workgroup takes 16 ENTRIES
 // of one list as the 16 columns ("unit").  The workgroup copies the list's first 256 rows (32 KB of the tiled byte copy)
 // to LDS in ONE round trip, with the unit's entries and their query bytes requested beside it; wave w scores tiles w, w + 4,
 // ... (two int8 MFMAs per tile score all 16 columns), keeps the k smallest of its 64 rows per column (k rounds of a
@@ -1021,7 +810,7 @@ __device__ __forceinline__ void ivf_bounds_list_body(const IvfWideParams& p, con
 }
 
 // A query's bound from its segments' k smallest distances (ivf_bounds_list_body): the k-th smallest of their union, with
-// the slack ivf_tau_body gives it.  One thread per query; the launch also leaves the bound tables' counters zeroed.
+// a slack on fp32 rows (integer distances are exact: the bound sits right above the k-th value).  One thread per query; the launch also leaves the bound tables' counters zeroed.
 __global__ __launch_bounds__(256) void ivf_tau_combine_kernel(const IvfWideParams p) {
     const int qg = blockIdx.x * 256 + threadIdx.x;
     for (int c = qg; c < p.nlist; c += (int)gridDim.x * 256) p.zero[(int64_t)c * kIvfWideCntStride + 1] = 0;
@@ -1230,16 +1019,9 @@ __device__ __forceinline__ void ivf_plan_body(const IvfWideParams& p, const int 
     if (tid == 0 && slice == nsl - 1) p.zero[sb * ivf_wide_plan_words(p.nlist) + (int64_t)p.nlist * kIvfWideCntStride] = s_carry;
 }
 
-// Bounds and plan in ONE launch (both need the pick kernel's output only and take about 10 us each: side by side instead
-// of one after the other).  The first n_plan * n_sb workgroups plan, the rest compute bounds, two queries each.
-__global__ __launch_bounds__(256) void ivf_tau_plan_kernel(const IvfWideParams p, const int n_plan, const int n_sb) {
-    __shared__ __attribute__((aligned(16))) char lds[kPlanLds];
-    const int wg = blockIdx.x;
-    if (wg < n_plan * n_sb) ivf_plan_body(p, wg / n_plan, wg % n_plan, n_plan, lds);
-    else ivf_tau_body(p, wg - n_plan * n_sb);
-}
-// ... with list-major bounds.  Four workgroups per CU: the bounds' workgroups are one short chain of cache misses each,
-// all of a launch group's lists should be in flight together.
+// Bounds and plan in ONE launch (both need the pick kernel's output only: side by side instead of one after the other).  The
+// first n_plan * n_sb workgroups plan, the rest take (list, part) pairs of the bounds.  Four workgroups per CU: the bounds'
+// workgroups are one short chain of cache misses each, all of a launch group's lists should be in flight together.
 __global__ __launch_bounds__(256, 4) void ivf_bounds_plan_kernel(const IvfWideParams p, const int n_plan, const int n_sb, const bool pad_here) {
     __shared__ __attribute__((aligned(16))) char lds[kBoundLds > kPlanLds ? kBoundLds : kPlanLds];
     const int wg = blockIdx.x;
@@ -1657,18 +1439,12 @@ hipError_t launch_ivf_wide_bounds_plan(const IvfWideParams& p, hipStream_t s, in
     const int n_sb = (p.n_batches + p.sb_batches - 1) / p.sb_batches;
     static const int plan_wgs = getenv("VSEARCH_PLAN_WGS") ? atoi(getenv("VSEARCH_PLAN_WGS")) : 16;  // (tuning knob)
     const int n_plan = (what & 2) ? std::max(plan_wgs, 16 / n_sb) : 0;  // (every planning workgroup reads all pair counters, a cache line each)
-    const int n_tau = !(what & 1) ? 0 : p.tq ? p.nlist * kBoundParts : (p.n_batches * kMaxBatch + 1) / 2;
+    const int n_tau = (what & 1) ? p.nlist * kBoundParts : 0;
     if (n_plan * n_sb + n_tau == 0) return hipSuccess;
-    if ((what & 1) && p.tq && (p.n_batches * kMaxBatch > 0x10000 || p.n_batches * kMaxBatch > p.tq_cap)) return hipErrorInvalidValue;
-    static const bool split = getenv("VSEARCH_SPLIT_BP") != nullptr;  // (diagnostic: the two halves as launches of their own)
+    if ((what & 1) && (!p.tq || p.n_batches * kMaxBatch > 0x10000 || p.n_batches * kMaxBatch > p.tq_cap)) return hipErrorInvalidValue;
     // (who pads the slot tables: the bounds' workgroups if the tables are complete when they run, i.e. with the plan beside them)
-    if (!p.tq || !(what & 1)) hipLaunchKernelGGL(ivf_tau_plan_kernel, dim3(n_plan * n_sb + n_tau), dim3(256), 0, s, p, n_plan, n_sb);
-    else if (split && n_plan) {
-        hipLaunchKernelGGL(ivf_bounds_plan_kernel, dim3(n_tau), dim3(256), 0, s, p, 0, n_sb, n_sb > 16);
-        hipLaunchKernelGGL(ivf_bounds_plan_kernel, dim3(n_plan * n_sb), dim3(256), 0, s, p, n_plan, n_sb, n_sb > 16);
-    } else
-        hipLaunchKernelGGL(ivf_bounds_plan_kernel, dim3(n_plan * n_sb + n_tau), dim3(256), 0, s, p, n_plan, n_sb, n_plan == 0 || n_sb > 16);
-    if ((what & 1) && p.tq) hipLaunchKernelGGL(ivf_tau_combine_kernel, dim3((p.n_batches * kMaxBatch + 255) / 256), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(ivf_bounds_plan_kernel, dim3(n_plan * n_sb + n_tau), dim3(256), 0, s, p, n_plan, n_sb, n_tau == 0 || n_plan == 0 || n_sb > 16);
+    if (what & 1) hipLaunchKernelGGL(ivf_tau_combine_kernel, dim3((p.n_batches * kMaxBatch + 255) / 256), dim3(256), 0, s, p);
     return hipGetLastError();
 }
 
@@ -1875,8 +1651,7 @@ hipError_t launch_ivf_wide_rank(const MergeParams& m, int64_t stride_g, int64_t 
     // a wave per query where a launch ranks thousands of queries (several super-batches); a workgroup per query otherwise
     if (glist && m.nq > 2048 && m.G <= 16 && m.flat_len && m.flat_len_sub_stride && !m.flags && !m.tau_out && !m.invalid && !m.run_if) {
         hipLaunchKernelGGL(ivf_wide_rank4_kernel, dim3((m.nq + 3) / 4), dim3(256), 0, s, m, p, glist);
-        static const int list_wgs = getenv("VSEARCH_RANK_LIST_WGS") ? atoi(getenv("VSEARCH_RANK_LIST_WGS")) : 256;  // (tuning knob)
-        hipLaunchKernelGGL(ivf_wide_rank_list_kernel, dim3(list_wgs), dim3(256), 0, s, m, L, p, glist);
+        hipLaunchKernelGGL(ivf_wide_rank_list_kernel, dim3(256), dim3(256), 0, s, m, L, p, glist);
     }
     else hipLaunchKernelGGL(ivf_wide_rank_kernel, dim3(m.nq), dim3(256), 0, s, m, L, p);
     return hipGetLastError();

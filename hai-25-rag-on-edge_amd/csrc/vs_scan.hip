@@ -10,11 +10,10 @@
 //   seed_*_kernel        : bounds for a multi-batch scan from 2048 sample tiles, queries in MFMA fragment order (launch_seed).
 //   merge_compact_kernel : ranking of candidate lists, cross-workgroup / cross-GPU merge (merge_kernel: general fallback).
 //   row_sqnorm_kernel    : compute_norms (cpu_baseline.cpp:95-125) in the reference's summation order.
-//   ivf_coarse_mfma_kernel, ivf_pick_kernel, ivf_tau_plan_kernel, ivf_scan_wide_kernel, ivf_wide_rank_kernel :
+//   ivf_coarse_mfma_kernel, ivf_pick_kernel, ivf_bounds_plan_kernel, ivf_tau_combine_kernel, ivf_scan_wide_kernel, ivf_wide_rank4_kernel :
 //                          IVFIndex::searchBatch (IVFIndex.cpp:640-859) as a list-major pipeline over launch groups of up
-//                          to 32 batches (one pass over the probed lists per group);
-//                          ivf_group_plan_kernel / ivf_unit_scan_kernel / ivf_select_kernel (one pass per batch),
-//                          ivf_list_scan_kernel / pick_probes_kernel / ivf_scan_kernel: earlier and fallback paths.
+//                          to 256 batches (one pass over the probed lists per super-batch of 32 batches);
+//                          pick_probes_kernel / ivf_scan_kernel: the per-batch fallback (nlist > 4096, k > 15).
 //   kpp_*_kernel, kmeans_*_kernel : index builder (create_ivf_model_reordered.py:88-118).
 //
 // (The UFIXED_POINT_8 score path of the reference's device runner -- quantiser, uint8 score matrix, top-k over it --
