@@ -633,7 +633,10 @@ hipError_t launch_ivf_fill(const int32_t* gathered, long long blk_words, int B, 
 // A workgroup's life is a chain of three cache misses and about a microsecond per unit: all of a launch group's lists are
 // meant to be in flight together (see ivf_bounds_plan_kernel).  (list, part): the units of a list are dealt to kBoundParts
 // workgroups.
-constexpr int kBoundParts = 2;
+#ifndef VS_BOUND_PARTS
+#define VS_BOUND_PARTS 2
+#endif
+constexpr int kBoundParts = VS_BOUND_PARTS;
 constexpr int kBoundLds = kIvfTauRows * kDim + kIvfTauRows * 4 + 4 * 16 * 16 * 4;  // rows | row terms | the waves' lists
 __device__ __forceinline__ void ivf_bounds_list_body(const IvfWideParams& p, const int c, const int part, char* const lds, const int pad_sb) {
     typedef int i32x4 __attribute__((ext_vector_type(4)));
