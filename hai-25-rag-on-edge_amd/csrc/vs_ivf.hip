@@ -1292,32 +1292,40 @@ __global__ __launch_bounds__(kIvfWideThreads) void ivf_scan_wide_kernel(const Iv
         const int r0 = rc.r0 - td, r_end = rc.r_end - td, nq = rc.nq;
         if (u + nw < n_units) rec = recs[u + nw];  // the next record, in flight during this one
         const int32_t* lqc = lq + (int64_t)rc.c * kIvfWideQ + rc.q0;
-#pragma unroll 1
+        // the unit's rows stay in registers (both tiles) while its column blocks pass: a block's query fragments -- eight loads
+        // of 64 separate 16-byte pieces each, the address unit's time -- are then fetched once per unit, not once per tile
+        f32x4 a[kIvfWideTiles][8], bn[kIvfWideTiles];
+#pragma unroll
         for (int t = 0; t < kIvfWideTiles; ++t) {
-            if (r0 + 16 * t >= r_end) break;  // wave-uniform
             const int row = min(r0 + 16 * t + r, r_end - 1);
-            f32x4 a[8];
 #pragma unroll
-            for (int c8 = 0; c8 < 8; ++c8) a[c8] = *reinterpret_cast<const f32x4*>(p.vecs + (int64_t)row * kDim + 16 * c8 + 4 * g);
-            const f32x4 bn = *reinterpret_cast<const f32x4_u*>(p.vnorm + r0 + 16 * t + 4 * g);
-            for (int cb = 0; cb < nq; cb += 16) {
-                const int sq = cb + r;
-                const bool live = sq < nq;
-                const int ql = live ? lqc[sq] >> 7 : 0;  // (the table holds slot * 128)
-                const int qg = qbase + ql;
-                const float* qsrc = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.q) + (long long)(qg >> 5) * p.q_batch_bytes) + (qg & 31) * kDim;
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int c8 = 0; c8 < 8; ++c8) a[t][c8] = *reinterpret_cast<const f32x4*>(p.vecs + (int64_t)row * kDim + 16 * c8 + 4 * g);
+            bn[t] = *reinterpret_cast<const f32x4_u*>(p.vnorm + min(r0 + 16 * t, r_end - 1) + 4 * g);  // (padded by 64)
+        }
+        for (int cb = 0; cb < nq; cb += 16) {
+            const int sq = cb + r;
+            const bool live = sq < nq;
+            const int ql = live ? lqc[sq] >> 7 : 0;  // (the table holds slot * 128)
+            const int qg = qbase + ql;
+            const float* qsrc = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.q) + (long long)(qg >> 5) * p.q_batch_bytes) + (qg & 31) * kDim;
+            f32x4 acc[kIvfWideTiles];
 #pragma unroll
-                for (int c8 = 0; c8 < 8; ++c8) {
-                    const f32x4 qf = *reinterpret_cast<const f32x4*>(qsrc + 16 * c8 + 4 * g);
+            for (int t = 0; t < kIvfWideTiles; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c8][i], qf[i], acc, 0, 0, 0);
-                }
-                const float qn = qn_s[ql];
-                const float tq = live ? tau_s[ql] : -VS_INF;
+            for (int c8 = 0; c8 < 8; ++c8) {
+                const f32x4 qf = *reinterpret_cast<const f32x4*>(qsrc + 16 * c8 + 4 * g);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int t = 0; t < kIvfWideTiles; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][c8][i], qf[i], acc[t], 0, 0, 0);
+            }
+            const float qn = qn_s[ql];
+            const float tq = live ? tau_s[ql] : -VS_INF;
+#pragma unroll
+            for (int t = 0; t < kIvfWideTiles; ++t)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float d = p.metric ? -acc[j] : fmaf(-2.0f, acc[j], qn + bn[j]);
+                    const float d = p.metric ? -acc[t][j] : fmaf(-2.0f, acc[t][j], qn + bn[t][j]);
                     const int rowj = r0 + 16 * t + 4 * g + j;
                     const bool pass = d < tq && rowj < r_end;
                     const unsigned long long mask = __ballot(pass);
@@ -1327,8 +1335,149 @@ __global__ __launch_bounds__(kIvfWideThreads) void ivf_scan_wide_kernel(const Iv
                         wbase += __popcll(mask);
                     }
                 }
-            }
         }
+    }
+    sink_bin_wave(p.sink, wb, wbase, lane);
+}
+
+// The list-major scan on the fp32 rows as a kernel of its own -- what runs when the host knows that the group is scored in
+// fp32 (vs_set_precision(h, 1), rows that are not bytes, the inner-product metric); ivf_scan_wide_kernel's fp32 branch stays
+// for a group that turns out to hold a query that is not byte valued.  Same records, same candidates.  8 waves per workgroup
+// instead of 16: nothing is staged but the bounds and norms, and 256 registers per wave hold what the loop needs to keep the
+// MFMA pipe fed -- the unit's two 16-row tiles of the CURRENT and the NEXT record (A fragments) and a column block's query
+// fragments (B), fetched once per unit.  In the shared kernel a column block waited for its slot-table entry, then
+// for its eight fragment loads, then ran 32 MFMAs, once per tile: 2.9 ms per 8192 queries where the arithmetic takes 1.1.
+constexpr int kIvfWideF32Threads = 512;
+__global__ __launch_bounds__(kIvfWideF32Threads) void ivf_scan_wide_f32_kernel(const IvfWideParams p) {
+    typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+    __shared__ float tau_s[kIvfWideSlots];
+    __shared__ float qn_s[kIvfWideSlots];
+    constexpr int WAVES = kIvfWideF32Threads / 64, NT = kIvfWideTiles, PF = 4;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    const int sb = blockIdx.y;
+    const int b0 = sb * p.sb_batches, b1 = min(p.n_batches, b0 + p.sb_batches);
+    const int qbase = b0 * kMaxBatch;
+    const int nslots = (b1 - b0) * kMaxBatch;
+    const int wb = ((int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x) * WAVES + wave;  // this wave's candidate buffer
+    const int nw = (int)gridDim.x * WAVES;
+    int u = wave * (int)gridDim.x + (int)blockIdx.x;
+    const int4* recs = reinterpret_cast<const int4*>(p.units + (int64_t)sb * p.units_sb_stride);
+    const int32_t* lq = p.lq + (int64_t)sb * p.nlist * kIvfWideQ;
+    int4* wbuf = p.sink.wbuf + (int64_t)wb * p.sink.wcap;
+    int wbase = 0;
+    const int n_units = p.zero[sb * ivf_wide_plan_words(p.nlist) + (int64_t)p.nlist * kIvfWideCntStride];
+    int4 rv0 = recs[min(u, p.units_cap - 1)], rv1 = recs[min(u + nw, p.units_cap - 1)];
+    for (int s = tid; s < kIvfWideSlots; s += kIvfWideF32Threads) {
+        const int qg = qbase + min(s, nslots - 1);
+        const bool live = s < nslots && (s & 31) < p.B && p.slow[qg] == 0;  // a query without a bound goes through the slow path only
+        tau_s[s] = live ? p.tau[qg] : -VS_INF;
+        qn_s[s] = p.qnorm[qg];
+    }
+    if (u >= n_units) rv0 = make_int4(0, 0, 0, 0);
+    if (u + nw >= n_units) rv1 = make_int4(0, 0, 0, 0);
+    __syncthreads();
+    if ((int)blockIdx.x >= n_units) return;  // workgroup-uniform: not even wave 0 has a record
+    struct Rec {
+        int r0, r_end, c, q0, nq, td;
+    };
+    auto unpack = [&](const int4& rv) __attribute__((always_inline)) {
+        Rec rc;
+        rc.c = __builtin_amdgcn_readfirstlane(rv.z);
+        rc.td = p.tdelta ? p.tdelta[rc.c] : 0;  // (records are in padded rows when the index keeps the tiled byte copy)
+        rc.r0 = __builtin_amdgcn_readfirstlane(rv.x) - rc.td;
+        rc.r_end = __builtin_amdgcn_readfirstlane(rv.y) - rc.td;
+        const int w = __builtin_amdgcn_readfirstlane(rv.w);
+        rc.q0 = w & 0xffff;
+        rc.nq = (w >> 16) - rc.q0;
+        return rc;
+    };
+    auto issue = [&](const Rec& rc, f32x4 (&a)[NT][8], f32x4 (&bn)[NT], int (&sq)[PF]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int row = max(min(rc.r0 + 16 * t + r, rc.r_end - 1), 0);
+#pragma unroll
+            for (int c8 = 0; c8 < 8; ++c8) a[t][c8] = *reinterpret_cast<const f32x4*>(p.vecs + (int64_t)row * kDim + 16 * c8 + 4 * g);
+            bn[t] = *reinterpret_cast<const f32x4_u*>(p.vnorm + max(min(rc.r0 + 16 * t, rc.r_end - 1), 0) + 4 * g);  // (padded by 64)
+        }
+        const int32_t* lqn = lq + (int64_t)rc.c * kIvfWideQ + rc.q0;
+#pragma unroll
+        for (int i = 0; i < PF; ++i) sq[i] = lqn[16 * i + r];  // (raw entries: a row of the table has room, selected at use)
+    };
+    auto qfrag = [&](const int ql, f32x4 (&qf)[8]) __attribute__((always_inline)) {
+        const int qg = qbase + ql;
+        const float* qsrc = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.q) + (long long)(qg >> 5) * p.q_batch_bytes) + (qg & 31) * kDim;
+#pragma unroll
+        for (int c8 = 0; c8 < 8; ++c8) qf[c8] = *reinterpret_cast<const f32x4*>(qsrc + 16 * c8 + 4 * g);
+    };
+    auto score = [&](const Rec& rc, const f32x4 (&a)[NT][8], const f32x4 (&bn)[NT], const f32x4 (&qf)[8], const int ql, const bool live) __attribute__((always_inline)) {
+        f32x4 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c8 = 0; c8 < 8; ++c8)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][c8][i], qf[c8][i], acc[t], 0, 0, 0);
+        const float qn = qn_s[ql];
+        const float tq = live ? tau_s[ql] : -VS_INF;
+        const int qg = qbase + ql;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float d = p.metric ? -acc[t][j] : fmaf(-2.0f, acc[t][j], qn + bn[t][j]);
+                const int rowj = rc.r0 + 16 * t + 4 * g + j;
+                const bool pass = d < tq && rowj < rc.r_end;
+                const unsigned long long mask = __ballot(pass);
+                if (mask) {
+                    const int pos = wbase + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+                    if (pass && pos < p.sink.wcap) wbuf[pos] = make_int4(qg, __builtin_bit_cast(int, d), rowj + rc.td, 0);
+                    wbase += __popcll(mask);
+                }
+            }
+    };
+    auto compute = [&](const Rec& rc, const f32x4 (&a)[NT][8], const f32x4 (&bn)[NT], const int (&sq)[PF]) __attribute__((always_inline)) {
+        if (rc.nq <= 0) return;  // wave-uniform
+        const int32_t* lqc = lq + (int64_t)rc.c * kIvfWideQ + rc.q0;
+        // (one fragment set: with the A fragments of two records resident a second set spills; the block's slot comes with the
+        // record's rows, so a block costs one cache round trip -- the SIMD's other wave scores meanwhile)
+        auto slot_of = [&](const int cb) __attribute__((always_inline)) {  // (wave-uniform cb) the lane's slot of column block cb
+            int e = 0;
+#pragma unroll
+            for (int i = 0; i < PF; ++i)
+                if (cb == 16 * i) e = sq[i];
+            if (cb >= 16 * PF) e = lqc[cb + r];
+            return cb + r < rc.nq ? e >> 7 : 0;  // (the table holds slot * 128)
+        };
+        for (int cb = 0; cb < rc.nq; cb += 16) {
+            f32x4 qf[8];
+            const int ql = slot_of(cb);
+            qfrag(ql, qf);
+            score(rc, a, bn, qf, ql, cb + r < rc.nq);
+        }
+    };
+    f32x4 A0[NT][8], A1[NT][8], BN0[NT], BN1[NT];
+    int SQ0[PF], SQ1[PF];
+    Rec R0 = unpack(rv0), R1;
+    issue(R0, A0, BN0, SQ0);
+    int4 rvn = rv1;
+    // software pipeline over the wave's records: the next record's rows and slots travel while this one is scored
+    for (;;) {
+        R1 = unpack(rvn);
+        rvn = u + 2 * nw < n_units ? recs[u + 2 * nw] : make_int4(0, 0, 0, 0);
+        issue(R1, A1, BN1, SQ1);
+        compute(R0, A0, BN0, SQ0);
+        u += nw;
+        if (u >= n_units) break;
+        R0 = unpack(rvn);
+        rvn = u + 2 * nw < n_units ? recs[u + 2 * nw] : make_int4(0, 0, 0, 0);
+        issue(R0, A0, BN0, SQ0);
+        compute(R1, A1, BN1, SQ1);
+        u += nw;
+        if (u >= n_units) break;
     }
     sink_bin_wave(p.sink, wb, wbase, lane);
 }
@@ -1462,7 +1611,11 @@ hipError_t launch_ivf_wide_scan(const IvfWideParams& p, int num_cus, hipStream_t
         if (e != hipSuccess) return e;
         attr_set[dev] = true;
     }
-    hipLaunchKernelGGL(ivf_scan_wide_kernel, dim3(ivf_wide_grid_x(num_cus, n_sb), n_sb), dim3(kIvfWideThreads), kIvfWideLds, s, p);
+    static const bool f32_own = !(getenv("VSEARCH_IVF_F32_SHARED") && atoi(getenv("VSEARCH_IVF_F32_SHARED")));  // (A/B knob)
+    if (f32_own && (!p.vecs_t8 || p.metric != 0))  // the group is scored in fp32, and the host knows it
+        hipLaunchKernelGGL(ivf_scan_wide_f32_kernel, dim3(ivf_wide_grid_x(num_cus, n_sb), n_sb), dim3(kIvfWideF32Threads), 0, s, p);
+    else
+        hipLaunchKernelGGL(ivf_scan_wide_kernel, dim3(ivf_wide_grid_x(num_cus, n_sb), n_sb), dim3(kIvfWideThreads), kIvfWideLds, s, p);
     return hipGetLastError();
 }
 
