@@ -1348,8 +1348,10 @@ __global__ __launch_bounds__(kIvfWideThreads) void ivf_scan_wide_kernel(const Iv
 // fragments (B), fetched once per unit.  In the shared kernel a column block waited for its slot-table entry, then
 // for its eight fragment loads, then ran 32 MFMAs, once per tile: 2.9 ms per 8192 queries where the arithmetic takes 1.1.
 constexpr int kIvfWideF32Threads = 512;
+constexpr int kIvfWideF32Lds = (kIvfWideF32Threads / 64) * 2 * 8192;  // per wave: two landing buffers of a column block's fragments
 __global__ __launch_bounds__(kIvfWideF32Threads) void ivf_scan_wide_f32_kernel(const IvfWideParams p) {
     typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+    extern __shared__ __attribute__((aligned(16))) char f32_smem[];
     __shared__ float tau_s[kIvfWideSlots];
     __shared__ float qn_s[kIvfWideSlots];
     constexpr int WAVES = kIvfWideF32Threads / 64, NT = kIvfWideTiles, PF = 4;
@@ -1368,7 +1370,10 @@ __global__ __launch_bounds__(kIvfWideF32Threads) void ivf_scan_wide_f32_kernel(c
     int4* wbuf = p.sink.wbuf + (int64_t)wb * p.sink.wcap;
     int wbase = 0;
     const int n_units = p.zero[sb * ivf_wide_plan_words(p.nlist) + (int64_t)p.nlist * kIvfWideCntStride];
-    int4 rv0 = recs[min(u, p.units_cap - 1)], rv1 = recs[min(u + nw, p.units_cap - 1)];
+    auto record = [&](const int idx) __attribute__((always_inline)) {  // (a zero record: rows 0.., no column block)
+        return idx < n_units ? recs[min(idx, p.units_cap - 1)] : make_int4(0, 0, 0, 0);
+    };
+    int4 rv0 = recs[min(u, p.units_cap - 1)], rv1 = recs[min(u + nw, p.units_cap - 1)], rv2 = recs[min(u + 2 * nw, p.units_cap - 1)];
     for (int s = tid; s < kIvfWideSlots; s += kIvfWideF32Threads) {
         const int qg = qbase + min(s, nslots - 1);
         const bool live = s < nslots && (s & 31) < p.B && p.slow[qg] == 0;  // a query without a bound goes through the slow path only
@@ -1377,6 +1382,7 @@ __global__ __launch_bounds__(kIvfWideF32Threads) void ivf_scan_wide_f32_kernel(c
     }
     if (u >= n_units) rv0 = make_int4(0, 0, 0, 0);
     if (u + nw >= n_units) rv1 = make_int4(0, 0, 0, 0);
+    if (u + 2 * nw >= n_units) rv2 = make_int4(0, 0, 0, 0);
     __syncthreads();
     if ((int)blockIdx.x >= n_units) return;  // workgroup-uniform: not even wave 0 has a record
     struct Rec {
@@ -1393,7 +1399,7 @@ __global__ __launch_bounds__(kIvfWideF32Threads) void ivf_scan_wide_f32_kernel(c
         rc.nq = (w >> 16) - rc.q0;
         return rc;
     };
-    auto issue = [&](const Rec& rc, f32x4 (&a)[NT][8], f32x4 (&bn)[NT], int (&sq)[PF]) __attribute__((always_inline)) {
+    auto issue_rows = [&](const Rec& rc, f32x4 (&a)[NT][8], f32x4 (&bn)[NT]) __attribute__((always_inline)) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int row = max(min(rc.r0 + 16 * t + r, rc.r_end - 1), 0);
@@ -1401,26 +1407,47 @@ __global__ __launch_bounds__(kIvfWideF32Threads) void ivf_scan_wide_f32_kernel(c
             for (int c8 = 0; c8 < 8; ++c8) a[t][c8] = *reinterpret_cast<const f32x4*>(p.vecs + (int64_t)row * kDim + 16 * c8 + 4 * g);
             bn[t] = *reinterpret_cast<const f32x4_u*>(p.vnorm + max(min(rc.r0 + 16 * t, rc.r_end - 1), 0) + 4 * g);  // (padded by 64)
         }
+    };
+    auto issue_slots = [&](const Rec& rc, int (&sq)[PF]) __attribute__((always_inline)) {
         const int32_t* lqn = lq + (int64_t)rc.c * kIvfWideQ + rc.q0;
 #pragma unroll
         for (int i = 0; i < PF; ++i) sq[i] = lqn[16 * i + r];  // (raw entries: a row of the table has room, selected at use)
     };
-    auto qfrag = [&](const int ql, f32x4 (&qf)[8]) __attribute__((always_inline)) {
-        const int qg = qbase + ql;
-        const float* qsrc = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.q) + (long long)(qg >> 5) * p.q_batch_bytes) + (qg & 31) * kDim;
+    auto slot_of = [&](const Rec& rc, const int (&sq)[PF], const int cb) __attribute__((always_inline)) {  // (wave-uniform cb)
+        int e = 0;
 #pragma unroll
-        for (int c8 = 0; c8 < 8; ++c8) qf[c8] = *reinterpret_cast<const f32x4*>(qsrc + 16 * c8 + 4 * g);
+        for (int i = 0; i < PF; ++i)
+            if (cb == 16 * i) e = sq[i];
+        if (cb >= 16 * PF) e = lq[(int64_t)rc.c * kIvfWideQ + rc.q0 + cb + r];
+        return cb + r < rc.nq ? e >> 7 : 0;  // (the table holds slot * 128)
     };
-    auto score = [&](const Rec& rc, const f32x4 (&a)[NT][8], const f32x4 (&bn)[NT], const f32x4 (&qf)[8], const int ql, const bool live) __attribute__((always_inline)) {
+    // A column block's query fragments land in the wave's LDS buffer `par` by LDS-DMA (no registers while they travel):
+    // instruction c8 moves the 16 bytes Q[slot][16 c8 + 4 g ..] of every lane to buffer + 1024 c8 + 16 lane, which is where the
+    // MFMA B operand of step c8 is read from.  The waits for these loads are written by hand (the compiler does not see them).
+    const unsigned lds_w = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)(f32_smem + wave * 16384));
+    const char* qbytes = reinterpret_cast<const char*>(p.q);
+    auto dma = [&](const int ql, const int par) __attribute__((always_inline)) {
+        const int qg = qbase + ql;
+        const unsigned voff = (unsigned)((long long)(qg >> 5) * p.q_batch_bytes) + (unsigned)((qg & 31) * (kDim * 4) + 16 * g);
+        const unsigned dst = lds_w + (unsigned)par * 8192u;
+        // (no instruction offset: it would move the LDS address as well as the global one)
+#define VS_QDMA(c8) asm volatile("s_add_u32 m0, %0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(voff + 64u * (c8)), "s"(qbytes), "n"((c8) * 1024) : "memory", "scc")
+        VS_QDMA(0); VS_QDMA(1); VS_QDMA(2); VS_QDMA(3); VS_QDMA(4); VS_QDMA(5); VS_QDMA(6); VS_QDMA(7);
+#undef VS_QDMA
+    };
+    auto score = [&](const Rec& rc, const f32x4 (&a)[NT][8], const f32x4 (&bn)[NT], const int par, const int ql, const bool live) __attribute__((always_inline)) {
+        const f32x4* qb = reinterpret_cast<const f32x4*>(f32_smem + wave * 16384 + par * 8192) + lane;
         f32x4 acc[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int c8 = 0; c8 < 8; ++c8)
+        for (int c8 = 0; c8 < 8; ++c8) {
+            const f32x4 qf = qb[c8 * 64];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][c8][i], qf[c8][i], acc[t], 0, 0, 0);
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][c8][i], qf[i], acc[t], 0, 0, 0);
+        }
         const float qn = qn_s[ql];
         const float tq = live ? tau_s[ql] : -VS_INF;
         const int qg = qbase + ql;
@@ -1439,46 +1466,74 @@ __global__ __launch_bounds__(kIvfWideF32Threads) void ivf_scan_wide_f32_kernel(c
                 }
             }
     };
-    auto compute = [&](const Rec& rc, const f32x4 (&a)[NT][8], const f32x4 (&bn)[NT], const int (&sq)[PF]) __attribute__((always_inline)) {
-        if (rc.nq <= 0) return;  // wave-uniform
-        const int32_t* lqc = lq + (int64_t)rc.c * kIvfWideQ + rc.q0;
-        // (one fragment set: with the A fragments of two records resident a second set spills; the block's slot comes with the
-        // record's rows, so a block costs one cache round trip -- the SIMD's other wave scores meanwhile)
-        auto slot_of = [&](const int cb) __attribute__((always_inline)) {  // (wave-uniform cb) the lane's slot of column block cb
-            int e = 0;
-#pragma unroll
-            for (int i = 0; i < PF; ++i)
-                if (cb == 16 * i) e = sq[i];
-            if (cb >= 16 * PF) e = lqc[cb + r];
-            return cb + r < rc.nq ? e >> 7 : 0;  // (the table holds slot * 128)
-        };
+    // The wave's column blocks form one sequence across its records.  At block i: the DMA of block i + 1 goes out, then the
+    // wait for block i's (everything but the eight loads just issued has landed), then -- at a record's first block -- the
+    // rows of the NEXT record and the slot entries of the one after it are requested, then block i is scored.
+    int par = 0;
+    bool young = false;  // (wave-uniform) the previous block requested rows and slots after its wait
+    auto compute = [&](const Rec& rc, const f32x4 (&a)[NT][8], const f32x4 (&bn)[NT], const int (&sq)[PF], const Rec& rn, f32x4 (&an)[NT][8],
+                       f32x4 (&bnn)[NT], const int (&sqn)[PF], const Rec& rnn, int (&sqnn)[PF]) __attribute__((always_inline)) {
+        int ql = slot_of(rc, sq, 0);  // (its DMA is in flight: issued by the previous record's last block, or by the prologue)
+        // (the record's rows are waited for HERE, by the compiler: its wait in front of the first MFMA would also be a wait for
+        // the DMA issued just before it.  The last row load issued stands for all of them.)
+        if (rc.nq > 0) asm volatile("" ::"v"(bn[NT - 1]));
         for (int cb = 0; cb < rc.nq; cb += 16) {
-            f32x4 qf[8];
-            const int ql = slot_of(cb);
-            qfrag(ql, qf);
-            score(rc, a, bn, qf, ql, cb + r < rc.nq);
+            int ql_next = 0;
+            const bool in_rec = cb + 16 < rc.nq, any = in_rec || rn.nq > 0;  // wave-uniform
+            if (in_rec) ql_next = slot_of(rc, sq, cb + 16);
+            else if (rn.nq > 0) ql_next = slot_of(rn, sqn, 0);
+            // What is younger than this block's DMA: the eight loads of the next block's, and -- if the block before this one
+            // was a record's first -- the 22 row and slot loads it requested after its wait (20 counted: a margin of two).
+            if (any) {
+                dma(ql_next, par ^ 1);
+                if (young) asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            } else {
+                if (young) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            young = false;
+            if (cb == 0) {
+                issue_rows(rn, an, bnn);
+                issue_slots(rnn, sqnn);
+                young = true;
+            }
+            score(rc, a, bn, par, ql, cb + r < rc.nq);
+            par ^= 1;
+            ql = ql_next;
+        }
+        if (rc.nq <= 0) {  // (a zero record, at the tail only: keep the row / slot pipeline moving)
+            issue_rows(rn, an, bnn);
+            issue_slots(rnn, sqnn);
+            young = false;  // (no DMA is in flight across it: the record before had no next block to request)
         }
     };
     f32x4 A0[NT][8], A1[NT][8], BN0[NT], BN1[NT];
-    int SQ0[PF], SQ1[PF];
-    Rec R0 = unpack(rv0), R1;
-    issue(R0, A0, BN0, SQ0);
-    int4 rvn = rv1;
-    // software pipeline over the wave's records: the next record's rows and slots travel while this one is scored
+    int SQ0[PF], SQ1[PF], SQ2[PF];
+    Rec R0 = unpack(rv0), R1 = unpack(rv1), R2 = unpack(rv2);
+    issue_slots(R0, SQ0);
+    issue_slots(R1, SQ1);
+    issue_rows(R0, A0, BN0);
+    if (R0.nq > 0) dma(slot_of(R0, SQ0, 0), 0);
+    int4 rvn = record(u + 3 * nw);
+    // three records in the pipeline: scored | rows travelling | slot entries travelling.  (Unrolled by six: the two row
+    // sets and the three slot sets rotate through fixed names.)
     for (;;) {
-        R1 = unpack(rvn);
-        rvn = u + 2 * nw < n_units ? recs[u + 2 * nw] : make_int4(0, 0, 0, 0);
-        issue(R1, A1, BN1, SQ1);
-        compute(R0, A0, BN0, SQ0);
-        u += nw;
-        if (u >= n_units) break;
-        R0 = unpack(rvn);
-        rvn = u + 2 * nw < n_units ? recs[u + 2 * nw] : make_int4(0, 0, 0, 0);
-        issue(R0, A0, BN0, SQ0);
-        compute(R1, A1, BN1, SQ1);
-        u += nw;
-        if (u >= n_units) break;
+#define VS_STEP(RC, AC, BC, SC, RN, AN, BNX, SN, RNN, SNN)                    \
+        compute(RC, AC, BC, SC, RN, AN, BNX, SN, RNN, SNN);                   \
+        u += nw;                                                              \
+        if (u >= n_units) break;                                              \
+        RC = unpack(rvn); /* the record three steps on takes the free name */ \
+        rvn = record(u + 3 * nw);
+        VS_STEP(R0, A0, BN0, SQ0, R1, A1, BN1, SQ1, R2, SQ2)
+        VS_STEP(R1, A1, BN1, SQ1, R2, A0, BN0, SQ2, R0, SQ0)
+        VS_STEP(R2, A0, BN0, SQ2, R0, A1, BN1, SQ0, R1, SQ1)
+        VS_STEP(R0, A1, BN1, SQ0, R1, A0, BN0, SQ1, R2, SQ2)
+        VS_STEP(R1, A0, BN0, SQ1, R2, A1, BN1, SQ2, R0, SQ0)
+        VS_STEP(R2, A1, BN1, SQ2, R0, A0, BN0, SQ0, R1, SQ1)
+#undef VS_STEP
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     sink_bin_wave(p.sink, wb, wbase, lane);
 }
 
@@ -1609,11 +1664,13 @@ hipError_t launch_ivf_wide_scan(const IvfWideParams& p, int num_cus, hipStream_t
     if (!attr_set[dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ivf_scan_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kIvfWideLds);
         if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(ivf_scan_wide_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kIvfWideF32Lds);
+        if (e != hipSuccess) return e;
         attr_set[dev] = true;
     }
     static const bool f32_own = !(getenv("VSEARCH_IVF_F32_SHARED") && atoi(getenv("VSEARCH_IVF_F32_SHARED")));  // (A/B knob)
     if (f32_own && (!p.vecs_t8 || p.metric != 0))  // the group is scored in fp32, and the host knows it
-        hipLaunchKernelGGL(ivf_scan_wide_f32_kernel, dim3(ivf_wide_grid_x(num_cus, n_sb), n_sb), dim3(kIvfWideF32Threads), 0, s, p);
+        hipLaunchKernelGGL(ivf_scan_wide_f32_kernel, dim3(ivf_wide_grid_x(num_cus, n_sb), n_sb), dim3(kIvfWideF32Threads), kIvfWideF32Lds, s, p);
     else
         hipLaunchKernelGGL(ivf_scan_wide_kernel, dim3(ivf_wide_grid_x(num_cus, n_sb), n_sb), dim3(kIvfWideThreads), kIvfWideLds, s, p);
     return hipGetLastError();
