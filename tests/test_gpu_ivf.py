@@ -585,6 +585,35 @@ def test_wide_groups_on_two_streams_hot_lists(gpu_pkg):
     assert np.array_equal(np.take_along_axis(ex, want_i.cpu().numpy()[sub].astype(np.int64), 1).astype(np.float32), gd)
 
 
+@pytest.mark.parametrize("nb,B", [(70, 32), (40, 20)])
+def test_fp32_rows_scan_kernel_hot_lists_equals_int8_rows(gpu_pkg, nb, B):
+    """`vs_set_precision(h, 1)` sends the list scan to its fp32 kernel (`ivf_scan_wide_f32_kernel`: query fragments by
+    LDS-DMA one column block ahead, rows one record ahead, hand-counted waits).  Few lists, so every list is probed by
+    hundreds of a super-batch's queries: records with far more than the four column blocks whose slots travel with the
+    rows, several launch groups and super-batches, a ragged batch size, waves without a record.  On integer data the
+    fp32 distances are exact: ids and distances must equal the int8-rows scan's bit for bit."""
+    import torch
+    dev = torch.device("cuda:0")
+    base, cents, vr, off, r2o = _make_index(gpu_pkg, n=30000, nlist=16, seed=23)
+    k, nprobe = 5, 4
+    q = gpu_pkg.synth_sift(B * nb, seed=79)
+    qd = torch.from_numpy(q).to(dev)
+    s = torch.cuda.current_stream().cuda_stream
+    with gpu_pkg.IVFIndex(vectors_reordered=vr, centroids=cents, cluster_offsets=off, reorder_to_original=r2o) as ivf:
+        out = []
+        for precision in (0, 1, 1):
+            ivf.set_precision(precision)
+            got_i = torch.full((nb * B, k), -7, dtype=torch.int32, device=dev)
+            got_d = torch.zeros((nb * B, k), dtype=torch.float32, device=dev)
+            ivf.search_dev_multi(qd.data_ptr(), nb, B, k, nprobe, got_i.data_ptr(), got_d.data_ptr(), s)
+            torch.cuda.synchronize()
+            out.append((got_i.cpu().numpy(), got_d.cpu().numpy()))
+    for gi, gd in out[1:]:
+        assert np.array_equal(gd, out[0][1]) and np.array_equal(gi, out[0][0])
+    ex = oracle.exact_int_dists(q[:200], base)
+    assert np.array_equal(np.take_along_axis(ex, out[1][0][:200].astype(np.int64), 1).astype(np.float32), out[1][1][:200])
+
+
 def test_wide_slow_path_duplicates_and_tiny_lists(gpu_pkg):
     """Queries the wide pipeline cannot bound or whose candidates do not fit their lists go through the exact slow path
     inside the ranking launch: (i) thousands of identical rows (every one of them is under the bound: the sub-lists
