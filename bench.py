@@ -617,7 +617,8 @@ def main():
                     info["roofline"] = {"bound": "hbm", "achieved": round(ach, 1) if ach else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                         "frac": frac, "algorithmic_rate_over_hbm_peak_cache_resident": above_hbm, "traffic": itraffic,
                                         "traffic_source": "static: profiles/traffic_ivf_list_scan.json (rocprofv3 --pmc passes, not measured in this run)",
-                                        "kernel": "vs::ivf_scan_wide_kernel", "kernel_us": round(ks_launch * 1e6, 2),
+                                        "kernel": "vs::ivf_scan_wide_kernel" if rb < 512 else "vs::ivf_scan_wide_f32_kernel",
+                                        "kernel_us": round(ks_launch * 1e6, 2),
                                         "launches": int(okern_n), "batches_per_launch": round(sum(window) / max(len(window), 1), 2),
                                         "algorithmic_bytes_per_launch": int(ib), "row_bytes": rb,
                                         "distinct_rows_per_launch": uniq_rows,
