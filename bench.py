@@ -614,7 +614,15 @@ def main():
                         # super-batch) the HBM roof binds and a value above 1 would mean the byte model is wrong.
                         assert rb < 512, ("the byte model does not describe the kernel", frac)
                         above_hbm, frac = frac, None
+                    # fp32 rows: the MFMA pipe is the nearer roof (2 * 128 flop per (query, row) pair of the launch's candidates)
+                    mfma = None
+                    if rb > 512 and ks_launch > 0:
+                        pairs = info["avg_candidates"] * BATCH * (sum(window) / max(len(window), 1))
+                        tf = 2.0 * DIM * pairs / ks_launch / 1e12
+                        mfma = {"achieved_tflops": round(tf, 1), "peak_tflops": MFMA_F32_PEAK_TFLOPS, "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4)}
+                        assert mfma["frac"] <= 1.0, mfma
                     info["roofline"] = {"bound": "hbm", "achieved": round(ach, 1) if ach else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                        "mfma_f32": mfma,
                                         "frac": frac, "algorithmic_rate_over_hbm_peak_cache_resident": above_hbm, "traffic": itraffic,
                                         "traffic_source": "static: profiles/traffic_ivf_list_scan.json (rocprofv3 --pmc passes, not measured in this run)",
                                         "kernel": "vs::ivf_scan_wide_kernel" if rb < 512 else "vs::ivf_scan_wide_f32_kernel",
