@@ -137,20 +137,12 @@ __global__ __launch_bounds__(256) void ivf_coarse_mfma_kernel(const float* __res
     // unit, not the arithmetic, set the kernel's time (13 us).  Rows are 132 floats apart in LDS: fragment reads of
     // 8 neighbouring rows then fall into different banks.
     constexpr int LD = kDim + 4;
-    // (one place for both: the queries are in registers when the first tile is written -- 34 KB, four workgroups per CU)
-    __shared__ __attribute__((aligned(16))) float c_s[64 * LD];
-    float* const q_s = c_s;
+    // Dynamic LDS, kCoarseLds bytes: every wave owns two 8 KB landing buffers for ITS 16 centroids of a tile (below); the
+    // queries' staging place in the prologue lies over them (the queries are in registers before the first tile lands).
+    extern __shared__ __attribute__((aligned(16))) char co_smem[];
+    float* const q_s = reinterpret_cast<float*>(co_smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
-    f32x4 vc[8], cn_nx = {0.f, 0.f, 0.f, 0.f};
-    auto load_tile = [&](int t) {  // (every load unconditional: the centroid array has kScanPadRows spare rows, the norms 64)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int idx = tid + 256 * i;  // float4 (row, column) of the 64 x 32 tile
-            vc[i] = *reinterpret_cast<const f32x4*>(cents + ((int64_t)t * 64 + (idx >> 5)) * kDim + 4 * (idx & 31));
-        }
-        cn_nx = *reinterpret_cast<const f32x4*>(cnorm + t * 64 + wave * 16 + 4 * g);
-    };
     {
         f32x4 vq[4];
 #pragma unroll
@@ -158,7 +150,6 @@ __global__ __launch_bounds__(256) void ivf_coarse_mfma_kernel(const float* __res
             const int idx = tid + 256 * i;  // float4 (row, column) of the 32 x 32 tile
             vq[i] = *reinterpret_cast<const f32x4*>(q + min(idx >> 5, B - 1) * kDim + 4 * (idx & 31));
         }
-        if (!prep_only) load_tile(t0);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int idx = tid + 256 * i;
@@ -226,46 +217,62 @@ __global__ __launch_bounds__(256) void ivf_coarse_mfma_kernel(const float* __res
     CO_STAMP(1);
     if (prep_only) return;  // (sharded front half: the queries of ALL slices are prepared on every rank, scored only on their own)
     const float qn[2] = {qn_s[r], qn_s[16 + r]};
+    // A wave's A fragments of a tile -- its 16 centroids, chunk c8: the 16 bytes C[16 wave + r][16 c8 + 4 g ..] of every lane --
+    // land in the wave's own LDS buffer by LDS-DMA, in fragment order (instruction c8 fills buffer + 1024 c8 + 16 lane), one
+    // tile ahead: no staging registers, no workgroup barrier in the loop, every wave at its own pace.  (Through registers and
+    // a shared 64-row tile the loop was stage 0.5 + fetch 0.9 + MFMA 1.5 + epilogue 0.8 us per tile and wave, with two
+    // barriers.)  One wait per tile, at the top, for everything issued during the tile before: the next tile's DMA, its norms,
+    // the previous tile's score stores -- all of them had a whole tile's MFMAs to complete.
+    const unsigned lds_w = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)(co_smem + wave * 16384));
+    const unsigned voff0 = (unsigned)((16 * wave + r) * (kDim * 4) + 16 * g);
+    const char* cbytes = reinterpret_cast<const char*>(cents);
+    auto dma_tile = [&](const int t, const int par) __attribute__((always_inline)) {
+        const unsigned voff = voff0 + (unsigned)t * (64u * kDim * 4u);
+        const unsigned dst = lds_w + (unsigned)par * 8192u;
+        // (no instruction offset: it would move the LDS address as well as the global one)
+#define VS_CDMA(c8) asm volatile("s_add_u32 m0, %0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(voff + 64u * (c8)), "s"(cbytes), "n"((c8) * 1024) : "memory", "scc")
+        VS_CDMA(0); VS_CDMA(1); VS_CDMA(2); VS_CDMA(3); VS_CDMA(4); VS_CDMA(5); VS_CDMA(6); VS_CDMA(7);
+#undef VS_CDMA
+    };
     f32x4 d_out[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};  // the wave's scores of a tile: 16 centroids x 2 x 16 queries
     auto store_scores = [&](int t) {
 #pragma unroll
         for (int h = 0; h < 2; ++h)
             if (h * 16 + r < B) *reinterpret_cast<f32x4*>(scores + (int64_t)(h * 16 + r) * ld + t * 64 + wave * 16 + 4 * g) = d_out[h];
     };
+    dma_tile(t0, 0);
+    f32x4 cn_nx = *reinterpret_cast<const f32x4*>(cnorm + t0 * 64 + wave * 16 + 4 * g);  // (padded by 64)
+    int par = 0;
     for (int t = t0; t < t1; ++t) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int idx = tid + 256 * i;
-            *reinterpret_cast<f32x4*>(c_s + (idx >> 5) * LD + 4 * (idx & 31)) = vc[i];
-        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const f32x4 cn = cn_nx;
-        __syncthreads();
+        asm volatile("" ::"v"(cn));  // (the compiler's own wait for the norms belongs HERE, not in front of the epilogue behind the next DMA)
+        if (t + 1 < t1) {  // (workgroup-uniform)
+            dma_tile(t + 1, par ^ 1);
+            cn_nx = *reinterpret_cast<const f32x4*>(cnorm + (t + 1) * 64 + wave * 16 + 4 * g);
+        }
+        if (t > t0) store_scores(t - 1);  // (a tile late: it has this tile's MFMAs to complete)
         if (t == t0 + 1) CO_STAMP(3);
-        if (t + 1 < t1) load_tile(t + 1);  // (workgroup-uniform)
-        // The previous tile's scores are stored HERE, a tile late: stores and loads share one in-order counter, and the
-        // wait for the next tile's centroids at the top of the loop was also a wait for stores issued a moment before it
-        // (a microsecond per tile).  Now everything it waits for was issued a whole tile earlier.
-        if (t > t0) store_scores(t - 1);
-        f32x4 a[8];
-#pragma unroll
-        for (int c = 0; c < 8; ++c) a[c] = *reinterpret_cast<const f32x4*>(c_s + (wave * 16 + r) * LD + 16 * c + 4 * g);
+        const f32x4* ab = reinterpret_cast<const f32x4*>(co_smem + wave * 16384 + par * 8192) + lane;
         const int row0 = t * 64 + wave * 16;  // this wave's 16 centroids
-        if (t == t0 + 1) CO_STAMP(4);
-        // (the two column blocks' chains are interleaved: a chain alone waits a few cycles between dependent MFMAs)
         f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
         if (B > 16) {  // workgroup-uniform
 #pragma unroll
-            for (int c = 0; c < 8; ++c)
+            for (int c = 0; c < 8; ++c) {
+                const f32x4 a = ab[c * 64];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][i], qf[0][c][i], acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][i], qf[1][c][i], acc[1], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], qf[0][c][i], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], qf[1][c][i], acc[1], 0, 0, 0);
                 }
+            }
         } else {
 #pragma unroll
-            for (int c = 0; c < 8; ++c)
+            for (int c = 0; c < 8; ++c) {
+                const f32x4 a = ab[c * 64];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][i], qf[0][c][i], acc[0], 0, 0, 0);
+                for (int i = 0; i < 4; ++i) acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], qf[0][c][i], acc[0], 0, 0, 0);
+            }
         }
         if (t == t0 + 1) CO_STAMP(5);
 #pragma unroll
@@ -279,15 +286,29 @@ __global__ __launch_bounds__(256) void ivf_coarse_mfma_kernel(const float* __res
         }
         if (t == t0) CO_STAMP(2);
         if (t == t0 + 1) CO_STAMP(6);
-        __syncthreads();  // (the tile's place is written again)
-        if (t == t0 + 1) CO_STAMP(8);
+        par ^= 1;
     }
     store_scores(t1 - 1);
     CO_STAMP(7);
 }
 
+constexpr int kCoarseLds = 4 * 16384;  // four waves x two landing buffers of 8 KB
+
 // tiles of 64 centroids a workgroup of the coarse kernel takes in a row: as many as leave the launch 512 workgroups (two per
 // CU), 8 at most
+// (the coarse kernel's dynamic LDS: 64 KB + its static words pass the default limit)
+static hipError_t coarse_lds_attr() {
+    static bool attr_set[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!attr_set[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ivf_coarse_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kCoarseLds);
+        if (e != hipSuccess) return e;
+        attr_set[dev] = true;
+    }
+    return hipSuccess;
+}
+
 static int coarse_nct(int tiles, int n_batches) {
     static const int forced = getenv("VSEARCH_COARSE_NCT") ? atoi(getenv("VSEARCH_COARSE_NCT")) : 0;  // (tuning knob)
     return forced > 0 ? forced : std::max(1, std::min(8, tiles * n_batches / 512));
@@ -563,7 +584,8 @@ hipError_t launch_ivf_coarse_pick(const float* q, int B, const float* cents, con
                                   int metric, float* scores, int ld, int32_t* probes, const IvfGroup& grp, hipStream_t s, int n_batches) {
     if (nprobe > 256 || nlist > kIvfFastNlist || ld < ((nlist + 63) & ~63)) return hipErrorInvalidValue;
     const int tiles = (nlist + 63) / 64, nct = coarse_nct(tiles, n_batches);
-    hipLaunchKernelGGL(ivf_coarse_mfma_kernel, dim3((tiles + nct - 1) / nct, n_batches), dim3(256), 0, s, q, B, cents, cnorm, nlist, metric,
+    if (hipError_t e = coarse_lds_attr(); e != hipSuccess) return e;
+    hipLaunchKernelGGL(ivf_coarse_mfma_kernel, dim3((tiles + nct - 1) / nct, n_batches), dim3(256), kCoarseLds, s, q, B, cents, cnorm, nlist, metric,
                        scores, ld, grp.mb, grp, 0, nct);
     if (nlist <= 1024) hipLaunchKernelGGL(ivf_pick_kernel<4>, dim3(B, n_batches), dim3(256), 0, s, scores, ld, nlist, nprobe, probes, grp);
     else if (nlist <= 2048) hipLaunchKernelGGL(ivf_pick_kernel<8>, dim3(B, n_batches), dim3(256), 0, s, scores, ld, nlist, nprobe, probes, grp);
@@ -575,7 +597,8 @@ hipError_t launch_ivf_coarse_pick(const float* q, int B, const float* cents, con
 hipError_t launch_ivf_prep_queries(const float* q, int B, const float* cents, const float* cnorm, int nlist, const IvfGroup& grp,
                                    hipStream_t s, int n_batches) {
     if (!grp.w_q8 || !grp.w_qterm || !grp.w_qnorm || !grp.w_invalid) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(ivf_coarse_mfma_kernel, dim3(1, n_batches), dim3(256), 0, s, q, B, cents, cnorm, nlist, 0, (float*)nullptr, 0, grp.mb, grp, 1, 1);
+    if (hipError_t e = coarse_lds_attr(); e != hipSuccess) return e;
+    hipLaunchKernelGGL(ivf_coarse_mfma_kernel, dim3(1, n_batches), dim3(256), kCoarseLds, s, q, B, cents, cnorm, nlist, 0, (float*)nullptr, 0, grp.mb, grp, 1, 1);
     return hipGetLastError();
 }
 
