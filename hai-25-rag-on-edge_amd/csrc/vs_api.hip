@@ -1079,7 +1079,8 @@ int ivf_group_wide_dev(vs_index* h, int lane, const float* q_dev, int nb, int B,
     W.dirty = true;
     const int sbb = vs::kIvfWideBatches;
     const vs::IvfGroup grp = wide_group(h, W, sbb, B);
-    const vs::IvfWideParams wp = wide_params(h, W, q_dev, nb, sbb, B, k, nprobe, out_d, out_i);
+    vs::IvfWideParams wp = wide_params(h, W, q_dev, nb, sbb, B, k, nprobe, out_d, out_i);
+    wp.tau_inline = 1;  // (bounds launch and scan are in this one pipeline: the scan merges a query's segment lists itself)
     stage_mark(h, 0, s);
     HIPCHK(vs::launch_ivf_coarse_pick(q_dev, B, h->d_centroids, h->d_cnorm, h->nlist, nprobe, h->metric,
                                       reinterpret_cast<float*>(W.slab + W.off_scores), (h->nlist + 63) & ~63,

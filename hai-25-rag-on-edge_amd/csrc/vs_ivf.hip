@@ -236,6 +236,9 @@ __global__ __launch_bounds__(256) void ivf_coarse_mfma_kernel(const float* __res
     };
     f32x4 d_out[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};  // the wave's scores of a tile: 16 centroids x 2 x 16 queries
     auto store_scores = [&](int t) {
+#ifdef VS_CO_NOSTORE  // (diagnostic variant: what the score stores cost)
+        if (t >= 0) return;
+#endif
 #pragma unroll
         for (int h = 0; h < 2; ++h)
             if (h * 16 + r < B) *reinterpret_cast<f32x4*>(scores + (int64_t)(h * 16 + r) * ld + t * 64 + wave * 16 + 4 * g) = d_out[h];
@@ -837,11 +840,7 @@ __device__ __forceinline__ void ivf_bounds_list_body(const IvfWideParams& p, con
 
 // A query's bound from its segments' k smallest distances (ivf_bounds_list_body): the k-th smallest of their union, with
 // a slack on fp32 rows (integer distances are exact: the bound sits right above the k-th value).  One thread per query; the launch also leaves the bound tables' counters zeroed.
-__global__ __launch_bounds__(256) void ivf_tau_combine_kernel(const IvfWideParams p) {
-    const int qg = blockIdx.x * 256 + threadIdx.x;
-    for (int c = qg; c < p.nlist; c += (int)gridDim.x * 256) p.zero[(int64_t)c * kIvfWideCntStride + 1] = 0;
-    const int batch = qg >> 5, qi = qg & 31;
-    if (batch >= p.n_batches || qi >= p.B) return;
+__device__ __forceinline__ float ivf_tau_of(const IvfWideParams& p, const int qg) {
     const int ns = p.nseg[qg];
     const float* lists = p.tk + (int64_t)qg * kBoundSegs * 16;
     int pos[kBoundSegs];
@@ -868,10 +867,20 @@ __global__ __launch_bounds__(256) void ivf_tau_combine_kernel(const IvfWideParam
                 head[sgm] = (sgm < ns && pos[sgm] < p.k) ? lists[sgm * 16 + pos[sgm]] : VS_INF;
             }
     }
-    const bool i8 = p.vecs_u8 && p.metric == 0 && p.invalid[batch] == 0;
+    const bool i8 = p.vecs_u8 && p.metric == 0 && p.invalid[qg >> 5] == 0;
     const float tb = i8 ? next_up(kth) : kth + 1e-4f * fabsf(kth) + 1e-30f;
-    p.tau[qg] = kth < VS_INF ? tb : VS_INF;
-    if (!(kth < VS_INF)) p.slow[qg] = 1;
+    return kth < VS_INF ? tb : VS_INF;  // +inf: no bound (fewer than k rows in the query's segments)
+}
+// ... as a launch: the sharded front half, whose bounds travel to the other ranks.  (An unsharded group's scan works the bound
+// out while it stages its queries, p.tau_inline: a launch of a thread per query was 5 us + a launch gap per group.)
+__global__ __launch_bounds__(256) void ivf_tau_combine_kernel(const IvfWideParams p) {
+    const int qg = blockIdx.x * 256 + threadIdx.x;
+    for (int c = qg; c < p.nlist; c += (int)gridDim.x * 256) p.zero[(int64_t)c * kIvfWideCntStride + 1] = 0;
+    const int batch = qg >> 5, qi = qg & 31;
+    if (batch >= p.n_batches || qi >= p.B) return;
+    const float t = ivf_tau_of(p, qg);
+    p.tau[qg] = t;
+    if (!(t < VS_INF)) p.slow[qg] = 1;
 }
 
 // Work plan of one super-batch (blockIdx.y), several workgroups each (see ivf_group_plan_kernel): records of bounded cost.
@@ -1143,8 +1152,21 @@ __global__ __launch_bounds__(kIvfWideThreads) void ivf_scan_wide_kernel(const Iv
     }
     for (int s = tid; s < kIvfWideSlots; s += kIvfWideThreads) {
         const int qg = qbase + min(s, nslots - 1);
-        const bool live = s < nslots && (s & 31) < p.B && p.slow[qg] == 0;  // a query without a bound goes through the slow path only
-        const float t0 = live ? p.tau[qg] : -VS_INF;
+        bool live = s < nslots && (s & 31) < p.B;
+        float t0 = -VS_INF;
+        if (p.tau_inline) {  // (uniform) the bound from the bounds launch's segment lists, see ivf_tau_of
+            if (live) {
+                t0 = ivf_tau_of(p, qg);
+                if (!(t0 < VS_INF)) {  // no bound: the slow path's (one workgroup of the super-batch says so to the ranking)
+                    live = false;
+                    t0 = -VS_INF;
+                    if (blockIdx.x == 0) p.slow[qg] = 1;
+                }
+            }
+        } else {
+            live = live && p.slow[qg] == 0;  // a query without a bound goes through the slow path only
+            if (live) t0 = p.tau[qg];
+        }
         tau_s[s] = t0;
         qn_s[s] = p.qnorm[qg];
         const int qt = p.qterm[qg];
@@ -1399,8 +1421,21 @@ __global__ __launch_bounds__(kIvfWideF32Threads) void ivf_scan_wide_f32_kernel(c
     int4 rv0 = recs[min(u, p.units_cap - 1)], rv1 = recs[min(u + nw, p.units_cap - 1)], rv2 = recs[min(u + 2 * nw, p.units_cap - 1)];
     for (int s = tid; s < kIvfWideSlots; s += kIvfWideF32Threads) {
         const int qg = qbase + min(s, nslots - 1);
-        const bool live = s < nslots && (s & 31) < p.B && p.slow[qg] == 0;  // a query without a bound goes through the slow path only
-        tau_s[s] = live ? p.tau[qg] : -VS_INF;
+        bool live = s < nslots && (s & 31) < p.B;
+        float t0 = -VS_INF;
+        if (p.tau_inline) {  // (uniform) see ivf_scan_wide_kernel
+            if (live) {
+                t0 = ivf_tau_of(p, qg);
+                if (!(t0 < VS_INF)) {
+                    t0 = -VS_INF;
+                    if (blockIdx.x == 0) p.slow[qg] = 1;
+                }
+            }
+        } else {
+            live = live && p.slow[qg] == 0;  // a query without a bound goes through the slow path only
+            if (live) t0 = p.tau[qg];
+        }
+        tau_s[s] = t0;
         qn_s[s] = p.qnorm[qg];
     }
     if (u >= n_units) rv0 = make_int4(0, 0, 0, 0);
@@ -1674,7 +1709,7 @@ hipError_t launch_ivf_wide_bounds_plan(const IvfWideParams& p, hipStream_t s, in
     if ((what & 1) && (!p.tq || p.n_batches * kMaxBatch > 0x10000 || p.n_batches * kMaxBatch > p.tq_cap)) return hipErrorInvalidValue;
     // (who pads the slot tables: the bounds' workgroups if the tables are complete when they run, i.e. with the plan beside them)
     hipLaunchKernelGGL(ivf_bounds_plan_kernel, dim3(n_plan * n_sb + n_tau), dim3(256), 0, s, p, n_plan, n_sb, n_tau == 0 || n_plan == 0 || n_sb > 16);
-    if (what & 1) hipLaunchKernelGGL(ivf_tau_combine_kernel, dim3((p.n_batches * kMaxBatch + 255) / 256), dim3(256), 0, s, p);
+    if ((what & 1) && !p.tau_inline) hipLaunchKernelGGL(ivf_tau_combine_kernel, dim3((p.n_batches * kMaxBatch + 255) / 256), dim3(256), 0, s, p);
     return hipGetLastError();
 }
 
@@ -1722,8 +1757,10 @@ __global__ __launch_bounds__(256) void ivf_wide_rank_kernel(const MergeParams m,
     const int batch = q / p.B, sb = batch / p.sb_batches;
     const int nql = (min(p.n_batches, (sb + 1) * p.sb_batches) - sb * p.sb_batches) * p.B;  // workgroups of this super-batch
     const int ql = (batch - sb * p.sb_batches) * p.B + q % p.B;
-    for (int c = ql + tid * nql; c < p.nlist; c += 256 * nql)
+    for (int c = ql + tid * nql; c < p.nlist; c += 256 * nql) {
         p.zero[sb * ivf_wide_plan_words(p.nlist) + (int64_t)c * kIvfWideCntStride] = 0;
+        if (sb == 0) p.zero[(int64_t)c * kIvfWideCntStride + 1] = 0;  // (the list's bound-table counter lives in super-batch 0's line)
+    }
     if (ql == 0 && tid == 0) p.zero[sb * ivf_wide_plan_words(p.nlist) + (int64_t)p.nlist * kIvfWideCntStride] = 0;  // the record count
     // (the words every workgroup reads: `overflow` is cleared by the next group's coarse kernel, the batches' "not byte
     // valued" flags are written as 0 or 1 there; a counter of finished workgroups here would be one contended atomic
@@ -1850,8 +1887,10 @@ __global__ __launch_bounds__(256) void ivf_wide_rank4_kernel(const MergeParams m
     const int batch = q / p.B, sb = batch / p.sb_batches;
     const int nql = (min(p.n_batches, (sb + 1) * p.sb_batches) - sb * p.sb_batches) * p.B;
     const int ql = (batch - sb * p.sb_batches) * p.B + q % p.B;
-    for (int c = ql + lane * nql; c < p.nlist; c += 64 * nql)
+    for (int c = ql + lane * nql; c < p.nlist; c += 64 * nql) {
         p.zero[sb * ivf_wide_plan_words(p.nlist) + (int64_t)c * kIvfWideCntStride] = 0;
+        if (sb == 0) p.zero[(int64_t)c * kIvfWideCntStride + 1] = 0;  // (the list's bound-table counter lives in super-batch 0's line)
+    }
 }
 
 // the queries ivf_wide_rank4_kernel left over: a fixed grid walks the list
@@ -1874,8 +1913,10 @@ __global__ __launch_bounds__(256) void ivf_wide_rank_list_kernel(const MergePara
         const int batch = q / p.B, sb = batch / p.sb_batches;
         const int nql = (min(p.n_batches, (sb + 1) * p.sb_batches) - sb * p.sb_batches) * p.B;
         const int ql = (batch - sb * p.sb_batches) * p.B + q % p.B;
-        for (int c = ql + (tid & 63) * nql; c < p.nlist; c += 64 * nql)
+        for (int c = ql + (tid & 63) * nql; c < p.nlist; c += 64 * nql) {
             p.zero[sb * ivf_wide_plan_words(p.nlist) + (int64_t)c * kIvfWideCntStride] = 0;
+            if (sb == 0) p.zero[(int64_t)c * kIvfWideCntStride + 1] = 0;  // (the list's bound-table counter lives in super-batch 0's line)
+        }
         __syncthreads();
     }
 }

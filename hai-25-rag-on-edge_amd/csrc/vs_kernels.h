@@ -341,6 +341,7 @@ struct IvfWideParams {
     int tq_cap;
     float* tk;                // [n_batches][32][kBoundSegs][16] the k smallest distances per (query, segment), ascending
     const int32_t* nseg;      // [n_batches][32]
+    int tau_inline;           // the scan works a query's bound out of tk / nseg itself (no ivf_tau_combine_kernel launch, tau unused)
     float* tau;               // [n_batches][32] bounds
     int32_t* slow;            // [n_batches][32] (pre-set to 0): no bound could be had -> exact slow path
     CandSink sink;
