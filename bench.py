@@ -605,15 +605,20 @@ def main():
                     tkey = "hbm_bytes_per_launch_fp32_rows" if rb > 512 else "hbm_bytes_per_launch"
                     if os.path.exists(ipath) and n_rows == N_BASE and nprobe == NPROBE and set(window) == {SI}:
                         itraffic = json.load(open(ipath)).get(tkey)   # (PMC figure of a launch of SI batches, profiles/README.md)
-                    frac = round(ach / HBM_PEAK_GBS, 4) if ach else None
-                    above_hbm = None
-                    if frac is not None and frac > 1.0:
-                        # Only possible where the rows stay in the Infinity Cache between launches (the 132 MB byte copy):
-                        # the algorithmic bytes then arrive faster than HBM could deliver them and a fraction of the HBM
-                        # peak says nothing -- reported as null with the ratio beside it.  On the fp32 rows (466 MB per
-                        # super-batch) the HBM roof binds and a value above 1 would mean the byte model is wrong.
-                        assert rb < 512, ("the byte model does not describe the kernel", frac)
-                        above_hbm, frac = frac, None
+                    # fp32 rows (466 MB per super-batch: no cache holds them): HBM binds, `achieved` = algorithmic bytes / time and
+                    # a fraction above 1 would mean the byte model is wrong.  Byte rows (132 MB: resident in the 256 MB
+                    # Infinity Cache from launch to launch): the algorithmic bytes are DELIVERED to the CUs, mostly not by HBM --
+                    # `delivered_gbs` (it can exceed the HBM peak) beside `achieved` / `frac` from the bytes HBM really moved
+                    # (the PMC figure of a launch of this shape, when profiles/ holds one; else null).
+                    delivered = round(ach, 1) if ach else None
+                    if rb > 512:
+                        frac = round(ach / HBM_PEAK_GBS, 4) if ach else None
+                        assert frac is None or frac <= 1.0, ("the byte model does not describe the kernel", frac)
+                        achieved = delivered
+                    else:
+                        achieved = round(itraffic / ks_launch / 1e9, 1) if (itraffic and ks_launch > 0) else None
+                        frac = round(achieved / HBM_PEAK_GBS, 4) if achieved else None
+                        assert frac is None or frac <= 1.0, ("HBM traffic above the HBM peak: the counters or the clock are wrong", frac)
                     # fp32 rows: the MFMA pipe is the nearer roof (2 * 128 flop per (query, row) pair of the launch's candidates)
                     mfma = None
                     if rb > 512 and ks_launch > 0:
@@ -621,9 +626,13 @@ def main():
                         tf = 2.0 * DIM * pairs / ks_launch / 1e12
                         mfma = {"achieved_tflops": round(tf, 1), "peak_tflops": MFMA_F32_PEAK_TFLOPS, "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4)}
                         assert mfma["frac"] <= 1.0, mfma
-                    info["roofline"] = {"bound": "hbm", "achieved": round(ach, 1) if ach else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    info["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                         "mfma_f32": mfma,
-                                        "frac": frac, "algorithmic_rate_over_hbm_peak_cache_resident": above_hbm, "traffic": itraffic,
+                                        "frac": frac,
+                                        "frac_basis": "algorithmic bytes" if rb > 512 else "measured HBM traffic (PMC); rows are Infinity-Cache resident",
+                                        "delivered_gbs": delivered,
+                                        "delivered_over_hbm_peak": round(ach / HBM_PEAK_GBS, 4) if ach else None,
+                                        "traffic": itraffic,
                                         "traffic_source": "static: profiles/traffic_ivf_list_scan.json (rocprofv3 --pmc passes, not measured in this run)",
                                         "kernel": "vs::ivf_scan_wide_kernel" if rb < 512 else "vs::ivf_scan_wide_f32_kernel",
                                         "kernel_us": round(ks_launch * 1e6, 2),
@@ -634,7 +643,7 @@ def main():
                                         "note": "one list-major pass per super-batch of 32 batches over the tiled exact int8 copy (128 B of "
                                                 "row + 4 B of row term per row); the 132 MB of rows fit the 256 MB Infinity Cache, so "
                                                 "repeated launches are served from there and the HBM counters can read below the "
-                                                "algorithmic bytes; fraction quoted against the HBM peak as the reference roof"
+                                                "algorithmic bytes: `frac` is the HBM traffic's, `delivered_over_hbm_peak` the algorithmic bytes' (can pass 1)"
                                                 if rb < 512 else "one list-major pass per super-batch of 32 batches over the fp32 rows "
                                                 "(IVFIndex.cpp:270-358's arithmetic; 512 B of row + 4 B of norm per row): the 466 MB a "
                                                 "super-batch touches do not fit the Infinity Cache, the HBM roof is the binding one"}
