@@ -1509,17 +1509,29 @@ __global__ __launch_bounds__(kIvfWideF32Threads) void ivf_scan_wide_f32_kernel(c
         const float qn = qn_s[ql];
         const float tq = live ? tau_s[ql] : -VS_INF;
         const int qg = qbase + ql;
+        // (the block's eight distances per lane, their minimum against the bound first: one ballot per block, not per value --
+        // an ordinary vector instruction costs the MFMA pipe about eight cycles, and nearly every block has no hit)
+        float d[NT][4];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d[t][j] = p.metric ? -acc[t][j] : fmaf(-2.0f, acc[t][j], qn + bn[t][j]);
+        float dmin = d[0][0];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dmin = fminf(dmin, d[t][j]);
+        if (__ballot(dmin < tq) == 0) return;
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float d = p.metric ? -acc[t][j] : fmaf(-2.0f, acc[t][j], qn + bn[t][j]);
                 const int rowj = rc.r0 + 16 * t + 4 * g + j;
-                const bool pass = d < tq && rowj < rc.r_end;
+                const bool pass = d[t][j] < tq && rowj < rc.r_end;  // (rows past the chunk's end are looked at here only)
                 const unsigned long long mask = __ballot(pass);
                 if (mask) {
                     const int pos = wbase + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
-                    if (pass && pos < p.sink.wcap) wbuf[pos] = make_int4(qg, __builtin_bit_cast(int, d), rowj + rc.td, 0);
+                    if (pass && pos < p.sink.wcap) wbuf[pos] = make_int4(qg, __builtin_bit_cast(int, d[t][j]), rowj + rc.td, 0);
                     wbase += __popcll(mask);
                 }
             }
