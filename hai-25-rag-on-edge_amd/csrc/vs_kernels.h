@@ -283,8 +283,9 @@ hipError_t launch_ivf_fill(const int32_t* gathered, long long blk_words, int B, 
 
 // ---- wide IVF pipeline: launch groups are cut into super-batches of kIvfWideBatches batches (<= 1024 queries) that
 // share ONE list-major pass: a list probed by any of them is read once and scored against all its queries (MFMA
-// column blocks of 16).  Bounds first (ivf_tau_kernel: k-th best of the first rows of the query's nearest resident
-// list), survivors to a CandSink, ranking by merge_compact_kernel -- no candidate-score arrays, no selection kernel.
+// column blocks of 16).  Bounds first (ivf_bounds_plan_kernel, list-major too: the k-th best among the first rows of the
+// query's two nearest lists), survivors to a CandSink, ranking by a wave per query -- no candidate-score arrays, no
+// selection kernel.
 constexpr int kIvfWideBatches = 32;  // batches per super-batch at most: every resident list is read once per 1024 queries
 constexpr int kIvfWideQ = kIvfWideBatches * kMaxBatch;  // query slots per super-batch
 #ifndef VS_BOUND_SEGS
