@@ -461,7 +461,8 @@ __global__ __launch_bounds__(256) void ivf_pick_kernel(const float* __restrict__
 
 // (One WAVE per query instead -- 16 scores per lane, the same bound from the 64 lane minima, ballot compaction, counting
 // rank -- was built and measured: 34.6 us per 8192 queries against this kernel's 29.3.  The selection is bound by the
-// vector instructions it issues per query, about a thousand either way, not by the workgroups' turnaround.)
+// vector instructions it issues per query, about a thousand either way, not by the workgroups' turnaround.  Two waves per query
+// (128 thread minima, 16 queries in flight per CU instead of 8): 27.2 us against 26.7 -- the same.)
 
 // ------------------------------------------------------------------------------------------------
 // IVF list scan.  One 256-thread workgroup per (query, probe) item; the four waves take
