@@ -430,6 +430,9 @@ __global__ __launch_bounds__(256) void ivf_pick_kernel(const float* __restrict__
     }
     PICK_STAMP(3);
     __syncthreads();
+#ifdef VS_PICK_NOTABLES  // (diagnostic variant: what the table entries -- 34 returning atomics per query -- cost)
+    if (nlist > 0) return;
+#endif
     if (grp.w_tq && tid < 64) {
         // the bound's tables (see ivf_bounds_list_body): the query enters itself with the first two of its probed lists
         // that hold rows, as segment 0 and 1 (looked for among the nearest 64)
