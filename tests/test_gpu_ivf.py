@@ -723,6 +723,40 @@ def test_sliced_pipeline_virtual_ranks_equal_unsharded(gpu_pkg, world, nb, B):
             sh.close()
 
 
+@pytest.mark.parametrize("world,nb,B", [(4, 37, 32), (8, 70, 20)])
+def test_sliced_pipeline_on_fp32_rows_equals_unsharded(gpu_pkg, world, nb, B):
+    """The sliced pipeline with `vs_set_precision(1)` on every shard: the front half's bounds come from the fp32 list heads,
+    the back half's scan is the fp32-rows kernel reading the exchanged bounds (not the segment lists) -- the one combination
+    of that kernel the unsharded tests do not reach.  On integer data: bit-identical to the unsharded int8-rows result."""
+    import torch
+    dev = torch.device("cuda:0")
+    base, cents, vr, off, r2o = _make_index(gpu_pkg, n=60000, nlist=256, seed=16)
+    k, nprobe = 5, 24
+    q = gpu_pkg.synth_sift(nb * B, seed=600 + nb)
+    s = torch.cuda.current_stream().cuda_stream
+    qd = torch.from_numpy(q).to(dev)
+    want_i = torch.zeros((nb * B, k), dtype=torch.int32, device=dev)
+    want_d = torch.zeros((nb * B, k), dtype=torch.float32, device=dev)
+    with gpu_pkg.IVFIndex(vectors_reordered=vr, centroids=cents, cluster_offsets=off, reorder_to_original=r2o) as ivf:
+        ivf.search_dev_multi(qd.data_ptr(), nb, B, k, nprobe, want_i.data_ptr(), want_d.data_ptr(), s)
+        torch.cuda.synchronize()
+    shards = [gpu_pkg.IVFIndex(vectors_reordered=vr, centroids=cents, cluster_offsets=off, reorder_to_original=r2o, rank=r, world=world)
+              for r in range(world)]
+    try:
+        for sh in shards:
+            sh.set_precision(1)
+        got_i = torch.full((nb * B, k), -7, dtype=torch.int32, device=dev)
+        got_d = torch.full((nb * B, k), -7.0, dtype=torch.float32, device=dev)
+        gpu_pkg.IVFIndex.search_dev_vshards(shards, qd.data_ptr(), nb, B, k, nprobe, got_i.data_ptr(), got_d.data_ptr(), s)
+        torch.cuda.synchronize()
+        assert torch.equal(got_d, want_d)
+        a, b = want_i.cpu().numpy(), got_i.cpu().numpy()
+        assert all(sorted(a[i].tolist()) == sorted(b[i].tolist()) for i in range(nb * B))
+    finally:
+        for sh in shards:
+            sh.close()
+
+
 def test_launch_groups_of_several_super_batches_and_fp32_rows(gpu_pkg):
     """(i) VSEARCH_IVF_GROUP (read when an index is created): launch groups of 128 batches = 4 super-batches per kernel
     launch must give what groups of 32 give.  (ii) vs_set_precision(1) on an IVF index: the list scan on the fp32 rows
