@@ -57,6 +57,36 @@ def test_full_probe_equals_exact(gpu_pkg):
     assert notie.mean() > 0.9 and np.array_equal(ids[notie], oi[notie])
 
 
+@pytest.mark.parametrize("nprobe", [100, 256])
+def test_large_nprobe_on_a_launch_group_of_several_super_batches(gpu_pkg, nprobe):
+    """nprobe above 64: the bound tables take a query's segments from its nearest 64 probes only, the slot tables take all
+    of them, a list is probed by hundreds of a super-batch's queries.  nprobe = nlist = 256 is the exact search: distances
+    must equal the brute-force oracle's; nprobe = 100 must equal the IVF oracle's."""
+    import torch
+    dev = torch.device("cuda:0")
+    base, cents, vr, off, r2o = _make_index(gpu_pkg, n=60000, nlist=256, seed=16)
+    nb, B, k = 40, 32, 5
+    q = gpu_pkg.synth_sift(nb * B, seed=321)
+    qd = torch.from_numpy(q).to(dev)
+    s = torch.cuda.current_stream().cuda_stream
+    with gpu_pkg.IVFIndex(vectors_reordered=vr, centroids=cents, cluster_offsets=off, reorder_to_original=r2o) as ivf:
+        got_i = torch.full((nb * B, k), -7, dtype=torch.int32, device=dev)
+        got_d = torch.zeros((nb * B, k), dtype=torch.float32, device=dev)
+        ivf.search_dev_multi(qd.data_ptr(), nb, B, k, nprobe, got_i.data_ptr(), got_d.data_ptr(), s)
+        torch.cuda.synchronize()
+    gi, gd = got_i.cpu().numpy(), got_d.cpu().numpy()
+    sub = np.r_[0:48, 32 * 20:32 * 20 + 48, 32 * 39:32 * 40]
+    if nprobe == 256:
+        _, od = oracle.search_bf(base, q[sub], k)
+        assert np.array_equal(gd[sub], od)
+    else:
+        _, od, _ = oracle.ivf_search(vr, off, r2o, cents, q[sub], k, nprobe)
+        same = np.array([np.array_equal(gd[sub][i], od[i]) for i in range(len(sub))])
+        assert same.mean() >= 0.97  # (probe sets can differ by a last-bit coarse tie, see test_matches_oracle_ivf)
+    ex = oracle.exact_int_dists(q[sub], base)
+    assert np.array_equal(np.take_along_axis(ex, gi[sub].astype(np.int64), 1).astype(np.float32), gd[sub])
+
+
 @pytest.mark.parametrize("nprobe", [1, 8, 32])
 @pytest.mark.parametrize("k", [1, 5, 10])
 def test_matches_oracle_ivf(gpu_pkg, nprobe, k):
